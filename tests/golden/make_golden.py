@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the UNCHANGED reference (/root/reference) in this container.
+
+Run (build container only; /root/reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Outputs small ``.npz`` fixtures next to this file.  Only inputs / expected outputs are stored (data),
+never reference source.  Stubs (oracle-only):
+  * ``inflated_resnet.load_pretrained_2D_weights`` -> no-op (it would download ResNet-50 weights),
+  * ``models.central.ntu.Visual/Skeleton`` -> parameter-less modules that serve precomputed pooled taps
+    through the reference's unchanged ``forward`` slicing,
+  * empty checkpoint files for ``ske_cp`` / ``rgb_cp``.
+Everything on the path (``train_sampled_models``, ``train_ntu_track_acc``,
+``Searchable_Skeleton_Image_Net``, ``LRCosineAnnealingScheduler``, ``tools.*``) runs byte-for-byte unchanged.
+"""
+import contextlib
+import io
+import os
+import re
+import sys
+import tempfile
+from types import SimpleNamespace
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(1, REPO)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import models.auxiliary.inflated_resnet as ir
+
+ir.load_pretrained_2D_weights = lambda *a, **k: None
+import models.central.ntu as cntu
+
+
+class FeatVisual(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+
+    def forward(self, x):
+        return (None, x["v0"], x["v1"], x["v2"], x["v3"], x["vlogit"])
+
+
+class FeatSkel(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+
+    def forward(self, x):
+        return [x["s0"], x["s1"], x["s2"], x["s3"]], x["slogit"]
+
+
+cntu.Visual, cntu.Skeleton = FeatVisual, FeatSkel
+import models.search.ntu_searchable as ntu
+import models.search.train_searchable.ntu as tr
+import models.auxiliary.scheduler as sc
+import models.search.tools as tools
+
+from oracle import np_oracle as O
+
+torch.set_num_threads(4)
+TMP = tempfile.mkdtemp()
+torch.save({}, os.path.join(TMP, "ske"))
+torch.save({}, os.path.join(TMP, "rgb"))
+
+
+class D(dict):
+    def to(self, dev):
+        return self
+
+    def size(self, i):
+        return next(iter(self.values())).size(i)
+
+
+class ListLoader:
+    """Unshuffled loader over a feature table: yields {'rgb','ske','label'} like datasets/ntu.py:254."""
+
+    def __init__(self, table, B):
+        self.t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in table.items()}
+        self.B = B
+        self.dataset = range(len(table["label"]))
+
+    def __iter__(self):
+        N = len(self.dataset)
+        for i in range(0, N, self.B):
+            sl = slice(i, min(i + self.B, N))
+            rgb = D({k: self.t[k][sl] for k in ("v0", "v1", "v2", "v3", "vlogit")})
+            ske = D({k: self.t[k][sl] for k in ("s0", "s1", "s2", "s3", "slogit")})
+            yield {"rgb": rgb, "ske": ske, "label": self.t["label"][sl]}
+
+
+def mkargs(**kw):
+    a = dict(vid_len=(8, 32), num_outputs=60, drpt=0.0, inner_representation_size=16, batchnorm=True,
+             alphas=False, multitask=False, weightsharing=False, batchsize=16, eta_max=1e-3, eta_min=1e-6,
+             Ti=1, Tm=2, use_dataparallel=False, verbose=False, epochs=2, checkpointdir=TMP, ske_cp="ske",
+             rgb_cp="rgb")
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def table(N, seed, with_logits=True, snr=0.3):
+    return O.synth_table(N, seed, snr=snr, with_logits=with_logits) if with_logits else \
+        dict(O.synth_table(N, seed, snr=snr), vlogit=np.zeros((N, 60), np.float32),
+             slogit=np.zeros((N, 60), np.float32))
+
+
+def hyper_of(args):
+    return O.Hyper(R=args.inner_representation_size, C=args.num_outputs, B=args.batchsize,
+                   bn=args.batchnorm, drpt=args.drpt, alphas=args.alphas, multitask=args.multitask,
+                   eta_max=args.eta_max, eta_min=args.eta_min, Ti=args.Ti, Tm=args.Tm, epochs=args.epochs)
+
+
+def load_det(model, conf, args, seed, perturb_bn=False):
+    """Overwrite the reference module's central params with the hash-generated ones."""
+    p = O.init_params(conf, hyper_of(args), seed, perturb_bn=perturb_bn)
+    sd = model.state_dict()
+    for k, v in p.items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k].copy_(torch.from_numpy(v))
+    return p
+
+
+def central_sd(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()
+            if k.startswith(("alphas", "fusion_layers", "central_classifier"))}
+
+
+def feats_of(t, sl):
+    rgb = D({k: torch.from_numpy(t[k][sl]) for k in ("v0", "v1", "v2", "v3", "vlogit")})
+    ske = D({k: torch.from_numpy(t[k][sl]) for k in ("s0", "s1", "s2", "s3", "slogit")})
+    return rgb, ske
+
+
+def put(out, key, arr):
+    """Small tensors in full; big ones as a strided sample + float64 sum."""
+    arr = np.asarray(arr)
+    if arr.size <= 4096:
+        out[key] = arr
+    else:
+        out[key + "#s"] = O.sample_view(arr)
+        out[key + "#sum"] = np.array(arr.astype(np.float64).sum())
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+# ------------------------------------------------------------------ G1 scheduler
+def g1():
+    out = {}
+    for j, (Ti, Tm, nbpe, n) in enumerate([(1, 2, 4.0, 40), (1, 2, 500.0, 1600), (5, 2, 625.0, 2000),
+                                           (1, 2, 6.25, 64)]):
+        s = sc.LRCosineAnnealingScheduler(1e-3, 1e-6, Ti, Tm, nbpe)
+        seq = []
+        for _ in range(n):
+            s.step()
+            seq.append(s.eta)
+        out[f"cfg{j}"] = np.array([Ti, Tm, nbpe, n], np.float64)
+        out[f"eta{j}"] = np.array(seq, np.float64)
+    save("g1_scheduler.npz", **out)
+
+
+# ------------------------------------------------------------------ G2/G3/G9 forward, loss, grads
+CONFS = {
+    "c4": [[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]],
+    "c0": [[2, 2, 0], [1, 0, 1], [3, 2, 0], [3, 1, 1]],
+    "l1": [[0, 0, 0]],
+    "l2": [[2, 3, 1], [0, 2, 2]],
+    "l3": [[1, 0, 2], [3, 3, 1], [0, 1, 0]],
+}
+
+
+VARIANTS = [
+    ("bn_train", dict(batchnorm=True, drpt=0.0), True),
+    ("bn_eval", dict(batchnorm=True, drpt=0.0), False),
+    ("bndrop_eval", dict(batchnorm=True, drpt=0.5), False),
+    ("drop_eval", dict(batchnorm=False, drpt=0.5), False),
+    ("alpha_bn_train", dict(batchnorm=True, drpt=0.0, alphas=True), True),
+    ("mt_bn_train", dict(batchnorm=True, drpt=0.0, multitask=True), True),
+]
+
+
+def g23():
+    """table = synth_table(16, 11, snr=0.3, with_logits=True); params = init_params(conf, hp, seed, perturb_bn=True)."""
+    out = {}
+    t = table(16, 11)
+    names = []
+    for ci, (cname, conf) in enumerate(CONFS.items()):
+        for vi, (vname, kw, train) in enumerate(VARIANTS):
+            for R in (16, 128):
+                if R == 128 and cname not in ("c4", "l2"):
+                    continue
+                seed = 1000 + 100 * ci + 10 * vi + (R == 128)
+                args = mkargs(inner_representation_size=R, **kw)
+                model = ntu.Searchable_Skeleton_Image_Net(args, np.array(conf))
+                load_det(model, conf, args, seed, perturb_bn=True)
+                model.train(train)
+                pre = f"{cname}/{vname}/{R}/"
+                names.append(f"{cname}/{vname}/{R}/{seed}")
+                rgb, ske = feats_of(t, slice(0, 16))
+                label = torch.from_numpy(t["label"][:16])
+                output = model((rgb, ske))
+                crit = torch.nn.CrossEntropyLoss()
+                if args.multitask:
+                    preds = torch.max(sum(output), 1)[1]
+                    loss = crit(output[0], label) + crit(output[1], label) + crit(output[2], label)
+                    out[pre + "loss_central"] = np.array(crit(output[0], label).item())
+                    logits = output[0]
+                else:
+                    preds = torch.max(output, 1)[1]
+                    loss = crit(output, label)
+                    logits = output
+                out[pre + "logits"] = logits.detach().numpy()
+                out[pre + "loss"] = np.array(loss.item())
+                out[pre + "preds"] = preds.numpy()
+                if train:
+                    loss.backward()
+                    for n_, p in model.named_parameters():
+                        if p.grad is not None:
+                            put(out, pre + "grad/" + n_, p.grad.numpy().copy())
+                    for k, v in central_sd(model).items():
+                        if "running" in k:
+                            out[pre + "after/" + k] = v
+    out["names"] = np.array(names)
+    save("g23_forward_backward.npz", **out)
+
+
+# ------------------------------------------------------------------ G4/G5/G6 deterministic trajectory
+class Capture:
+    """searchable_type factory (it is a plain callable, ntu_searchable.py:44): constructs the reference
+    module, overwrites the central params with the hash-generated ones (seed = base + index)."""
+
+    def __init__(self, seed0, perturb_bn=False):
+        self.seed0 = seed0
+        self.models = []
+        self.perturb_bn = perturb_bn
+
+    def __call__(self, args, conf):
+        m = ntu.Searchable_Skeleton_Image_Net(args, conf)
+        load_det(m, conf, args, self.seed0 + len(self.models), perturb_bn=self.perturb_bn)
+        self.models.append(m)
+        return m
+
+
+HIST_RE = r"(train|dev) Loss: ([0-9.eE+naninf-]+) Acc: ([0-9.eE+naninf-]+)"
+
+
+def parse_hist(text):
+    return np.array([(0 if m.group(1) == "train" else 1, float(m.group(2)), float(m.group(3)))
+                     for m in re.finditer(HIST_RE, text)], np.float64)
+
+
+def run_tsm(confs, args, loaders, seed0):
+    cap = Capture(seed0)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        accs = ntu.train_sampled_models([np.array(c) for c in confs], cap, loaders, args, "cpu")
+    return [float(a) for a in accs], cap, parse_hist(buf.getvalue())
+
+
+def g456():
+    """Deterministic mode (drpt=0 + BN, unshuffled).  train = synth_table(64, 21, snr=0.3),
+    dev = synth_table(48, 22, snr=0.3), params = init_params(conf, hp, 5)."""
+    out = {}
+    ttr, tdv = table(64, 21, with_logits=False), table(48, 22, with_logits=False)
+    for cname, R in (("c4", 16), ("c4", 128), ("l2", 16)):
+        conf = np.array(CONFS[cname])
+        args = mkargs(inner_representation_size=R, batchnorm=True, drpt=0.0, epochs=3, batchsize=16)
+        model = ntu.Searchable_Skeleton_Image_Net(args, conf)
+        load_det(model, conf, args, 5)
+        pre = f"{cname}/{R}/"
+        opt = torch.optim.Adam(model.central_params(), lr=args.eta_max, weight_decay=1e-4)
+        sched = sc.LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, 64 / 16)
+        crit = torch.nn.CrossEntropyLoss()
+        # replica of the train-phase body of train_ntu_track_acc (:46-69) to dump state after 1,2,10 steps
+        model.train(True)
+        step = 0
+        losses = []
+        for ep in range(3):
+            for data in ListLoader(ttr, 16):
+                opt.zero_grad()
+                output = model((data["rgb"], data["ske"]))
+                loss = crit(output, data["label"])
+                sched.step()
+                sched.update_optimizer(opt)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+                step += 1
+                if step in (1, 2, 10):
+                    for k, v in central_sd(model).items():
+                        if "num_batches" not in k:
+                            put(out, pre + f"step{step}/p/" + k, v)
+                    name_of = {id(p): n for n, p in model.named_parameters()}
+                    for p, st in opt.state.items():
+                        put(out, pre + f"step{step}/m/" + name_of[id(p)], st["exp_avg"].numpy().copy())
+                        put(out, pre + f"step{step}/v/" + name_of[id(p)], st["exp_avg_sq"].numpy().copy())
+        out[pre + "losses"] = np.array(losses)
+        # the unchanged train_sampled_models -> train_ntu_track_acc from the same init
+        accs, cap, hist = run_tsm([conf], args, {"train": ListLoader(ttr, 16), "dev": ListLoader(tdv, 16)}, 5)
+        out[pre + "best_acc"] = np.array(accs[0])
+        out[pre + "hist"] = hist
+        for k, v in central_sd(cap.models[0]).items():   # best-epoch weights restored (:86)
+            if "num_batches" not in k:
+                put(out, pre + "final/" + k, v)
+    save("g456_trajectory.npz", **out)
+
+
+# ------------------------------------------------------------------ G7 train_sampled_models on 4 confs
+def g7():
+    """train = synth_table(256, 31, snr=0.5), dev = synth_table(128, 32, snr=0.5); params seed 9+i."""
+    out = {}
+    ttr, tdv = table(256, 31, with_logits=False, snr=0.5), table(128, 32, with_logits=False, snr=0.5)
+    confs = [CONFS["l1"], CONFS["l2"], CONFS["l3"], CONFS["c4"]]
+    for B in (16, 20):      # 20: ragged last batch (256 = 12*20+16, 128 = 6*20+8)
+        args = mkargs(inner_representation_size=16, batchnorm=True, drpt=0.0, epochs=3, batchsize=B)
+        accs, cap, hist = run_tsm(confs, args, {"train": ListLoader(ttr, B), "dev": ListLoader(tdv, B)}, 9)
+        out[f"B{B}/accs"] = np.array(accs)
+        out[f"B{B}/hist"] = hist
+    for i in range(4):
+        out[f"conf{i}"] = np.array(confs[i])
+    # multitask variant through train_ntu_track_acc directly (found-script style, main_found_ntu.py:121)
+    ttr2, tdv2 = table(256, 31, with_logits=True, snr=0.5), table(128, 32, with_logits=True, snr=0.5)
+    args = mkargs(inner_representation_size=16, batchnorm=True, drpt=0.0, epochs=3, batchsize=16, multitask=True)
+    conf = np.array(CONFS["c0"])
+    model = ntu.Searchable_Skeleton_Image_Net(args, conf)
+    load_det(model, conf, args, 13)
+    opt = torch.optim.Adam(model.central_params(), lr=args.eta_max, weight_decay=1e-4)
+    sched = sc.LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, 256 / 16)
+    crits = [torch.nn.CrossEntropyLoss()] * 3
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        acc = tr.train_ntu_track_acc(model, crits, opt, sched,
+                                     {"train": ListLoader(ttr2, 16), "dev": ListLoader(tdv2, 16)},
+                                     {"train": 256, "dev": 128}, device="cpu", num_epochs=3, multitask=True)
+    out["mt_acc"] = np.array(float(acc))
+    out["mt_hist"] = parse_hist(buf.getvalue())
+    # alphas variant
+    args = mkargs(inner_representation_size=16, batchnorm=True, drpt=0.0, epochs=3, batchsize=16, alphas=True)
+    accs, cap, hist = run_tsm([CONFS["l3"]], args, {"train": ListLoader(ttr, 16), "dev": ListLoader(tdv, 16)}, 21)
+    out["alpha_acc"] = np.array(accs[0])
+    out["alpha_hist"] = hist
+    out["alpha_final"] = np.array([cap.models[0].state_dict()[f"alphas.{i}.alpha_x"].item() for i in range(3)])
+    save("g7_population.npz", **out)
+
+
+# ------------------------------------------------------------------ G8 controller-side pins
+def g8():
+    out = {}
+    out["layer_confs"] = np.array(ntu.get_possible_layer_configurations(0))
+    a = SimpleNamespace(initial_temperature=10.0, final_temperature=0.2, temperature_decay=4.0)
+    out["temperature"] = np.array([tools.compute_temperature(i, a) for i in range(12)])
+    merged0 = tools.merge_unfolded_with_sampled([], ntu.get_possible_layer_configurations(0), 0)
+    out["merged0"] = np.array(merged0)
+    np.random.seed(0)
+    accs = np.linspace(0.1, 0.9, len(merged0))
+    samp = tools.sample_k_configurations(merged0, accs, 5, 10.0)
+    out["sampled0"] = np.array(samp)
+    merged1 = tools.merge_unfolded_with_sampled(samp, ntu.get_possible_layer_configurations(1), 1)
+    out["merged1"] = np.array(merged1)
+    np.random.seed(1)
+    samp1 = tools.sample_k_configurations(merged1, np.linspace(0.2, 0.8, len(merged1)), 5, 2.5)
+    out["sampled1"] = np.array(samp1)
+    merged1b = tools.merge_unfolded_with_sampled(samp1, ntu.get_possible_layer_configurations(0), 0)
+    out["merged1b"] = np.array(merged1b)
+    save("g8_controller.npz", **out)
+
+
+# ------------------------------------------------------------------ G10 stochastic e2e statistics
+def g10():
+    """Dropout on, shuffled order: best dev acc over seeds (the reference's own seed noise).
+    set A (search defaults): R=16, no BN, drpt 0.5, snr 1.0;  set B (config-2 like): R=128, BN, drpt 0.5, snr 0.15.
+    train = synth_table(2048, 1, snr), dev = synth_table(2048, 2, snr)."""
+    out = {}
+    N, Nd = 2048, 2048
+
+    class ShuffleLoader(ListLoader):
+        def __iter__(self):
+            N = len(self.dataset)
+            perm = torch.randperm(N)
+            for i in range(0, N, self.B):
+                sl = perm[i:i + self.B]
+                rgb = D({k: self.t[k][sl] for k in ("v0", "v1", "v2", "v3", "vlogit")})
+                ske = D({k: self.t[k][sl] for k in ("s0", "s1", "s2", "s3", "slogit")})
+                yield {"rgb": rgb, "ske": ske, "label": self.t["label"][sl]}
+
+    for tag, snr, R, bn, confs, nseed in (("A", 1.0, 16, False, [CONFS["c4"], CONFS["l1"], CONFS["l2"]], 12),
+                                          ("B", 0.15, 128, True, [CONFS["c4"]], 8)):
+        ttr, tdv = table(N, 1, with_logits=False, snr=snr), table(Nd, 2, with_logits=False, snr=snr)
+        out[tag + "/meta"] = np.array([N, Nd, snr, R, 16, 3, int(bn), 0.5])  # N,Ndev,snr,R,B,epochs,bn,drpt
+        args = mkargs(inner_representation_size=R, batchnorm=bn, drpt=0.5, epochs=3, batchsize=16)
+        loaders = {"train": ShuffleLoader(ttr, 16), "dev": ListLoader(tdv, 16)}
+        allacc = []
+        for seed in range(nseed):
+            torch.manual_seed(100 + seed)                  # dropout + shuffle streams of the reference
+            accs, _, _ = run_tsm(confs, args, loaders, 1000 + 10 * seed)
+            allacc.append(accs)
+            print("g10", tag, "seed", seed, accs, flush=True)
+        out[tag + "/accs"] = np.array(allacc)
+        for i, c in enumerate(confs):
+            out[tag + f"/conf{i}"] = np.array(c)
+    save("g10_stochastic.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g10"]
+    for w in which:
+        globals()[w]()

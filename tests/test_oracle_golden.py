@@ -1,0 +1,185 @@
+"""Pins the numpy oracle (oracle/np_oracle.py) against golden vectors produced by the UNCHANGED
+reference under torch 2.10 (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+
+CONFS = {
+    "c4": [[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]],
+    "c0": [[2, 2, 0], [1, 0, 1], [3, 2, 0], [3, 1, 1]],
+    "l1": [[0, 0, 0]],
+    "l2": [[2, 3, 1], [0, 2, 2]],
+    "l3": [[1, 0, 2], [3, 3, 1], [0, 1, 0]],
+}
+VARIANTS = {
+    "bn_train": (dict(bn=True, drpt=0.0), True),
+    "bn_eval": (dict(bn=True, drpt=0.0), False),
+    "bndrop_eval": (dict(bn=True, drpt=0.5), False),
+    "drop_eval": (dict(bn=False, drpt=0.5), False),
+    "alpha_bn_train": (dict(bn=True, drpt=0.0, alphas=True), True),
+    "mt_bn_train": (dict(bn=True, drpt=0.0, multitask=True), True),
+}
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def check(g, key, arr, rtol, atol, scale_atol=0.0, loose_atol=None):
+    """scale_atol: extra absolute tolerance as a fraction of max|expected| (fp32 cancellation noise
+    in BN-backward is relative to the tensor's scale, not the element).
+    loose_atol: Adam normalises by sqrt(v), so an element whose gradient is at round-off level moves
+    by up to ~lr per step in either direction; <=3% of the elements may miss the tight tolerance
+    but every element must meet this loose one."""
+    full = key in g
+    want = g[key] if full else g[key + "#s"]
+    got = np.asarray(arr) if full else O.sample_view(arr)
+    atol = atol + scale_atol * float(np.abs(want).max())
+    if loose_atol is None:
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=key)
+    else:
+        bad = np.abs(got - want) > atol + rtol * np.abs(want)
+        assert bad.mean() <= 0.03, (key, bad.mean())
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=loose_atol, err_msg=key)
+    if not full:
+        np.testing.assert_allclose(np.asarray(arr, np.float64).sum(), g[key + "#sum"], rtol=2e-3,
+                                   atol=atol * arr.size ** 0.5, err_msg=key + "#sum")
+
+
+# ------------------------------------------------------------------ G1
+def test_scheduler_known_answers(golden_dir):
+    g = load(golden_dir, "g1_scheduler.npz")
+    for j in range(4):
+        Ti, Tm, nbpe, n = g[f"cfg{j}"]
+        seq = O.eta_sequence(1e-3, 1e-6, Ti, Tm, nbpe, int(n))
+        np.testing.assert_allclose(seq, g[f"eta{j}"], rtol=1e-12, atol=0)
+    # SURVEY §3.3 known answer
+    seq = O.eta_sequence(1e-3, 1e-6, 1, 2, 4.0, 6)
+    np.testing.assert_allclose(seq, [1e-3, 8.537e-4, 5.005e-4, 1.473e-4, 1e-6, 1e-3], rtol=1e-3)
+
+
+# ------------------------------------------------------------------ G2/G3/G9
+def test_forward_loss_grads(golden_dir):
+    g = load(golden_dir, "g23_forward_backward.npz")
+    t = O.synth_table(16, 11, snr=0.3, with_logits=True)
+    labels = t["label"]
+    n = 0
+    for name in g["names"]:
+        cname, vname, R, seed = str(name).split("/")
+        R, seed = int(R), int(seed)
+        kw, train = VARIANTS[vname]
+        hp = O.Hyper(R=R, B=16, **kw)
+        conf = np.array(CONFS[cname])
+        params = O.init_params(conf, hp, seed, perturb_bn=True)
+        pre = f"{cname}/{vname}/{R}/"
+        logits, cache = O.forward(params, conf, hp, t, train)
+        np.testing.assert_allclose(logits, g[pre + "logits"], rtol=2e-4, atol=2e-5, err_msg=pre)
+        loss, dlog, preds = O.ce_loss(logits, labels)
+        if hp.multitask:
+            np.testing.assert_allclose(loss, g[pre + "loss_central"], rtol=1e-5)
+            l3 = loss + O.ce_loss(t["vlogit"], labels)[0] + O.ce_loss(t["slogit"], labels)[0]
+            np.testing.assert_allclose(l3, g[pre + "loss"], rtol=1e-5)
+            preds = O.predict(logits + t["vlogit"] + t["slogit"])
+        else:
+            np.testing.assert_allclose(loss, g[pre + "loss"], rtol=1e-5)
+        assert np.array_equal(preds, g[pre + "preds"]), pre
+        if train:
+            grads = O.backward(params, hp, cache, dlog)
+            for k, v in grads.items():
+                check(g, pre + "grad/" + k, v, rtol=2e-3, atol=2e-7, scale_atol=1e-3)
+            O.bn_update_running(params, hp, cache)
+            for i in range(len(conf)):
+                for s in ("running_mean", "running_var"):
+                    k = f"fusion_layers.{i}.2.{s}"
+                    np.testing.assert_allclose(params[k], g[pre + "after/" + k], rtol=1e-5, atol=1e-6)
+        n += 1
+    assert n >= 40
+
+
+# ------------------------------------------------------------------ G4/G5/G6
+@pytest.mark.parametrize("cname,R", [("c4", 16), ("c4", 128), ("l2", 16)])
+def test_deterministic_trajectory(golden_dir, cname, R):
+    g = load(golden_dir, "g456_trajectory.npz")
+    ttr, tdv = O.synth_table(64, 21, snr=0.3), O.synth_table(48, 22, snr=0.3)
+    conf = np.array(CONFS[cname])
+    hp = O.Hyper(R=R, B=16, bn=True, drpt=0.0, epochs=3)
+    params = O.init_params(conf, hp, 5)
+    pre = f"{cname}/{R}/"
+    losses = []
+
+    def on_step(gstep, p, st, loss):
+        losses.append(loss)
+        step = gstep + 1
+        if step in (1, 2, 10):
+            for k, v in p.items():
+                if k.startswith("alphas"):
+                    continue
+                check(g, pre + f"step{step}/p/" + k, v, rtol=1e-4, atol=2e-6 * step, loose_atol=1e-3 * step)
+            for k in st.m:
+                check(g, pre + f"step{step}/m/" + k, st.m[k], rtol=2e-3, atol=1e-9, scale_atol=2e-3, loose_atol=1.0)
+                check(g, pre + f"step{step}/v/" + k, st.v[k], rtol=4e-3, atol=1e-14, scale_atol=2e-3, loose_atol=1.0)
+
+    hist = []
+    best = O.train_candidate(conf, hp, params, ttr, tdv, history=hist, on_step=on_step)
+    np.testing.assert_allclose(losses, g[pre + "losses"], rtol=2e-4)
+    ghist = g[pre + "hist"]      # rows: (phase, loss, acc) printed with 4 decimals by the reference
+    for ep, h in enumerate(hist):
+        tr_row, dv_row = ghist[2 * ep], ghist[2 * ep + 1]
+        assert abs(h["train_loss"] - tr_row[1]) < 2e-4 and abs(h["train_acc"] - tr_row[2]) < 1e-4
+        assert abs(h["dev_loss"] - dv_row[1]) < 2e-4 and abs(h["dev_acc"] - dv_row[2]) < 1e-4
+    assert best == pytest.approx(float(g[pre + "best_acc"]), abs=1e-12)
+
+
+# ------------------------------------------------------------------ G7
+@pytest.mark.parametrize("B", [16, 20])
+def test_population_accuracies(golden_dir, B):
+    g = load(golden_dir, "g7_population.npz")
+    ttr, tdv = O.synth_table(256, 31, snr=0.5), O.synth_table(128, 32, snr=0.5)
+    confs = [g[f"conf{i}"] for i in range(4)]
+    hp = O.Hyper(R=16, B=B, bn=True, drpt=0.0, epochs=3)
+    accs = O.train_sampled_models(confs, hp, ttr, tdv, init_seed=9)
+    np.testing.assert_allclose(accs, g[f"B{B}/accs"], atol=1e-12)
+
+
+def test_multitask_and_alphas_runs(golden_dir):
+    g = load(golden_dir, "g7_population.npz")
+    ttr = O.synth_table(256, 31, snr=0.5, with_logits=True)
+    tdv = O.synth_table(128, 32, snr=0.5, with_logits=True)
+    hp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=3, multitask=True)
+    conf = np.array(CONFS["c0"])
+    hist = []
+    acc = O.train_candidate(conf, hp, O.init_params(conf, hp, 13), ttr, tdv, history=hist)
+    assert acc == pytest.approx(float(g["mt_acc"]), abs=1e-12)
+    for ep, h in enumerate(hist):       # printed accuracies use the summed-logit argmax
+        assert abs(h["train_acc"] - g["mt_hist"][2 * ep][2]) < 1e-4
+        assert abs(h["dev_acc"] - g["mt_hist"][2 * ep + 1][2]) < 1e-4
+    hp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=3, alphas=True)
+    conf = np.array(CONFS["l3"])
+    params = O.init_params(conf, hp, 21)
+    t1, t2 = O.synth_table(256, 31, snr=0.5), O.synth_table(128, 32, snr=0.5)
+    acc = O.train_candidate(conf, hp, params, t1, t2)
+    assert acc == pytest.approx(float(g["alpha_acc"]), abs=1e-12)
+    got = [float(params[f"alphas.{i}.alpha_x"][0]) for i in range(3)]
+    np.testing.assert_allclose(got, g["alpha_final"], rtol=2e-3, atol=1e-6)
+
+
+# ------------------------------------------------------------------ G8
+def test_layer_configurations(golden_dir):
+    g = load(golden_dir, "g8_controller.npz")
+    assert np.array_equal(np.array(O.get_possible_layer_configurations(0)), g["layer_confs"])
+    assert len(O.get_possible_layer_configurations(2)) == 32
+
+
+def test_illegal_variant_raises():
+    with pytest.raises(ValueError):
+        O.Hyper(bn=False, drpt=0.0).check()
+
+
+def test_dropout_mask_rate():
+    keep = O.dropout_keep(7, 3, 1, 64, 128, 0.5)
+    assert abs(keep.mean() - 0.5) < 0.03
+    keep2 = O.dropout_keep(7, 4, 1, 64, 128, 0.5)
+    assert (keep != keep2).mean() > 0.4
