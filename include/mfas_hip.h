@@ -1,0 +1,125 @@
+/* mfas_hip.h — C ABI of the MI355X-native MFAS inner candidate-training engine.
+ *
+ * The reference (jperezrua/mfas) has no native/FFI layer: its hot path is Python calling PyTorch.
+ * These entry points are what a binding for that path replaces (reference file:line cited per
+ * function).  Plain pointers and sizes only; every tensor pointer is a DEVICE pointer owned by the
+ * caller unless stated otherwise; functions return 0 on success or a negative MFAS_E* code and never
+ * throw across the boundary.  One population handle is driven by one host thread on one HIP stream.
+ */
+#ifndef MFAS_HIP_H
+#define MFAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFAS_OK 0
+#define MFAS_EINVAL -1   /* bad argument / unsupported hyper-parameter combination */
+#define MFAS_EHIP -2     /* a HIP runtime call failed; see mfas_last_error() */
+#define MFAS_ENOMEM -3
+
+#define MFAS_MAX_CELLS 4 /* max_fusions (main_searchable_ntu.py:39) */
+
+#define MFAS_DT_F32 0
+#define MFAS_DT_BF16 1
+#define MFAS_DT_F16 2
+
+/* The `args` fields the path reads (models/search/ntu_searchable.py:28-84,200-292) plus the Adam
+ * constants fixed at ntu_searchable.py:65 (weight_decay=1e-4, torch defaults otherwise). */
+typedef struct mfas_hyper {
+    int32_t R;          /* args.inner_representation_size */
+    int32_t C;          /* args.num_outputs */
+    int32_t B;          /* args.batchsize */
+    int32_t bn;         /* args.batchnorm */
+    int32_t alphas;     /* args.alphas */
+    int32_t multitask;  /* args.multitask: argmax over central+visual+skeleton logits */
+    double drpt;        /* args.drpt (<=1e-10: no Dropout module) */
+    double wd, beta1, beta2, adam_eps, bn_eps, bn_momentum;
+    int32_t s_sizes[4]; /* skeleton tap widths (ntu_searchable.py:291) */
+    int32_t v_sizes[4]; /* visual tap widths   (ntu_searchable.py:292) */
+} mfas_hyper;
+
+/* Pooled feature table = what Visual/Skeleton.forward + GlobalPooling2D hand to the fusion net
+ * (models/central/ntu.py:35-50,129-183; ntu_searchable.py:211-225) for N samples, plus labels
+ * (datasets/ntu.py:254).  Row-major (N, width) arrays. */
+typedef struct mfas_table {
+    const void* s[4];
+    const void* v[4];
+    const float* vlogit; /* (N, C) unimodal logits for multitask, or NULL */
+    const float* slogit;
+    const int32_t* label; /* (N) in [0, C) */
+    int64_t N;
+    int32_t dtype; /* MFAS_DT_* of s[]/v[] */
+    int32_t _pad;
+} mfas_table;
+
+/* Per-epoch statistics train_ntu_track_acc accumulates (train_searchable/ntu.py:72-79). */
+typedef struct mfas_epoch_stats {
+    double train_loss_sum; /* sum over samples of the CE loss (running_loss) */
+    double dev_loss_sum;
+    int64_t train_corrects; /* running_corrects */
+    int64_t dev_corrects;
+} mfas_epoch_stats;
+
+typedef struct mfas_population mfas_population; /* opaque; owns its device workspace */
+
+const char* mfas_last_error(void);
+int mfas_version(void);
+
+/* Replaces the model/optimizer construction half of train_sampled_models' population loop
+ * (ntu_searchable.py:38-72): K candidates, confs[k][cell][{ske_tap, vis_tap, nonlinearity}],
+ * n_cells[k] rows used.  drop_seeds[k] seeds candidate k's dropout stream (NULL: 0..K-1).
+ * chunk_cols: feature-column chunk per workgroup (0 = auto). */
+int mfas_population_create(const mfas_hyper* hp, const int32_t* confs /* K*4*3 */,
+                           const int32_t* n_cells /* K */, const uint32_t* drop_seeds, int32_t K,
+                           int32_t device, void* hip_stream, int32_t chunk_cols,
+                           mfas_population** out);
+void mfas_population_destroy(mfas_population* pop);
+
+/* Number of floats of candidate k's central parameters in reference state_dict order:
+ * alphas.i.alpha_x (L), then per cell fusion_layers.i.0.weight (R x K_i row-major), .0.bias (R),
+ * [.2.weight, .2.bias, .2.running_mean, .2.running_var (R each) if bn], then
+ * central_classifier.weight (C x R), central_classifier.bias (C)   (ntu_searchable.py:191-200). */
+int64_t mfas_population_param_count(const mfas_population* pop, int32_t k);
+
+/* Load / read back candidate k's parameters (device float buffers in the order above).
+ * plane 0 = parameters, 1 = Adam exp_avg, 2 = Adam exp_avg_sq.  set() also zeroes the Adam state
+ * and the step counter (a fresh torch.optim.Adam, ntu_searchable.py:65). */
+int mfas_population_set_params(mfas_population* pop, int32_t k, const float* flat);
+int mfas_population_get_params(mfas_population* pop, int32_t k, int32_t plane, float* flat);
+
+/* Device-side PyTorch-default-shaped init (U(+-1/sqrt(fan_in)), BN gamma=1/beta=0/rm=0/rv=1,
+ * alpha = 0.1*noise) from the hash generator documented in oracle/np_oracle.py:init_params. */
+int mfas_population_init(mfas_population* pop, const uint32_t* seeds /* K, host */);
+
+/* Replaces train_ntu_track_acc (train_searchable/ntu.py:14-89) for the whole population in lockstep:
+ * for each epoch: train over `train` in the given sample order (order: device int32 [epochs][N_train],
+ * NULL = sequential), then evaluate `dev`.  step_scalars: HOST float2 per train step
+ * {lr_t/(1-beta1^t), sqrt(1-beta2^t)} (scheduler.py:25-46 + torch Adam bias corrections).
+ * max_steps >= 0 stops after that many train steps of the first epoch (debug/known-answer tests;
+ * dev evaluation is skipped).  stats: HOST [K][epochs].  status: HOST [K], 1 = non-finite loss seen.
+ * snapshot_best != 0 keeps the best-dev-epoch parameters and restores them at the end (:82-86). */
+int mfas_population_train(mfas_population* pop, const mfas_table* train, const mfas_table* dev,
+                          const int32_t* order, const float* step_scalars, int32_t epochs,
+                          int64_t max_steps, int32_t snapshot_best, mfas_epoch_stats* stats,
+                          int32_t* status);
+
+/* Replaces Searchable_Skeleton_Image_Net.forward in eval mode (ntu_searchable.py:206-247) for
+ * candidate k on rows [row0, row0+nrows) of a table: writes logits (nrows, C) (device, row-major);
+ * and test_ntu_track_acc (train_searchable/ntu.py:92-125) when corrects != NULL (HOST int64). */
+int mfas_population_forward(mfas_population* pop, int32_t k, const mfas_table* tab, int64_t row0,
+                            int64_t nrows, float* logits, int64_t* corrects);
+
+/* Timing of the dominant kernel (fused cell sweep) over the last train() call, measured with HIP
+ * events on the population's stream: number of launches, summed milliseconds, and the algorithmic
+ * HBM bytes of one update+forward launch (24*P_tiles + feature bytes). */
+int mfas_population_sweep_profile(const mfas_population* pop, int64_t* launches, double* total_ms,
+                                  double* bytes_per_launch);
+int mfas_population_set_profiling(mfas_population* pop, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFAS_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of the C-ABI engine (include/mfas_hip.h, built from mfas_amd/csrc/mfas_hip.hip).
+
+There is deliberately no fallback: if ``libmfas_hip.so`` is missing or fails to load, importing
+anything that needs the engine raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmfas_hip.so")
+
+MFAS_DT = {"float32": 0, "bfloat16": 1, "float16": 2}
+
+
+class mfas_hyper(C.Structure):
+    _fields_ = [("R", C.c_int32), ("C", C.c_int32), ("B", C.c_int32), ("bn", C.c_int32),
+                ("alphas", C.c_int32), ("multitask", C.c_int32), ("drpt", C.c_double),
+                ("wd", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("adam_eps", C.c_double), ("bn_eps", C.c_double), ("bn_momentum", C.c_double),
+                ("s_sizes", C.c_int32 * 4), ("v_sizes", C.c_int32 * 4)]
+
+
+class mfas_table(C.Structure):
+    _fields_ = [("s", C.c_void_p * 4), ("v", C.c_void_p * 4), ("vlogit", C.c_void_p),
+                ("slogit", C.c_void_p), ("label", C.c_void_p), ("N", C.c_int64),
+                ("dtype", C.c_int32), ("_pad", C.c_int32)]
+
+
+class mfas_epoch_stats(C.Structure):
+    _fields_ = [("train_loss_sum", C.c_double), ("dev_loss_sum", C.c_double),
+                ("train_corrects", C.c_int64), ("dev_corrects", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the engine once; raise loudly if it is not built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"MFAS HIP engine not built: {LIB_PATH} missing "
+                           "(run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    L = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    L.mfas_last_error.restype = C.c_char_p
+    L.mfas_version.restype = C.c_int
+    L.mfas_population_create.argtypes = [C.POINTER(mfas_hyper), P, P, P, C.c_int32, C.c_int32, P,
+                                         C.c_int32, C.POINTER(P)]
+    L.mfas_population_destroy.argtypes = [P]
+    L.mfas_population_destroy.restype = None
+    L.mfas_population_param_count.argtypes = [P, C.c_int32]
+    L.mfas_population_param_count.restype = C.c_int64
+    L.mfas_population_set_params.argtypes = [P, C.c_int32, P]
+    L.mfas_population_get_params.argtypes = [P, C.c_int32, C.c_int32, P]
+    L.mfas_population_init.argtypes = [P, P]
+    L.mfas_population_train.argtypes = [P, C.POINTER(mfas_table), C.POINTER(mfas_table), P, P, C.c_int32,
+                                        C.c_int64, C.c_int32, P, P]
+    L.mfas_population_forward.argtypes = [P, C.c_int32, C.POINTER(mfas_table), C.c_int64, C.c_int64, P, P]
+    L.mfas_population_sweep_profile.argtypes = [P, P, P, P]
+    L.mfas_population_set_profiling.argtypes = [P, C.c_int32]
+    _lib = L
+    return L
+
+
+EXPORTS = ["mfas_last_error", "mfas_version", "mfas_population_create", "mfas_population_destroy",
+           "mfas_population_param_count", "mfas_population_set_params", "mfas_population_get_params",
+           "mfas_population_init", "mfas_population_train", "mfas_population_forward",
+           "mfas_population_sweep_profile", "mfas_population_set_profiling"]
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"mfas_hip error {rc}: {lib().mfas_last_error().decode()}")

@@ -1,0 +1,1673 @@
+// mfas_hip.hip — MI355X (gfx950 / CDNA4) inner candidate-training engine for MFAS.
+//
+// What it replaces (reference = jperezrua/mfas, pure PyTorch):
+//   train_sampled_models                models/search/ntu_searchable.py:23-102
+//   train_ntu_track_acc                 models/search/train_searchable/ntu.py:14-89
+//   Searchable_Skeleton_Image_Net.forward (+ autograd + torch.optim.Adam)   ntu_searchable.py:206-286
+//
+// Design: the whole population trains in lockstep.  Per train step three kernels run for
+// ALL candidates at once:
+//   k_chain  (1 workgroup / candidate): the serial R-wide part — reduce feature partial sums, cell chain
+//            (prev-out GEMM on f32 MFMA, activation, BN batch stats, dropout), head, CE loss, and the
+//            backward chain producing dy_i for every cell;
+//   k_sweep  (1 workgroup / (candidate, weight chunk)): the HBM-bound part — for every weight tile:
+//            dW = x_t^T dy (f32 MFMA) -> Adam(+L2) update of W/m/v in registers -> store -> immediately
+//            use the new W for the NEXT step's forward partial sums (f32 MFMA).  24 B/param/step = the
+//            algorithmic minimum with state in HBM.
+// Dev evaluation is row-parallel (k_eval).  Weights live in a 16x16 tile-major layout that is exactly the
+// MFMA 16x16x4 f32 operand layout, so every W/m/v access is one coalesced 16 B/lane load.
+//
+// MFMA used: v_mfma_f32_16x16x4_f32 (exact f32 fma chain).  Layout (lane l):
+//   A[i = l&15][k = l>>4],  B[k = l>>4][j = l&15],  D[i = 4*(l>>4)+reg][j = l&15].
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "mfas_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define KIND_S 0
+#define KIND_V 1
+#define KIND_OUT 2
+#define KIND_HEAD 3
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(MFAS_EHIP, std::string(#x) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Device-side descriptors
+// ------------------------------------------------------------------------------------------------
+struct SegDesc {          // one workgroup of k_sweep / k_pack
+    int32_t cand, kind, cell, tap;
+    int32_t k0, cc;       // first column inside the segment, chunk columns (multiple of 16)
+    int32_t rows_p, width;  // padded rows; FEAT: table row width (elements)
+    int64_t w_off;        // float offset (within a plane) of this chunk: tiles [rb][kb][256]
+    int64_t wt_off;       // OUT/HEAD: float offset in the transposed arena, else -1
+    int32_t part_idx;     // FEAT: chunk index within the cell's partial list
+    int32_t rows, cols;   // true rows (R or C) / true columns of the whole segment
+    int64_t src_off;      // flat-parameter offset of the matrix this segment belongs to
+    int32_t src_ld, src_col0;
+    uint32_t init_seed;   // hash seed of that matrix (device init)
+    float init_bound;
+};
+
+struct CandDev {
+    int32_t L;
+    int32_t conf[MFAS_MAX_CELLS][3];
+    int64_t seg_off[MFAS_MAX_CELLS][3];   // plane offset of S / V / OUT segment of cell i (-1: none)
+    int32_t seg_cc[MFAS_MAX_CELLS][3];    // chunk columns of that segment
+    int32_t seg_cols[MFAS_MAX_CELLS][3];  // padded columns
+    int64_t head_off;
+    int64_t outT_off[MFAS_MAX_CELLS];     // transposed arena offset of cell i's OUT segment
+    int64_t headT_off;
+    int64_t vec_off;                      // plane offset of the vector block
+    int32_t nch_s[MFAS_MAX_CELLS], nch_v[MFAS_MAX_CELLS];
+    int32_t part_cell_off[MFAS_MAX_CELLS];  // first partial-slot index of cell i
+    int64_t step_off;                     // float offset of this candidate's step buffers
+    uint32_t drop_seed;
+    int32_t _pad;
+    // flat (reference state_dict order) offsets of this candidate's parameters
+    int64_t f_alpha, f_W[MFAS_MAX_CELLS], f_b[MFAS_MAX_CELLS], f_bn[MFAS_MAX_CELLS], f_Wc, f_bc;
+    int32_t K_in[MFAS_MAX_CELLS];   // in_features of cell i
+    int32_t _pad2[4];
+};
+
+struct DevStats {
+    double train_loss, dev_loss;
+    long long train_corr, dev_corr;
+};
+
+struct AdamC {
+    float ss, bc2s, w1, b2, w2, eps, wd;
+};
+
+struct Geo {             // geometry shared by all candidates of a population
+    int32_t R, C, Rp, Cp, nrb, ncb, B, Bp, MB;
+    int32_t bn, alphas, multitask, use_drop;
+    float drop_scale, bn_eps, bn_mom;
+    uint32_t drop_thr;
+    // per-candidate step-buffer sub-offsets (floats)
+    int64_t sb_part, sb_dy, sb_xo, sb_dlog, sb_sav, sb_gsc, sb_size;
+    int32_t vec_cell_stride;   // 5*Rp + 16
+    int32_t vec_head;          // offset of head bias inside the vector block
+    int32_t sw[4], vw[4];      // tap widths (elements per table row)
+};
+
+// vector block of a candidate (inside every plane): per cell [b | gamma | beta | rm | rv | alpha(16)], then bc[Cp]
+#define VEC_B 0
+#define VEC_G 1
+#define VEC_BE 2
+#define VEC_RM 3
+#define VEC_RV 4
+
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352DU;
+    x ^= x >> 15;
+    x *= 0x846CA68BU;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ static inline uint32_t lowbias32_h(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352DU;
+    x ^= x >> 15;
+    x *= 0x846CA68BU;
+    x ^= x >> 16;
+    return x;
+}
+// oracle/np_oracle.py:hash_u01
+__host__ __device__ static inline float hash_u01(uint32_t h0, uint32_t idx) {
+    return (float)(lowbias32_h(idx ^ h0) >> 8) * (1.0f / 16777216.0f);
+}
+static inline uint32_t hash_h0(uint32_t seed) { return lowbias32_h(seed * 0x9E3779B9U + 0x7F4A7C15U); }
+static inline uint32_t param_seed(uint32_t seed, uint32_t slot) {
+    return (uint32_t)(((uint64_t)seed * 1000003ULL + (uint64_t)slot * 7919ULL + 17ULL) & 0x7FFFFFFFULL);
+}
+
+__device__ __forceinline__ float act_fwd(float y, int nl) {
+    if (nl == 0) return fmaxf(y, 0.0f);
+    if (nl == 1) return 1.0f / (1.0f + expf(-y));
+    return y > 0.0f ? y : 0.01f * y;
+}
+__device__ __forceinline__ float act_bwd(float a, float da, int nl) {
+    if (nl == 0) return a > 0.0f ? da : 0.0f;
+    if (nl == 1) return da * (1.0f - a) * a;
+    return a > 0.0f ? da : 0.01f * da;   // leaky: sign(a) == sign(y)
+}
+
+__device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, const AdamC& c) {
+    g = g + c.wd * w;
+    m = m + c.w1 * (g - m);
+    v = v * c.b2;
+    v = v + (c.w2 * g) * g;
+    const float denom = sqrtf(v) / c.bc2s + c.eps;
+    w = w - c.ss * (m / denom);
+}
+
+// sum over the 4 lane groups that share (lane & 15): column reduction of an MFMA D block
+__device__ __forceinline__ float colsum(float x) {
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+
+__device__ __forceinline__ int64_t tile_addr(int64_t seg_off, int rows_p, int cc, int rb, int kb) {
+    const int nkb_c = cc >> 4;
+    const int chunk = kb / nkb_c;
+    const int kbi = kb - chunk * nkb_c;
+    return seg_off + (int64_t)chunk * rows_p * cc + ((int64_t)rb * nkb_c + kbi) * 256;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row staging: table rows (any dtype) -> f32 LDS tile [rows][stride]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_table(float* dst, int stride, const void* tab, int dtype, int width,
+                                            int col0, int ncols, const int32_t* ord, int64_t pos,
+                                            int base, int nvalid, int nrows, int tid, int nthreads) {
+    if (dtype == MFAS_DT_F32) {
+        const int vpr = ncols >> 2;
+        for (int e = tid; e < nrows * vpr; e += nthreads) {
+            const int b = e / vpr, c = (e - b * vpr) << 2;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (b < nvalid) {
+                const int64_t row = ord ? (int64_t)ord[pos + b] : (int64_t)(base + b);
+                val = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(tab) + row * width + col0 + c);
+            }
+            *reinterpret_cast<f32x4*>(dst + b * stride + c) = val;
+        }
+    } else {
+        const int vpr = ncols >> 3;
+        for (int e = tid; e < nrows * vpr; e += nthreads) {
+            const int b = e / vpr, c = (e - b * vpr) << 3;
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+            if (b < nvalid) {
+                const int64_t row = ord ? (int64_t)ord[pos + b] : (int64_t)(base + b);
+                const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(tab) +
+                                                                  row * width + col0 + c);
+                const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (dtype == MFAS_DT_BF16) {
+                        f[2 * j] = __uint_as_float(w[j] << 16);
+                        f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000U);
+                    } else {
+                        f[2 * j] = __half2float(__ushort_as_half((unsigned short)(w[j] & 0xFFFFU)));
+                        f[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(w[j] >> 16)));
+                    }
+                }
+                lo = (f32x4){f[0], f[1], f[2], f[3]};
+                hi = (f32x4){f[4], f[5], f[6], f[7]};
+            }
+            *reinterpret_cast<f32x4*>(dst + b * stride + c) = lo;
+            *reinterpret_cast<f32x4*>(dst + b * stride + c + 4) = hi;
+        }
+    }
+}
+
+// f32 row-major global [nrows][src_stride] -> LDS [nrows][stride]
+__device__ __forceinline__ void stage_f32(float* dst, int stride, const float* src, int src_stride, int ncols,
+                                          int nrows, int tid, int nthreads) {
+    const int vpr = ncols >> 2;
+    for (int e = tid; e < nrows * vpr; e += nthreads) {
+        const int b = e / vpr, c = (e - b * vpr) << 2;
+        *reinterpret_cast<f32x4*>(dst + b * stride + c) =
+            *reinterpret_cast<const f32x4*>(src + (int64_t)b * src_stride + c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sweep — fused dW + Adam + next-step forward over one weight chunk
+// ------------------------------------------------------------------------------------------------
+struct SweepArgs {
+    const SegDesc* desc;
+    const CandDev* cands;
+    float* plane;
+    int64_t plane_stride;
+    float* wt;
+    float* stepbuf;
+    mfas_table tab;
+    const int32_t* order;
+    int64_t pos_t, pos_n;
+    int32_t base_t, base_n, nvalid_t, nvalid_n;
+    int32_t do_update, do_forward;
+    AdamC ac;
+    Geo g;
+};
+
+template <int MB>
+__global__ void __launch_bounds__(256) k_sweep(const SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const SegDesc d = a.desc[blockIdx.x];
+    const CandDev& cd = a.cands[d.cand];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int Bp = MB * 16;
+    const int cc = d.cc, rows_p = d.rows_p, nrb = rows_p >> 4, nkb = cc >> 4;
+    const int ST = cc + 16;   // x_t stride: conflict-free ds_read_b32 column reads
+    const int SN = cc + 4;    // x_{t+1} stride: 16 B aligned rows for ds_read_b128
+    const int SD = rows_p + 16;
+    float* xt = lds;
+    float* xn = xt + Bp * ST;
+    float* dyl = xn + Bp * SN;
+    float* wred = dyl + Bp * SD;   // [4 waves][nrb][MB][256], only when the chunk is k-split over waves
+    const bool feat = d.kind <= KIND_V;
+    const bool upd = a.do_update != 0;
+    const bool fwd = (a.do_forward != 0) && feat;
+    if (!upd && !fwd) return;
+    float* sb = a.stepbuf + cd.step_off;
+
+    if (upd) {
+        if (feat) {
+            const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
+            stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_t, a.base_t, a.nvalid_t, Bp,
+                        tid, 256);
+        } else {
+            const int xcell = d.kind == KIND_OUT ? d.cell - 1 : cd.L - 1;
+            stage_f32(xt, ST, sb + a.g.sb_xo + (int64_t)xcell * Bp * a.g.Rp, a.g.Rp, cc, Bp, tid, 256);
+        }
+        const float* dsrc = d.kind == KIND_HEAD ? sb + a.g.sb_dlog : sb + a.g.sb_dy + (int64_t)d.cell * Bp * a.g.Rp;
+        stage_f32(dyl, SD, dsrc, rows_p, rows_p, Bp, tid, 256);
+    }
+    if (fwd) {
+        const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
+        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_n, a.base_n, a.nvalid_n, Bp, tid,
+                    256);
+    }
+    __syncthreads();
+
+    float* Wp = a.plane + d.w_off;
+    float* Mp = Wp + a.plane_stride;
+    float* Vp = Mp + a.plane_stride;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const AdamC ac = a.ac;
+    // alpha scaling of the gradient of S / V columns (aux_models.py:103-111): sigma(alpha_t) as used by this
+    // step's forward, published by k_chain (alpha itself has already been stepped); 1.0 when alphas are off
+    float gsc = 1.0f;
+    if (a.g.alphas && feat && upd) gsc = sb[a.g.sb_gsc + d.cell * 2 + d.kind];
+
+    // Work split: with >= 4 row blocks every wave owns whole row blocks (streams contiguous tiles, no
+    // reduction); with fewer (R = 16/32) the waves split the k blocks and reduce through LDS.
+    const bool split_k = nrb < 4;
+    const int rb0 = split_k ? 0 : wave, rbs = split_k ? 1 : 4;
+    const int kb0 = split_k ? wave : 0, kbs = split_k ? 4 : 1;
+    float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * nrb * MB) << 8);
+
+    for (int rb = rb0; rb < nrb; rb += rbs) {
+        float dyf[MB * 4];
+        if (upd) {
+#pragma unroll
+            for (int j = 0; j < MB * 4; ++j) dyf[j] = dyl[(4 * j + lg) * SD + rb * 16 + l15];
+        }
+        f32x4 yacc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kb = kb0; kb < nkb; kb += kbs) {
+            const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+            f32x4 w4 = *reinterpret_cast<const f32x4*>(Wp + off);
+            if (upd) {
+                f32x4 m4 = *reinterpret_cast<const f32x4*>(Mp + off);
+                f32x4 v4 = *reinterpret_cast<const f32x4*>(Vp + off);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < MB * 4; ++j)
+                    acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float w = w4[q], m = m4[q], v = v4[q];
+                    adam1(w, m, v, acc[q] * gsc, ac);
+                    w4[q] = w;
+                    m4[q] = m;
+                    v4[q] = v;
+                }
+                *reinterpret_cast<f32x4*>(Wp + off) = w4;
+                *reinterpret_cast<f32x4*>(Mp + off) = m4;
+                *reinterpret_cast<f32x4*>(Vp + off) = v4;
+                if (d.wt_off >= 0) {   // keep the transposed copy used by the backward chain in step
+                    float* T = a.wt + d.wt_off + ((int64_t)kb * nrb + rb) * 256;
+                    const int base = (((l15 >> 2) * 16 + 4 * lg) << 2) + (l15 & 3);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) T[base + 4 * q] = w4[q];
+                }
+            }
+            if (fwd) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * SN + kb * 16 + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[q], yacc[mb]);
+                }
+            }
+        }
+        if (fwd) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                if (split_k)
+                    *reinterpret_cast<f32x4*>(wred + (((wave * nrb + rb) * MB + mb) << 8) + lane * 4) = yacc[mb];
+                else   // partial slot in MFMA D layout [chunk][rb][mb][lane][4]
+                    *reinterpret_cast<f32x4*>(part + ((rb * MB + mb) << 8) + lane * 4) = yacc[mb];
+            }
+        }
+    }
+    if (!fwd || !split_k) return;
+    __syncthreads();
+    // deterministic cross-wave reduction (fixed order 0..3)
+    for (int e = tid; e < nrb * MB * 64; e += 256) {
+        const int slot = e >> 6, ln = e & 63;
+        f32x4 s = *reinterpret_cast<const f32x4*>(wred + (slot << 8) + ln * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            s += *reinterpret_cast<const f32x4*>(wred + ((w * nrb * MB + slot) << 8) + ln * 4);
+        *reinterpret_cast<f32x4*>(part + (slot << 8) + ln * 4) = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_chain — one workgroup per candidate: forward chain, CE loss, backward chain (train step)
+// ------------------------------------------------------------------------------------------------
+struct ChainArgs {
+    const CandDev* cands;
+    float* plane;
+    int64_t plane_stride;
+    const float* wt;
+    float* stepbuf;
+    mfas_table tab;
+    const int32_t* order;
+    int64_t pos_t;
+    int32_t base_t, nvalid;
+    int32_t gstep, epoch, E;
+    AdamC ac;
+    Geo g;
+    DevStats* stats;
+    int32_t* status;
+};
+
+__device__ __forceinline__ bool drop_keep(uint32_t h0, int cell, uint32_t idx, uint32_t thr) {
+    // oracle/np_oracle.py:dropout_keep
+    const uint32_t key = idx + (uint32_t)cell * 0x7F4A7C15U;
+    return (lowbias32(key ^ h0) >> 8) >= thr;
+}
+
+template <int MB>
+__global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const CandDev& cd = a.cands[blockIdx.x];
+    const Geo& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int Bp = MB * 16;
+    const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
+    const int SX = Rp + 4, SC = Cp + 4;
+    float* xo_l = lds;                       // [2][Bp][SX]  ping-pong out_i (A operand of the next cell)
+    float* dy_l = xo_l + 2 * Bp * SX;        // [2][Bp][SX]  ping-pong dy_i (A operand of the backward chain)
+    float* lg_l = dy_l + 2 * Bp * SX;        // [Bp][SC]     logits -> dlogits
+    float* rstd_l = lg_l + Bp * SC;          // [L][Rp]
+    float* red_l = rstd_l + MFAS_MAX_CELLS * Rp;   // [2*Bp] loss / correct per row
+    int* lab_l = reinterpret_cast<int*>(red_l + 2 * Bp);   // [Bp]
+
+    float* W = a.plane;
+    float* Mv = a.plane + a.plane_stride;
+    float* Vv = Mv + a.plane_stride;
+    float* sb = a.stepbuf + cd.step_off;
+    const int nvalid = a.nvalid;
+    const float nf = (float)nvalid;
+    const AdamC ac = a.ac;
+    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(a.gstep + 1));
+
+    if (tid < Bp) {
+        int lab = 0;
+        if (tid < nvalid) {
+            const int64_t row = a.order ? (int64_t)a.order[a.pos_t + tid] : (int64_t)(a.base_t + tid);
+            lab = a.tab.label[row];
+        }
+        lab_l[tid] = lab;
+    }
+
+    // ------------------------------------------------------------------ forward chain
+    for (int i = 0; i < L; ++i) {
+        const float* xprev = xo_l + ((i + 1) & 1) * Bp * SX;
+        float* xcur = xo_l + (i & 1) * Bp * SX;
+        const int nl = cd.conf[i][2];
+        const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
+        const int nch = cd.nch_s[i] + cd.nch_v[i];
+        const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8);
+        float sgS = 1.0f, sgV = 1.0f;
+        if (g.alphas) {
+            const float sg = 1.0f / (1.0f + expf(-W[vb + 5 * Rp]));
+            sgS = sg;
+            sgV = 1.0f - sg;
+            if (tid == 0) {
+                sb[g.sb_gsc + i * 2] = sgS;
+                sb[g.sb_gsc + i * 2 + 1] = sgV;
+            }
+        }
+        for (int rb = wave; rb < nrb; rb += 4) {
+            f32x4 acc[MB], accv[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                accv[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            for (int ch = 0; ch < nch; ++ch) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(part + ((((int64_t)ch * nrb + rb) * MB + mb) << 8) + lane * 4);
+                    if (ch < cd.nch_s[i]) acc[mb] += p; else accv[mb] += p;
+                }
+            }
+            if (g.alphas) {   // keep raw S-V difference for d(alpha); scale the two modality sums
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    *reinterpret_cast<f32x4*>(sb + g.sb_sav + ((((int64_t)(2 * MFAS_MAX_CELLS + i) * nrb + rb) * MB + mb) << 8) + lane * 4) = acc[mb] - accv[mb];
+                    acc[mb] = acc[mb] * sgS + accv[mb] * sgV;
+                }
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] += accv[mb];
+            }
+            if (i > 0) {
+                for (int kb = 0; kb < nrb; ++kb) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][2], Rp, Rp, rb, kb) + lane * 4);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xprev + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w4[q], acc[mb]);
+                    }
+                }
+            }
+            const int r = rb * 16 + l15;
+            const bool colok = r < R;
+            const float bias = W[vb + VEC_B * Rp + r];
+            float av[MB][4];
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    const float y = acc[mb][q] + bias;
+                    const float v = act_fwd(y, nl);
+                    av[mb][q] = v;
+                    if (b < nvalid) s += v;
+                }
+            float zv[MB][4];
+            if (g.bn) {
+                const float mu = colsum(s) / nf;
+                float s2 = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        const float dlt = av[mb][q] - mu;
+                        if (b < nvalid) s2 += dlt * dlt;
+                    }
+                const float var = colsum(s2) / nf;
+                const float rstd = 1.0f / sqrtf(var + g.bn_eps);
+                const float gam = W[vb + VEC_G * Rp + r], bet = W[vb + VEC_BE * Rp + r];
+                f32x4 xh4[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float xh = (av[mb][q] - mu) * rstd;
+                        xh4[mb][q] = xh;
+                        zv[mb][q] = xh * gam + bet;
+                    }
+                if (lg == 0) {
+                    rstd_l[i * Rp + r] = rstd;
+                    if (colok) {   // running stats: momentum 0.1, unbiased variance
+                        float rm = W[vb + VEC_RM * Rp + r], rv = W[vb + VEC_RV * Rp + r];
+                        const float unb = var * (nf / (nf - 1.0f));
+                        rm += g.bn_mom * (mu - rm);
+                        rv += g.bn_mom * (unb - rv);
+                        W[vb + VEC_RM * Rp + r] = rm;
+                        W[vb + VEC_RV * Rp + r] = rv;
+                    }
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    *reinterpret_cast<f32x4*>(sb + g.sb_sav + ((((int64_t)(MFAS_MAX_CELLS + i) * nrb + rb) * MB + mb) << 8) + lane * 4) = xh4[mb];
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zv[mb][q] = av[mb][q];
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = av[mb][q];
+                *reinterpret_cast<f32x4*>(sb + g.sb_sav + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4) = a4;
+            }
+            float* xo_g = sb + g.sb_xo + (int64_t)i * Bp * Rp;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float o = zv[mb][q];
+                    if (g.use_drop)
+                        o = drop_keep(h0, i, (uint32_t)(b * R + r), g.drop_thr) ? o * g.drop_scale : 0.0f;
+                    if (!(colok && b < nvalid)) o = 0.0f;
+                    xcur[b * SX + r] = o;
+                    xo_g[b * Rp + r] = o;
+                }
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ head + CE loss
+    {
+        const float* xl = xo_l + ((L - 1) & 1) * Bp * SX;
+        for (int cb = wave; cb < ncb; cb += 4) {
+            f32x4 acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < nrb; ++kb) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.head_off, Cp, Rp, cb, kb) + lane * 4);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xl + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w4[q], acc[mb]);
+                }
+            }
+            const int c = cb * 16 + l15;
+            const float bias = W[cd.vec_off + g.vec_head + c];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lg_l[(mb * 16 + 4 * lg + q) * SC + c] = acc[mb][q] + bias;
+        }
+    }
+    __syncthreads();
+    if (tid < Bp) {
+        float* row = lg_l + tid * SC;
+        float loss = 0.f, corr = 0.f;
+        if (tid < nvalid) {
+            const int lab = lab_l[tid];
+            float mx = row[0];
+            for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
+            loss = -(row[lab] - mx - logf(se));
+            // argmax, first max on ties (torch.max(dim=1)); multitask: central + visual + skeleton logits
+            int best = 0;
+            float bv;
+            if (g.multitask) {
+                const int64_t grow = a.order ? (int64_t)a.order[a.pos_t + tid] : (int64_t)(a.base_t + tid);
+                const float* vl = a.tab.vlogit + grow * C;
+                const float* sl = a.tab.slogit + grow * C;
+                bv = (row[0] + vl[0]) + sl[0];
+                for (int c = 1; c < C; ++c) {
+                    const float t = (row[c] + vl[c]) + sl[c];
+                    if (t > bv) { bv = t; best = c; }
+                }
+            } else {
+                bv = row[0];
+                for (int c = 1; c < C; ++c)
+                    if (row[c] > bv) { bv = row[c]; best = c; }
+            }
+            corr = best == lab ? 1.f : 0.f;
+            for (int c = 0; c < Cp; ++c) {
+                float dl = 0.f;
+                if (c < C) {
+                    dl = expf(row[c] - mx) / se;
+                    if (c == lab) dl -= 1.0f;
+                    dl = dl / nf;
+                }
+                row[c] = dl;
+            }
+        } else {
+            for (int c = 0; c < Cp; ++c) row[c] = 0.f;
+        }
+        red_l[tid] = loss;
+        red_l[Bp + tid] = corr;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ls = 0.f, cs = 0.f;
+        for (int b = 0; b < Bp; ++b) { ls += red_l[b]; cs += red_l[Bp + b]; }
+        DevStats& st = a.stats[(int64_t)blockIdx.x * a.E + a.epoch];
+        st.train_loss += (double)ls;
+        st.train_corr += (long long)cs;
+        if (!(fabsf(ls) <= 3.0e38f)) a.status[blockIdx.x] = 1;
+    }
+    // dlogits -> global (x operand dy of the HEAD segment); head-bias Adam
+    {
+        float* dlg = sb + g.sb_dlog;
+        for (int e = tid; e < Bp * Cp; e += 256) {
+            const int b = e / Cp, c = e - b * Cp;
+            dlg[e] = lg_l[b * SC + c];
+        }
+        if (tid < C) {
+            float gsum = 0.f;
+            for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + tid];
+            const int64_t o = cd.vec_off + g.vec_head + tid;
+            float w = W[o], m = Mv[o], v = Vv[o];
+            adam1(w, m, v, gsum, ac);
+            W[o] = w; Mv[o] = m; Vv[o] = v;
+        }
+    }
+
+    // ------------------------------------------------------------------ backward chain
+    for (int i = L - 1; i >= 0; --i) {
+        const int nl = cd.conf[i][2];
+        const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
+        const bool from_head = (i == L - 1);
+        const float* src = from_head ? lg_l : dy_l + ((i + 1) & 1) * Bp * SX;
+        const int sstride = from_head ? SC : SX;
+        const int nkk = from_head ? ncb : nrb;
+        const float* T = a.wt + (from_head ? cd.headT_off : cd.outT_off[i + 1]);
+        float* dcur = dy_l + (i & 1) * Bp * SX;
+        float dalpha = 0.f;
+        for (int rb = wave; rb < nrb; rb += 4) {
+            f32x4 acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < nkk; ++kb) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(T + (((int64_t)rb * nkk + kb) << 8) + lane * 4);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(src + (mb * 16 + l15) * sstride + kb * 16 + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w4[q], acc[mb]);
+                }
+            }
+            const int r = rb * 16 + l15;
+            const bool colok = r < R;
+            f32x4 a4[MB], xh4[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                a4[mb] = *reinterpret_cast<const f32x4*>(sb + g.sb_sav + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4);
+                if (g.bn)
+                    xh4[mb] = *reinterpret_cast<const f32x4*>(sb + g.sb_sav + ((((int64_t)(MFAS_MAX_CELLS + i) * nrb + rb) * MB + mb) << 8) + lane * 4);
+            }
+            float dz[MB][4];
+            float sdz = 0.f, sdzx = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float d = acc[mb][q];
+                    if (g.use_drop)
+                        d = drop_keep(h0, i, (uint32_t)(b * R + r), g.drop_thr) ? d * g.drop_scale : 0.0f;
+                    if (!(b < nvalid)) d = 0.f;
+                    dz[mb][q] = d;
+                    sdz += d;
+                    if (g.bn) sdzx += d * xh4[mb][q];
+                }
+            float dgam = 0.f, dbet = 0.f;
+            if (g.bn) {
+                dbet = colsum(sdz);
+                dgam = colsum(sdzx);
+                const float gr = W[vb + VEC_G * Rp + r] * rstd_l[i * Rp + r];
+                const float k1 = dbet / nf, k2 = dgam / nf;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        const float da = gr * (dz[mb][q] - k1 - xh4[mb][q] * k2);
+                        dz[mb][q] = b < nvalid ? da : 0.f;
+                    }
+            }
+            float sdy = 0.f;
+            float* dy_g = sb + g.sb_dy + (int64_t)i * Bp * Rp;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x4 df = {0.f, 0.f, 0.f, 0.f};
+                if (g.alphas)
+                    df = *reinterpret_cast<const f32x4*>(sb + g.sb_sav + ((((int64_t)(2 * MFAS_MAX_CELLS + i) * nrb + rb) * MB + mb) << 8) + lane * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float dy = act_bwd(a4[mb][q], dz[mb][q], nl);
+                    if (!colok) dy = 0.f;
+                    sdy += dy;
+                    dalpha += dy * df[q];
+                    dcur[b * SX + r] = dy;
+                    dy_g[b * Rp + r] = dy;
+                }
+            }
+            const float db = colsum(sdy);
+            if (lg == 0 && colok) {   // Adam on the column's vector parameters (one owner lane per column)
+                int64_t o = vb + VEC_B * Rp + r;
+                float w = W[o], m = Mv[o], v = Vv[o];
+                adam1(w, m, v, db, ac);
+                W[o] = w; Mv[o] = m; Vv[o] = v;
+                if (g.bn) {
+                    o = vb + VEC_G * Rp + r;
+                    w = W[o]; m = Mv[o]; v = Vv[o];
+                    adam1(w, m, v, dgam, ac);
+                    W[o] = w; Mv[o] = m; Vv[o] = v;
+                    o = vb + VEC_BE * Rp + r;
+                    w = W[o]; m = Mv[o]; v = Vv[o];
+                    adam1(w, m, v, dbet, ac);
+                    W[o] = w; Mv[o] = m; Vv[o] = v;
+                }
+            }
+        }
+        if (g.alphas) {   // d(alpha_i) = sigma'(alpha) * sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]
+            for (int o = 32; o > 0; o >>= 1) dalpha += __shfl_xor(dalpha, o);
+            if (lane == 0) red_l[wave] = dalpha;
+        }
+        __syncthreads();
+        if (g.alphas && tid == 0) {
+            const float tot = (red_l[0] + red_l[1]) + (red_l[2] + red_l[3]);
+            const int64_t o = vb + 5 * Rp;
+            float w = W[o], m = Mv[o], v = Vv[o];
+            const float sg = 1.0f / (1.0f + expf(-w));
+            adam1(w, m, v, tot * sg * (1.0f - sg), ac);
+            W[o] = w; Mv[o] = m; Vv[o] = v;
+        }
+        if (g.alphas) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_eval — eval-mode forward (BN running stats, no dropout) over a block of table rows
+// ------------------------------------------------------------------------------------------------
+struct EvalArgs {
+    const CandDev* cands;
+    const float* plane;
+    mfas_table tab;
+    int64_t row0, nrows;
+    int32_t cand0;
+    int32_t epoch, E;
+    Geo g;
+    float* logits;        // optional (nrows, C) for candidate cand0
+    DevStats* stats;      // optional: dev_corr / dev_loss of stats[cand*E + epoch]
+    long long* corr_out;  // optional single counter
+};
+
+#define EVAL_CE 128   // staged feature columns per pass
+
+template <int MBE, int NRBW>
+__global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int cand = a.cand0 + blockIdx.y;
+    const CandDev& cd = a.cands[cand];
+    const Geo& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int ME = MBE * 16;
+    const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
+    const int SX = Rp + 4, SC = Cp + 4, SS = EVAL_CE + 4;
+    float* xs = lds;                     // [ME][SS]
+    float* xo_l = xs + ME * SS;          // [2][ME][SX]
+    float* lg_l = xo_l + 2 * ME * SX;    // [ME][SC]
+    const float* W = a.plane;
+    const int64_t brow = a.row0 + (int64_t)blockIdx.x * ME;
+    const int nvalid = (int)min((int64_t)ME, a.row0 + a.nrows - brow);
+
+    for (int i = 0; i < L; ++i) {
+        const float* xprev = xo_l + ((i + 1) & 1) * ME * SX;
+        float* xcur = xo_l + (i & 1) * ME * SX;
+        const int nl = cd.conf[i][2];
+        const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
+        float sgS = 1.0f, sgV = 1.0f;
+        if (g.alphas) {
+            const float sg = 1.0f / (1.0f + expf(-W[vb + 5 * Rp]));
+            sgS = sg;
+            sgV = 1.0f - sg;
+        }
+        f32x4 acc[NRBW][MBE];
+#pragma unroll
+        for (int j = 0; j < NRBW; ++j)
+#pragma unroll
+            for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int sv = 0; sv < 2; ++sv) {
+            const int tap = cd.conf[i][sv];
+            const void* tp = sv == 0 ? a.tab.s[tap] : a.tab.v[tap];
+            const int cols = cd.seg_cols[i][sv], cc = cd.seg_cc[i][sv];
+            const int tw = sv == 0 ? g.sw[tap] : g.vw[tap];
+            if (g.alphas && sv == 1) {   // switch modality: fold the S sum with its scale, restart for V
+#pragma unroll
+                for (int j = 0; j < NRBW; ++j)
+#pragma unroll
+                    for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * (sgS / sgV);
+            }
+            for (int c0 = 0; c0 < cols; c0 += EVAL_CE) {
+                const int nc = min(EVAL_CE, cols - c0);
+                __syncthreads();
+                stage_table(xs, SS, tp, a.tab.dtype, tw, c0, nc, nullptr, 0, (int)brow, nvalid, ME, tid, 256);
+                __syncthreads();
+                for (int kbl = 0; kbl < (nc >> 4); ++kbl) {
+                    const int kb = (c0 >> 4) + kbl;
+#pragma unroll
+                    for (int j = 0; j < NRBW; ++j) {
+                        const int rb = wave + 4 * j;
+                        if (rb < nrb) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][sv], Rp, cc, rb, kb) + lane * 4);
+#pragma unroll
+                            for (int mb = 0; mb < MBE; ++mb) {
+                                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], w4[q], acc[j][mb]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (g.alphas) {
+#pragma unroll
+            for (int j = 0; j < NRBW; ++j)
+#pragma unroll
+                for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * sgV;
+        }
+#pragma unroll
+        for (int j = 0; j < NRBW; ++j) {
+            const int rb = wave + 4 * j;
+            if (rb < nrb) {
+                if (i > 0) {
+                    for (int kb = 0; kb < nrb; ++kb) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][2], Rp, Rp, rb, kb) + lane * 4);
+#pragma unroll
+                        for (int mb = 0; mb < MBE; ++mb) {
+                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xprev + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], w4[q], acc[j][mb]);
+                        }
+                    }
+                }
+                const int r = rb * 16 + l15;
+                const float bias = W[vb + VEC_B * Rp + r];
+                float sc = 1.0f, sh = 0.0f, rm = 0.0f;
+                if (g.bn) {
+                    rm = W[vb + VEC_RM * Rp + r];
+                    sc = 1.0f / sqrtf(W[vb + VEC_RV * Rp + r] + g.bn_eps);
+                }
+                const float gam = g.bn ? W[vb + VEC_G * Rp + r] : 1.0f;
+                sh = g.bn ? W[vb + VEC_BE * Rp + r] : 0.0f;
+#pragma unroll
+                for (int mb = 0; mb < MBE; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        float o = act_fwd(acc[j][mb][q] + bias, nl);
+                        if (g.bn) o = ((o - rm) * sc) * gam + sh;
+                        if (!(r < R)) o = 0.f;
+                        xcur[b * SX + r] = o;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    {
+        const float* xl = xo_l + ((L - 1) & 1) * ME * SX;
+        for (int cb = wave; cb < ncb; cb += 4) {
+            f32x4 hacc[MBE];
+#pragma unroll
+            for (int mb = 0; mb < MBE; ++mb) hacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < nrb; ++kb) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.head_off, Cp, Rp, cb, kb) + lane * 4);
+#pragma unroll
+                for (int mb = 0; mb < MBE; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xl + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hacc[mb] = MFMA16(x4[q], w4[q], hacc[mb]);
+                }
+            }
+            const int c = cb * 16 + l15;
+            const float bias = W[cd.vec_off + g.vec_head + c];
+#pragma unroll
+            for (int mb = 0; mb < MBE; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lg_l[(mb * 16 + 4 * lg + q) * SC + c] = hacc[mb][q] + bias;
+        }
+    }
+    __syncthreads();
+    if (a.logits) {
+        for (int e = tid; e < nvalid * C; e += 256) {
+            const int b = e / C, c = e - b * C;
+            a.logits[(brow - a.row0 + b) * C + c] = lg_l[b * SC + c];
+        }
+    }
+    if (tid < ME) {   // ME <= 64: exactly wave 0
+        float loss = 0.f;
+        int corr = 0;
+        if (tid < nvalid) {
+            const float* row = lg_l + tid * SC;
+            const int64_t grow = brow + tid;
+            const int lab = a.tab.label[grow];
+            float mx = row[0];
+            for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
+            loss = -(row[lab] - mx - logf(se));
+            int best = 0;
+            float bv;
+            if (g.multitask) {
+                const float* vl = a.tab.vlogit + grow * C;
+                const float* sl = a.tab.slogit + grow * C;
+                bv = (row[0] + vl[0]) + sl[0];
+                for (int c = 1; c < C; ++c) {
+                    const float t = (row[c] + vl[c]) + sl[c];
+                    if (t > bv) { bv = t; best = c; }
+                }
+            } else {
+                bv = row[0];
+                for (int c = 1; c < C; ++c)
+                    if (row[c] > bv) { bv = row[c]; best = c; }
+            }
+            corr = best == lab ? 1 : 0;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            loss += __shfl_xor(loss, o);
+            corr += __shfl_xor(corr, o);
+        }
+        if (tid == 0) {
+            if (a.stats) {
+                DevStats& st = a.stats[(int64_t)cand * a.E + a.epoch];
+                atomicAdd(reinterpret_cast<unsigned long long*>(&st.dev_corr), (unsigned long long)corr);
+                atomicAdd(&st.dev_loss, (double)loss);
+            }
+            if (a.corr_out) atomicAdd(reinterpret_cast<unsigned long long*>(a.corr_out), (unsigned long long)corr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Parameter import / export / device init (tile-major <-> reference row-major state_dict order)
+// ------------------------------------------------------------------------------------------------
+#define PK_SET 0
+#define PK_GET 1
+#define PK_INIT 2
+
+struct PackArgs {
+    const SegDesc* desc;
+    const CandDev* cands;
+    float* plane;
+    int64_t plane_stride;
+    float* wt;
+    float* flat;            // SET: source, GET: destination (one candidate)
+    const uint32_t* seeds;  // INIT: per candidate
+    int32_t mode, sel_plane;
+    Geo g;
+};
+
+__device__ __forceinline__ uint32_t d_param_seed(uint32_t seed, uint32_t slot) {
+    return (uint32_t)(((unsigned long long)seed * 1000003ULL + (unsigned long long)slot * 7919ULL + 17ULL) & 0x7FFFFFFFULL);
+}
+__device__ __forceinline__ uint32_t d_hash_h0(uint32_t seed) { return lowbias32(seed * 0x9E3779B9U + 0x7F4A7C15U); }
+__device__ __forceinline__ float d_hash_u01(uint32_t h0, uint32_t idx) {
+    return (float)(lowbias32(idx ^ h0) >> 8) * (1.0f / 16777216.0f);
+}
+
+__global__ void __launch_bounds__(256) k_pack(const PackArgs a) {
+    const SegDesc d = a.desc[blockIdx.x];
+    const int nkb = d.cc >> 4, nrb = d.rows_p >> 4;
+    float* Wp = a.plane + d.w_off;
+    uint32_t h0 = 0;
+    if (a.mode == PK_INIT) h0 = d_hash_h0(d_param_seed(a.seeds[d.cand], d.init_seed));
+    for (int e = threadIdx.x; e < d.rows_p * d.cc; e += 256) {
+        const int tile = e >> 8, within = e & 255, lane = within >> 2, q = within & 3;
+        const int rb = tile / nkb, kb = tile - rb * nkb;
+        const int r = rb * 16 + (lane & 15);
+        const int k = d.k0 + kb * 16 + 4 * (lane >> 4) + q;   // column inside the segment
+        const bool ok = r < d.rows && k < d.cols;
+        const int64_t fidx = (int64_t)r * d.src_ld + d.src_col0 + k;
+        if (a.mode == PK_GET) {
+            if (ok) a.flat[d.src_off + fidx] = Wp[a.sel_plane * a.plane_stride + e];
+            continue;
+        }
+        float val = 0.f;
+        if (ok) {
+            if (a.mode == PK_SET) val = a.flat[d.src_off + fidx];
+            else val = (d_hash_u01(h0, (uint32_t)fidx) * 2.0f - 1.0f) * d.init_bound;
+        }
+        Wp[e] = val;
+        Wp[a.plane_stride + e] = 0.f;
+        Wp[2 * a.plane_stride + e] = 0.f;
+        if (d.wt_off >= 0) {
+            const int l15 = lane & 15, lg = lane >> 4;
+            float* T = a.wt + d.wt_off + ((int64_t)kb * nrb + rb) * 256;
+            T[((((l15 >> 2) * 16 + 4 * lg) + q) << 2) + (l15 & 3)] = val;
+        }
+    }
+}
+
+// vector parameters of one candidate (SET/GET) or of all candidates (INIT: blockIdx.x = candidate)
+__global__ void __launch_bounds__(256) k_vec(const PackArgs a, int cand_fixed) {
+    const int cand = cand_fixed >= 0 ? cand_fixed : blockIdx.x;
+    const CandDev& cd = a.cands[cand];
+    const Geo& g = a.g;
+    float* P0 = a.plane + cd.vec_off;
+    const int tid = threadIdx.x;
+    const int nvec = MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp;
+    if (a.mode != PK_GET)
+        for (int e = tid; e < nvec; e += 256) {   // zero everything first (padding, Adam state)
+            P0[e] = 0.f;
+            P0[a.plane_stride + e] = 0.f;
+            P0[2 * a.plane_stride + e] = 0.f;
+        }
+    __syncthreads();
+    float* P = P0 + (a.mode == PK_GET ? a.sel_plane * a.plane_stride : 0);
+    const uint32_t seed = a.mode == PK_INIT ? a.seeds[cand] : 0;
+    for (int i = 0; i < cd.L; ++i) {
+        float* vb = P + i * g.vec_cell_stride;
+        const float bound = (float)(1.0 / sqrt((double)cd.K_in[i]));
+        const uint32_t hb = d_hash_h0(d_param_seed(seed, 2 * i + 1));
+        for (int r = tid; r < g.R; r += 256) {
+            if (a.mode == PK_SET) {
+                vb[VEC_B * g.Rp + r] = a.flat[cd.f_b[i] + r];
+                if (g.bn) {
+                    vb[VEC_G * g.Rp + r] = a.flat[cd.f_bn[i] + r];
+                    vb[VEC_BE * g.Rp + r] = a.flat[cd.f_bn[i] + g.R + r];
+                    vb[VEC_RM * g.Rp + r] = a.flat[cd.f_bn[i] + 2 * g.R + r];
+                    vb[VEC_RV * g.Rp + r] = a.flat[cd.f_bn[i] + 3 * g.R + r];
+                }
+            } else if (a.mode == PK_GET) {
+                a.flat[cd.f_b[i] + r] = vb[VEC_B * g.Rp + r];
+                if (g.bn) {
+                    a.flat[cd.f_bn[i] + r] = vb[VEC_G * g.Rp + r];
+                    a.flat[cd.f_bn[i] + g.R + r] = vb[VEC_BE * g.Rp + r];
+                    // running stats exist only in plane 0
+                    a.flat[cd.f_bn[i] + 2 * g.R + r] = a.sel_plane == 0 ? vb[VEC_RM * g.Rp + r] : 0.f;
+                    a.flat[cd.f_bn[i] + 3 * g.R + r] = a.sel_plane == 0 ? vb[VEC_RV * g.Rp + r] : 0.f;
+                }
+            } else {
+                vb[VEC_B * g.Rp + r] = (d_hash_u01(hb, (uint32_t)r) * 2.0f - 1.0f) * bound;
+                if (g.bn) {
+                    vb[VEC_G * g.Rp + r] = 1.0f;
+                    vb[VEC_RV * g.Rp + r] = 1.0f;
+                }
+            }
+        }
+        if (tid == 0) {
+            if (a.mode == PK_SET) vb[5 * g.Rp] = a.flat[cd.f_alpha + i];
+            else if (a.mode == PK_GET) a.flat[cd.f_alpha + i] = vb[5 * g.Rp];
+            else if (g.alphas) {
+                const uint32_t ha = d_hash_h0(d_param_seed(seed, 40 + i));
+                const float u0 = d_hash_u01(ha, 0), u1 = d_hash_u01(ha, 1), u2 = d_hash_u01(ha, 2), u3 = d_hash_u01(ha, 3);
+                vb[5 * g.Rp] = ((((u0 + u1) + (u2 + u3)) - 2.0f) * 1.7320508075688772f) * 0.1f;
+            }
+        }
+    }
+    {
+        float* hb_ = P + g.vec_head;
+        const float bound = (float)(1.0 / sqrt((double)g.R));
+        const uint32_t hh = d_hash_h0(d_param_seed(seed, 11));
+        for (int c = tid; c < g.C; c += 256) {
+            if (a.mode == PK_SET) hb_[c] = a.flat[cd.f_bc + c];
+            else if (a.mode == PK_GET) a.flat[cd.f_bc + c] = hb_[c];
+            else hb_[c] = (d_hash_u01(hh, (uint32_t)c) * 2.0f - 1.0f) * bound;
+        }
+    }
+}
+
+// ================================================================================================
+// Host side: C ABI
+// ================================================================================================
+struct mfas_population {
+    mfas_hyper hp;
+    Geo g;
+    int K = 0, device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<CandDev> cands;
+    std::vector<SegDesc> descs;
+    std::vector<int> desc_start;    // K+1
+    std::vector<int64_t> nparams;
+    std::vector<int64_t> cand_plane_base, cand_plane_size;
+    float* plane = nullptr;
+    float* wt = nullptr;
+    float* stepbuf = nullptr;
+    float* best = nullptr;          // snapshot_best: copy of plane 0
+    int64_t plane_stride = 0, wt_size = 0, step_total = 0;
+    CandDev* d_cands = nullptr;
+    SegDesc* d_descs = nullptr;
+    DevStats* d_stats = nullptr;
+    int32_t* d_status = nullptr;
+    uint32_t* d_seeds = nullptr;
+    long long* d_corr = nullptr;
+    size_t lds_sweep = 0, lds_chain = 0, lds_eval = 0;
+    int mbe = 4, nrbw = 1;
+    int stats_cap = 0;
+    // profiling of the dominant kernel
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;     // pairs
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0, bytes_per_launch = 0.0;
+    double alg_state_bytes = 0.0, alg_feat_elems = 0.0;
+};
+
+static inline int ceil16(int x) { return (x + 15) & ~15; }
+
+extern "C" const char* mfas_last_error(void) { return g_err.c_str(); }
+extern "C" int mfas_version(void) { return 100; }
+
+static int pick_chunk(int cols_p, int target) {
+    int best = 16;
+    for (int c = 16; c <= cols_p && c <= target; c += 16)
+        if (cols_p % c == 0) best = c;
+    return best;
+}
+
+template <typename KT>
+static hipError_t set_lds(KT kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells,
+                                      const uint32_t* drop_seeds, int32_t K, int32_t device, void* hip_stream,
+                                      int32_t chunk_cols, mfas_population** out) {
+    if (!hp || !confs || !n_cells || !out || K <= 0) return fail(MFAS_EINVAL, "null argument or K <= 0");
+    if (hp->R < 1 || hp->R > 512 || hp->C < 1 || hp->C > 256) return fail(MFAS_EINVAL, "R must be in [1,512], C in [1,256]");
+    if (hp->B < 2 || hp->B > 64) return fail(MFAS_EINVAL, "batchsize must be in [2,64]");
+    if (!(hp->drpt > 1e-10) && !hp->bn)   // ntu_searchable.py:274-284: `op` never assigned
+        return fail(MFAS_EINVAL, "illegal cell variant: drpt < 1e-10 without batchnorm (reference: UnboundLocalError)");
+    if (hp->drpt >= 1.0) return fail(MFAS_EINVAL, "drpt must be < 1");
+    for (int j = 0; j < 4; ++j)
+        if (hp->s_sizes[j] < 16 || hp->s_sizes[j] % 16 || hp->v_sizes[j] < 16 || hp->v_sizes[j] % 16)
+            return fail(MFAS_EINVAL, "tap widths must be positive multiples of 16");
+    mfas_population* p = new (std::nothrow) mfas_population();
+    if (!p) return fail(MFAS_ENOMEM, "host alloc");
+    p->hp = *hp;
+    p->K = K;
+    p->device = device;
+    p->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { delete p; return fail(MFAS_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
+
+    Geo& g = p->g;
+    memset(&g, 0, sizeof(g));
+    g.R = hp->R; g.C = hp->C; g.Rp = ceil16(hp->R); g.Cp = ceil16(hp->C);
+    g.nrb = g.Rp / 16; g.ncb = g.Cp / 16; g.B = hp->B;
+    g.MB = (hp->B + 15) / 16; if (g.MB == 3) g.MB = 4;
+    g.Bp = g.MB * 16;
+    g.bn = hp->bn != 0; g.alphas = hp->alphas != 0; g.multitask = hp->multitask != 0;
+    g.use_drop = hp->drpt > 1e-10;
+    g.drop_scale = g.use_drop ? (float)(1.0 / (1.0 - hp->drpt)) : 1.0f;
+    g.drop_thr = g.use_drop ? (uint32_t)floor(hp->drpt * 16777216.0) : 0u;
+    g.bn_eps = (float)hp->bn_eps; g.bn_mom = (float)hp->bn_momentum;
+    g.vec_cell_stride = 5 * g.Rp + 16;
+    g.vec_head = MFAS_MAX_CELLS * g.vec_cell_stride;
+    for (int j = 0; j < 4; ++j) { g.sw[j] = hp->s_sizes[j]; g.vw[j] = hp->v_sizes[j]; }
+    const int vec_size = (g.vec_head + g.Cp + 63) & ~63;
+
+    // ---- chunk target: enough workgroups to fill 256 CUs several times over
+    int target = chunk_cols;
+    if (target <= 0) {
+        double totF = 0;
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < n_cells[k]; ++i)
+                totF += hp->s_sizes[confs[(k * 4 + i) * 3] & 3] + hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 3];
+        target = 256;
+        while (target > 64 && totF / target < 1024.0) target >>= 1;
+    }
+    target = std::max(16, (target / 16) * 16);
+
+    p->cands.resize(K);
+    p->desc_start.assign(K + 1, 0);
+    p->nparams.resize(K);
+    p->cand_plane_base.resize(K);
+    p->cand_plane_size.resize(K);
+    int64_t plane_off = 0, wt_off = 0, step_off = 0;
+    double alg_bytes = 0.0, alg_feat = 0.0;
+    int max_slots = 0;
+    std::vector<int> slots(K);
+    // first pass: layout
+    for (int k = 0; k < K; ++k) {
+        CandDev& c = p->cands[k];
+        memset(&c, 0, sizeof(c));
+        const int L = n_cells[k];
+        if (L < 1 || L > MFAS_MAX_CELLS) { delete p; return fail(MFAS_EINVAL, "n_cells must be in [1,4]"); }
+        c.L = L;
+        c.drop_seed = drop_seeds ? drop_seeds[k] : (uint32_t)k;
+        p->desc_start[k] = (int)p->descs.size();
+        p->cand_plane_base[k] = plane_off;
+        c.vec_off = plane_off;
+        plane_off += vec_size;
+        int64_t f = 0;
+        c.f_alpha = f; f += L;
+        int pslot = 0;
+        for (int i = 0; i < L; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                c.conf[i][j] = confs[(k * 4 + i) * 3 + j];
+                c.seg_off[i][j] = -1;
+            }
+            if (c.conf[i][0] < 0 || c.conf[i][0] > 3 || c.conf[i][1] < 0 || c.conf[i][1] > 3 || c.conf[i][2] < 0 || c.conf[i][2] > 2) {
+                delete p; return fail(MFAS_EINVAL, "configuration entry out of range");
+            }
+            const int sw = hp->s_sizes[c.conf[i][0]], vw = hp->v_sizes[c.conf[i][1]];
+            const int Kin = sw + vw + (i > 0 ? hp->R : 0);
+            c.K_in[i] = Kin;
+            c.f_W[i] = f; f += (int64_t)hp->R * Kin;
+            c.f_b[i] = f; f += hp->R;
+            c.f_bn[i] = f; if (hp->bn) f += 4 * (int64_t)hp->R;
+            c.part_cell_off[i] = pslot;
+            const float bound = (float)(1.0 / sqrt((double)Kin));
+            const int widths[3] = {sw, vw, g.Rp};
+            const int col0[3] = {0, sw, sw + vw};
+            for (int j = 0; j < 3; ++j) {
+                if (j == 2 && i == 0) continue;
+                const int cols_p = widths[j];
+                const int cc = j < 2 ? pick_chunk(cols_p, target) : cols_p;
+                const int nch = cols_p / cc;
+                c.seg_off[i][j] = plane_off;
+                c.seg_cc[i][j] = cc;
+                c.seg_cols[i][j] = cols_p;
+                if (j == 0) c.nch_s[i] = nch;
+                if (j == 1) c.nch_v[i] = nch;
+                if (j == 2) { c.outT_off[i] = wt_off; }
+                for (int ch = 0; ch < nch; ++ch) {
+                    SegDesc d;
+                    memset(&d, 0, sizeof(d));
+                    d.cand = k; d.kind = j; d.cell = i; d.tap = j < 2 ? c.conf[i][j] : 0;
+                    d.k0 = ch * cc; d.cc = cc; d.rows_p = g.Rp; d.width = j < 2 ? widths[j] : g.Rp;
+                    d.w_off = plane_off + (int64_t)ch * g.Rp * cc;
+                    d.wt_off = j == 2 ? wt_off : -1;
+                    d.part_idx = j < 2 ? (j == 0 ? ch : c.nch_s[i] + ch) : 0;
+                    d.rows = hp->R; d.cols = j < 2 ? widths[j] : hp->R;
+                    d.src_off = c.f_W[i]; d.src_ld = Kin; d.src_col0 = col0[j];
+                    d.init_seed = 2 * i; d.init_bound = bound;
+                    p->descs.push_back(d);
+                }
+                if (j < 2) pslot += nch;
+                plane_off += (int64_t)g.Rp * cols_p;
+                if (j == 2) wt_off += (int64_t)g.Rp * g.Rp;
+                alg_bytes += 24.0 * hp->R * (j < 2 ? widths[j] : hp->R);
+                if (j < 2) alg_feat += (double)hp->B * widths[j];   // x elements (dtype size applied at train time)
+            }
+        }
+        c.f_Wc = f; f += (int64_t)hp->C * hp->R;
+        c.f_bc = f; f += hp->C;
+        p->nparams[k] = f;
+        {   // head
+            c.head_off = plane_off;
+            c.headT_off = wt_off;
+            SegDesc d;
+            memset(&d, 0, sizeof(d));
+            d.cand = k; d.kind = KIND_HEAD; d.cell = L - 1; d.tap = 0;
+            d.k0 = 0; d.cc = g.Rp; d.rows_p = g.Cp; d.width = g.Rp;
+            d.w_off = plane_off; d.wt_off = wt_off; d.part_idx = 0;
+            d.rows = hp->C; d.cols = hp->R;
+            d.src_off = c.f_Wc; d.src_ld = hp->R; d.src_col0 = 0;
+            d.init_seed = 10; d.init_bound = (float)(1.0 / sqrt((double)hp->R));
+            p->descs.push_back(d);
+            plane_off += (int64_t)g.Cp * g.Rp;
+            wt_off += (int64_t)g.Cp * g.Rp;
+            alg_bytes += 24.0 * hp->C * hp->R;
+        }
+        plane_off = (plane_off + 63) & ~63LL;
+        p->cand_plane_size[k] = plane_off - p->cand_plane_base[k];
+        slots[k] = pslot;
+        max_slots = std::max(max_slots, pslot);
+    }
+    p->desc_start[K] = (int)p->descs.size();
+    // step buffers (same geometry for every candidate: sized for the largest)
+    {
+        const int64_t br = (int64_t)g.Bp * g.Rp;
+        int64_t o = 0;
+        g.sb_part = o; o += (int64_t)max_slots * br;
+        g.sb_dy = o; o += MFAS_MAX_CELLS * br;
+        g.sb_xo = o; o += MFAS_MAX_CELLS * br;
+        g.sb_dlog = o; o += (int64_t)g.Bp * g.Cp;
+        g.sb_sav = o; o += 3 * MFAS_MAX_CELLS * br;
+        g.sb_gsc = o; o += 16;
+        g.sb_size = (o + 63) & ~63LL;
+        for (int k = 0; k < K; ++k) { p->cands[k].step_off = step_off; step_off += g.sb_size; }
+    }
+    p->plane_stride = plane_off;
+    p->wt_size = wt_off;
+    p->step_total = step_off;
+    p->alg_state_bytes = alg_bytes;
+    p->alg_feat_elems = alg_feat;
+    p->bytes_per_launch = alg_bytes + 4.0 * alg_feat;
+
+    // ---- LDS budgets
+    size_t ls = 0;
+    for (const SegDesc& d : p->descs) {
+        const int nrb = d.rows_p / 16;
+        size_t fl = (size_t)g.Bp * (d.cc + 16) + (size_t)g.Bp * (d.cc + 4) + (size_t)g.Bp * (d.rows_p + 16);
+        if (nrb < 4) fl += (size_t)4 * nrb * g.MB * 256;
+        ls = std::max(ls, fl * 4);
+    }
+    p->lds_sweep = ls;
+    p->lds_chain = ((size_t)4 * g.Bp * (g.Rp + 4) + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * g.Rp + 3 * g.Bp + 16) * 4;
+    p->nrbw = (g.nrb + 3) / 4;
+    if (p->nrbw == 3) p->nrbw = 4;
+    for (p->mbe = 4; p->mbe >= 1; p->mbe >>= 1) {
+        const int ME = p->mbe * 16;
+        p->lds_eval = ((size_t)ME * (EVAL_CE + 4) + (size_t)2 * ME * (g.Rp + 4) + (size_t)ME * (g.Cp + 4)) * 4;
+        if (p->lds_eval <= 120 * 1024) break;
+    }
+    if (p->mbe < 1 || p->nrbw > 8 || p->lds_sweep > 150 * 1024 || p->lds_chain > 150 * 1024) {
+        delete p;
+        return fail(MFAS_EINVAL, "geometry does not fit the 160 KiB LDS (R / batchsize too large)");
+    }
+
+#define CREATE_CHK(x)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            std::string m_ = std::string(#x) + ": " + hipGetErrorString(e_);                       \
+            mfas_population_destroy(p);                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? MFAS_ENOMEM : MFAS_EHIP, m_);                  \
+        }                                                                                          \
+    } while (0)
+    CREATE_CHK(hipMalloc(&p->plane, sizeof(float) * 3 * (size_t)p->plane_stride));
+    CREATE_CHK(hipMalloc(&p->wt, sizeof(float) * (size_t)std::max<int64_t>(p->wt_size, 64)));
+    CREATE_CHK(hipMalloc(&p->stepbuf, sizeof(float) * (size_t)p->step_total));
+    CREATE_CHK(hipMalloc(&p->d_cands, sizeof(CandDev) * K));
+    CREATE_CHK(hipMalloc(&p->d_descs, sizeof(SegDesc) * p->descs.size()));
+    CREATE_CHK(hipMalloc(&p->d_status, sizeof(int32_t) * K));
+    CREATE_CHK(hipMalloc(&p->d_seeds, sizeof(uint32_t) * K));
+    CREATE_CHK(hipMalloc(&p->d_corr, sizeof(long long)));
+    CREATE_CHK(hipMemcpy(p->d_cands, p->cands.data(), sizeof(CandDev) * K, hipMemcpyHostToDevice));
+    CREATE_CHK(hipMemcpy(p->d_descs, p->descs.data(), sizeof(SegDesc) * p->descs.size(), hipMemcpyHostToDevice));
+    CREATE_CHK(hipMemsetAsync(p->plane, 0, sizeof(float) * 3 * (size_t)p->plane_stride, p->stream));
+    CREATE_CHK(hipMemsetAsync(p->wt, 0, sizeof(float) * (size_t)std::max<int64_t>(p->wt_size, 64), p->stream));
+    CREATE_CHK(hipMemsetAsync(p->stepbuf, 0, sizeof(float) * (size_t)p->step_total, p->stream));
+    CREATE_CHK(set_lds(k_sweep<1>, p->lds_sweep));
+    CREATE_CHK(set_lds(k_sweep<2>, p->lds_sweep));
+    CREATE_CHK(set_lds(k_sweep<4>, p->lds_sweep));
+    CREATE_CHK(set_lds(k_chain<1>, p->lds_chain));
+    CREATE_CHK(set_lds(k_chain<2>, p->lds_chain));
+    CREATE_CHK(set_lds(k_chain<4>, p->lds_chain));
+    CREATE_CHK(hipStreamSynchronize(p->stream));
+    *out = p;
+    return MFAS_OK;
+}
+
+extern "C" void mfas_population_destroy(mfas_population* p) {
+    if (!p) return;
+    hipSetDevice(p->device);
+    hipStreamSynchronize(p->stream);
+    for (hipEvent_t e : p->ev) hipEventDestroy(e);
+    hipFree(p->plane); hipFree(p->wt); hipFree(p->stepbuf); hipFree(p->best);
+    hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
+    hipFree(p->d_seeds); hipFree(p->d_corr);
+    delete p;
+}
+
+extern "C" int64_t mfas_population_param_count(const mfas_population* p, int32_t k) {
+    if (!p || k < 0 || k >= p->K) return fail(MFAS_EINVAL, "bad candidate index");
+    return p->nparams[k];
+}
+
+static PackArgs pack_args(mfas_population* p, int mode, int plane, float* flat) {
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.desc = p->d_descs; a.cands = p->d_cands; a.plane = p->plane; a.plane_stride = p->plane_stride;
+    a.wt = p->wt; a.flat = flat; a.seeds = p->d_seeds; a.mode = mode; a.sel_plane = plane; a.g = p->g;
+    return a;
+}
+
+extern "C" int mfas_population_set_params(mfas_population* p, int32_t k, const float* flat) {
+    if (!p || !flat || k < 0 || k >= p->K) return fail(MFAS_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(p->device));
+    PackArgs a = pack_args(p, PK_SET, 0, const_cast<float*>(flat));
+    a.desc = p->d_descs + p->desc_start[k];
+    const int n = p->desc_start[k + 1] - p->desc_start[k];
+    hipLaunchKernelGGL(k_pack, dim3(n), dim3(256), 0, p->stream, a);
+    hipLaunchKernelGGL(k_vec, dim3(1), dim3(256), 0, p->stream, a, (int)k);
+    HIPCHK(hipGetLastError());
+    return MFAS_OK;
+}
+
+extern "C" int mfas_population_get_params(mfas_population* p, int32_t k, int32_t plane, float* flat) {
+    if (!p || !flat || k < 0 || k >= p->K || plane < 0 || plane > 2) return fail(MFAS_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemsetAsync(flat, 0, sizeof(float) * p->nparams[k], p->stream));
+    PackArgs a = pack_args(p, PK_GET, plane, flat);
+    a.desc = p->d_descs + p->desc_start[k];
+    const int n = p->desc_start[k + 1] - p->desc_start[k];
+    hipLaunchKernelGGL(k_pack, dim3(n), dim3(256), 0, p->stream, a);
+    hipLaunchKernelGGL(k_vec, dim3(1), dim3(256), 0, p->stream, a, (int)k);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return MFAS_OK;
+}
+
+extern "C" int mfas_population_init(mfas_population* p, const uint32_t* seeds) {
+    if (!p || !seeds) return fail(MFAS_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpyAsync(p->d_seeds, seeds, sizeof(uint32_t) * p->K, hipMemcpyHostToDevice, p->stream));
+    PackArgs a = pack_args(p, PK_INIT, 0, nullptr);
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)p->descs.size()), dim3(256), 0, p->stream, a);
+    hipLaunchKernelGGL(k_vec, dim3(p->K), dim3(256), 0, p->stream, a, -1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(p->stream));   // seeds is a host buffer
+    return MFAS_OK;
+}
+
+static int check_table(const mfas_population* p, const mfas_table* t, bool need_logits) {
+    if (!t || t->N <= 0 || !t->label) return fail(MFAS_EINVAL, "table: null or empty");
+    if (t->dtype < 0 || t->dtype > 2) return fail(MFAS_EINVAL, "table: bad dtype");
+    for (int j = 0; j < 4; ++j)
+        if (!t->s[j] || !t->v[j]) return fail(MFAS_EINVAL, "table: null tap pointer");
+    if (need_logits && (!t->vlogit || !t->slogit)) return fail(MFAS_EINVAL, "multitask needs vlogit/slogit");
+    (void)p;
+    return MFAS_OK;
+}
+
+template <int MB>
+static void launch_sweep(mfas_population* p, const SweepArgs& a) {
+    hipLaunchKernelGGL(k_sweep<MB>, dim3((unsigned)p->descs.size()), dim3(256), p->lds_sweep, p->stream, a);
+}
+template <int MB>
+static void launch_chain(mfas_population* p, const ChainArgs& a) {
+    hipLaunchKernelGGL(k_chain<MB>, dim3(p->K), dim3(256), p->lds_chain, p->stream, a);
+}
+
+template <int MBE, int NRBW>
+static hipError_t launch_eval_t(mfas_population* p, const EvalArgs& a, int ncand) {
+    hipError_t e = set_lds(k_eval<MBE, NRBW>, p->lds_eval);
+    if (e != hipSuccess) return e;
+    const int ME = MBE * 16;
+    const unsigned nblk = (unsigned)((a.nrows + ME - 1) / ME);
+    hipLaunchKernelGGL((k_eval<MBE, NRBW>), dim3(nblk, ncand), dim3(256), p->lds_eval, p->stream, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch_eval(mfas_population* p, const EvalArgs& a, int ncand) {
+#define EV_CASE(M, N) if (p->mbe == M && p->nrbw == N) return launch_eval_t<M, N>(p, a, ncand);
+    EV_CASE(4, 1) EV_CASE(4, 2) EV_CASE(4, 4) EV_CASE(4, 8)
+    EV_CASE(2, 1) EV_CASE(2, 2) EV_CASE(2, 4) EV_CASE(2, 8)
+    EV_CASE(1, 1) EV_CASE(1, 2) EV_CASE(1, 4) EV_CASE(1, 8)
+#undef EV_CASE
+    return hipErrorInvalidValue;
+}
+
+extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train, const mfas_table* dev,
+                                     const int32_t* order, const float* step_scalars, int32_t epochs,
+                                     int64_t max_steps, int32_t snapshot_best, mfas_epoch_stats* stats,
+                                     int32_t* status) {
+    if (!p || !step_scalars || epochs <= 0 || !stats) return fail(MFAS_EINVAL, "bad argument");
+    int rc = check_table(p, train, p->g.multitask);
+    if (rc) return rc;
+    const bool do_dev = max_steps < 0;
+    if (do_dev) { rc = check_table(p, dev, p->g.multitask); if (rc) return rc; }
+    HIPCHK(hipSetDevice(p->device));
+    const Geo& g = p->g;
+    const int K = p->K, B = g.B;
+    const int64_t N = train->N;
+    const int64_t nb = (N + B - 1) / B;
+    if (N - (nb - 1) * B == 1 && g.bn)   // torch BatchNorm1d raises on a size-1 train batch
+        return fail(MFAS_EINVAL, "final train batch of size 1 with batchnorm (reference raises ValueError)");
+
+    if (p->stats_cap < K * epochs) {
+        hipFree(p->d_stats); p->d_stats = nullptr;
+        HIPCHK(hipMalloc(&p->d_stats, sizeof(DevStats) * K * epochs));
+        p->stats_cap = K * epochs;
+    }
+    HIPCHK(hipMemsetAsync(p->d_stats, 0, sizeof(DevStats) * K * epochs, p->stream));
+    HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int32_t) * K, p->stream));
+    if (snapshot_best && !p->best) HIPCHK(hipMalloc(&p->best, sizeof(float) * (size_t)p->plane_stride));
+    std::vector<double> best_acc(K, 0.0);
+    std::vector<DevStats> hstats((size_t)K * epochs);
+
+    const mfas_hyper& hp = p->hp;
+    AdamC ac;
+    ac.w1 = (float)(1.0 - hp.beta1); ac.b2 = (float)hp.beta2; ac.w2 = (float)(1.0 - hp.beta2);
+    ac.eps = (float)hp.adam_eps; ac.wd = (float)hp.wd; ac.ss = 0.f; ac.bc2s = 1.f;
+
+    SweepArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.desc = p->d_descs; sa.cands = p->d_cands; sa.plane = p->plane; sa.plane_stride = p->plane_stride;
+    sa.wt = p->wt; sa.stepbuf = p->stepbuf; sa.tab = *train; sa.order = order; sa.g = g; sa.ac = ac;
+    ChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.cands = p->d_cands; ca.plane = p->plane; ca.plane_stride = p->plane_stride; ca.wt = p->wt;
+    ca.stepbuf = p->stepbuf; ca.tab = *train; ca.order = order; ca.E = epochs; ca.g = g;
+    ca.stats = p->d_stats; ca.status = p->d_status; ca.ac = ac;
+
+    p->prof_launches = 0; p->prof_ms = 0.0;
+    size_t ev_used = 0;
+    const int elt = train->dtype == MFAS_DT_F32 ? 4 : 2;
+    // algorithmic HBM bytes of one update+forward sweep: 24 B/param (read+write W,m,v) + the batch's taps + labels
+    p->bytes_per_launch = p->alg_state_bytes + p->alg_feat_elems * elt + 8.0 * B * K;
+
+    auto sweep = [&](int upd, int fwd, int64_t ep, int64_t t, float ss, float bc2s) {
+        sa.do_update = upd; sa.do_forward = fwd;
+        sa.pos_t = ep * N + t * B; sa.base_t = (int)(t * B);
+        sa.nvalid_t = (int)std::min<int64_t>(B, N - t * B);
+        const int64_t tn = fwd ? (upd ? t + 1 : t) : t;
+        sa.pos_n = ep * N + tn * B; sa.base_n = (int)(tn * B);
+        sa.nvalid_n = (int)std::min<int64_t>(B, N - tn * B);
+        sa.ac.ss = ss; sa.ac.bc2s = bc2s;
+        const bool prof = p->profiling && upd && fwd;
+        if (prof) {
+            if (p->ev.size() < ev_used + 2) {
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                p->ev.push_back(e0); p->ev.push_back(e1);
+            }
+            hipEventRecord(p->ev[ev_used], p->stream);
+        }
+        if (g.MB == 1) launch_sweep<1>(p, sa);
+        else if (g.MB == 2) launch_sweep<2>(p, sa);
+        else launch_sweep<4>(p, sa);
+        if (prof) { hipEventRecord(p->ev[ev_used + 1], p->stream); ev_used += 2; }
+    };
+
+    int64_t gstep = 0;
+    bool stop = false;
+    for (int ep = 0; ep < epochs && !stop; ++ep) {
+        // prologue: forward partial sums for the first batch of the epoch
+        sweep(0, 1, ep, 0, 0.f, 1.f);
+        for (int64_t t = 0; t < nb; ++t) {
+            if (max_steps >= 0 && gstep >= max_steps) { stop = true; break; }
+            const float ss = step_scalars[2 * gstep], bc2s = step_scalars[2 * gstep + 1];
+            ca.pos_t = (int64_t)ep * N + t * B; ca.base_t = (int)(t * B);
+            ca.nvalid = (int)std::min<int64_t>(B, N - t * B);
+            ca.gstep = (int)gstep; ca.epoch = ep;
+            ca.ac.ss = ss; ca.ac.bc2s = bc2s;
+            if (g.MB == 1) launch_chain<1>(p, ca);
+            else if (g.MB == 2) launch_chain<2>(p, ca);
+            else launch_chain<4>(p, ca);
+            const bool last = (t + 1 == nb) || (max_steps >= 0 && gstep + 1 >= max_steps);
+            sweep(1, last ? 0 : 1, ep, t, ss, bc2s);
+            ++gstep;
+        }
+        HIPCHK(hipGetLastError());
+        if (do_dev) {
+            EvalArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.cands = p->d_cands; ea.plane = p->plane; ea.tab = *dev; ea.row0 = 0; ea.nrows = dev->N;
+            ea.cand0 = 0; ea.epoch = ep; ea.E = epochs; ea.g = g; ea.stats = p->d_stats;
+            HIPCHK(launch_eval(p, ea, K));
+            if (snapshot_best) {
+                HIPCHK(hipMemcpyAsync(hstats.data(), p->d_stats, sizeof(DevStats) * K * epochs, hipMemcpyDeviceToHost, p->stream));
+                HIPCHK(hipStreamSynchronize(p->stream));
+                for (int k = 0; k < K; ++k) {
+                    const double acc = (double)hstats[(size_t)k * epochs + ep].dev_corr / (double)dev->N;
+                    if (acc > best_acc[k]) {   // strict >, from 0 (train_searchable/ntu.py:82)
+                        best_acc[k] = acc;
+                        HIPCHK(hipMemcpyAsync(p->best + p->cand_plane_base[k], p->plane + p->cand_plane_base[k],
+                                              sizeof(float) * p->cand_plane_size[k], hipMemcpyDeviceToDevice, p->stream));
+                    }
+                }
+            }
+        }
+    }
+    if (snapshot_best && do_dev) {
+        for (int k = 0; k < K; ++k)
+            if (best_acc[k] > 0.0)
+                HIPCHK(hipMemcpyAsync(p->plane + p->cand_plane_base[k], p->best + p->cand_plane_base[k],
+                                      sizeof(float) * p->cand_plane_size[k], hipMemcpyDeviceToDevice, p->stream));
+    }
+    HIPCHK(hipMemcpyAsync(hstats.data(), p->d_stats, sizeof(DevStats) * K * epochs, hipMemcpyDeviceToHost, p->stream));
+    std::vector<int32_t> hstatus(K, 0);
+    HIPCHK(hipMemcpyAsync(hstatus.data(), p->d_status, sizeof(int32_t) * K, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    for (size_t i = 0; i < hstats.size(); ++i) {
+        stats[i].train_loss_sum = hstats[i].train_loss;
+        stats[i].dev_loss_sum = hstats[i].dev_loss;
+        stats[i].train_corrects = hstats[i].train_corr;
+        stats[i].dev_corrects = hstats[i].dev_corr;
+    }
+    if (status) memcpy(status, hstatus.data(), sizeof(int32_t) * K);
+    if (p->profiling) {
+        for (size_t i = 0; i + 1 < ev_used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) == hipSuccess) { p->prof_ms += ms; p->prof_launches++; }
+        }
+    }
+    return MFAS_OK;
+}
+
+extern "C" int mfas_population_forward(mfas_population* p, int32_t k, const mfas_table* tab, int64_t row0,
+                                       int64_t nrows, float* logits, int64_t* corrects) {
+    if (!p || k < 0 || k >= p->K || nrows <= 0 || row0 < 0) return fail(MFAS_EINVAL, "bad argument");
+    int rc = check_table(p, tab, p->g.multitask);
+    if (rc) return rc;
+    if (row0 + nrows > tab->N) return fail(MFAS_EINVAL, "row range outside the table");
+    HIPCHK(hipSetDevice(p->device));
+    EvalArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.cands = p->d_cands; ea.plane = p->plane; ea.tab = *tab; ea.row0 = row0; ea.nrows = nrows;
+    ea.cand0 = k; ea.epoch = 0; ea.E = 1; ea.g = p->g; ea.logits = logits;
+    if (corrects) {
+        HIPCHK(hipMemsetAsync(p->d_corr, 0, sizeof(long long), p->stream));
+        ea.corr_out = p->d_corr;
+    }
+    HIPCHK(launch_eval(p, ea, 1));
+    if (corrects) {
+        long long h = 0;
+        HIPCHK(hipMemcpyAsync(&h, p->d_corr, sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+        *corrects = (int64_t)h;
+    }
+    return MFAS_OK;
+}
+
+extern "C" int mfas_population_set_profiling(mfas_population* p, int32_t on) {
+    if (!p) return fail(MFAS_EINVAL, "null");
+    p->profiling = on != 0;
+    return MFAS_OK;
+}
+
+extern "C" int mfas_population_sweep_profile(const mfas_population* p, int64_t* launches, double* total_ms,
+                                             double* bytes_per_launch) {
+    if (!p) return fail(MFAS_EINVAL, "null");
+    if (launches) *launches = p->prof_launches;
+    if (total_ms) *total_ms = p->prof_ms;
+    if (bytes_per_launch) *bytes_per_launch = p->bytes_per_launch;
+    return MFAS_OK;
+}

@@ -1,0 +1,298 @@
+"""Python face of the HIP engine: hyper-parameters, feature tables, and the lockstep population.
+
+PyTorch is used for device memory, the current HIP stream and ``torch.distributed`` only; all
+arithmetic of the path runs inside ``libmfas_hip.so`` (mfas_amd/csrc/mfas_hip.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .scheduler import adam_step_scalars
+
+S_SIZES = (128, 256, 1024, 512)    # /root/reference/models/search/ntu_searchable.py:291
+V_SIZES = (512, 1024, 2048, 2048)  # ntu_searchable.py:292
+TAPS = ("s0", "s1", "s2", "s3", "v0", "v1", "v2", "v3")
+
+
+@dataclass
+class Hyper:
+    """The ``args`` fields the path reads (ntu_searchable.py:28-84,200-292)."""
+    R: int = 16
+    C: int = 60
+    B: int = 20
+    bn: bool = False
+    drpt: float = 0.5
+    alphas: bool = False
+    multitask: bool = False
+    wd: float = 1e-4            # ntu_searchable.py:65
+    beta1: float = 0.9
+    beta2: float = 0.999
+    adam_eps: float = 1e-8
+    bn_eps: float = 1e-5
+    bn_momentum: float = 0.1
+    s_sizes: Sequence[int] = S_SIZES
+    v_sizes: Sequence[int] = V_SIZES
+
+    @classmethod
+    def from_args(cls, args) -> "Hyper":
+        s_sizes = list(getattr(args, "s_sizes", S_SIZES))
+        if not hasattr(args, "s_sizes") and hasattr(args, "vid_len"):
+            s_sizes[2] = int(args.vid_len[1]) * 32      # ntu_searchable.py:291
+        return cls(R=int(args.inner_representation_size), C=int(args.num_outputs), B=int(args.batchsize),
+                   bn=bool(args.batchnorm), drpt=float(args.drpt), alphas=bool(args.alphas),
+                   multitask=bool(getattr(args, "multitask", False)), s_sizes=tuple(s_sizes),
+                   v_sizes=tuple(getattr(args, "v_sizes", V_SIZES)))
+
+    def to_c(self) -> _lib.mfas_hyper:
+        h = _lib.mfas_hyper()
+        h.R, h.C, h.B = self.R, self.C, self.B
+        h.bn, h.alphas, h.multitask = int(self.bn), int(self.alphas), int(self.multitask)
+        h.drpt = float(self.drpt)
+        h.wd, h.beta1, h.beta2 = self.wd, self.beta1, self.beta2
+        h.adam_eps, h.bn_eps, h.bn_momentum = self.adam_eps, self.bn_eps, self.bn_momentum
+        for j in range(4):
+            h.s_sizes[j] = int(self.s_sizes[j])
+            h.v_sizes[j] = int(self.v_sizes[j])
+        return h
+
+
+def cell_in_features(conf, i, hp: Hyper) -> int:
+    return hp.s_sizes[int(conf[i][0])] + hp.v_sizes[int(conf[i][1])] + (hp.R if i > 0 else 0)
+
+
+def flat_layout(conf, hp: Hyper):
+    """[(state_dict key, shape, offset)] of a candidate's central parameters in the engine's flat
+    order (= reference state_dict order, ntu_searchable.py:191-200), and the total float count."""
+    out, off = [], 0
+    L = len(conf)
+
+    def put(key, shape):
+        nonlocal off
+        out.append((key, tuple(shape), off))
+        off += int(np.prod(shape))
+
+    for i in range(L):
+        put(f"alphas.{i}.alpha_x", (1,))
+    for i in range(L):
+        K = cell_in_features(conf, i, hp)
+        put(f"fusion_layers.{i}.0.weight", (hp.R, K))
+        put(f"fusion_layers.{i}.0.bias", (hp.R,))
+        if hp.bn:
+            for nm in ("weight", "bias", "running_mean", "running_var"):
+                put(f"fusion_layers.{i}.2.{nm}", (hp.R,))
+    put("central_classifier.weight", (hp.C, hp.R))
+    put("central_classifier.bias", (hp.C,))
+    return out, off
+
+
+# ------------------------------------------------------------------------------------------------
+class FeatureTable:
+    """Pooled backbone taps for N samples resident in HBM: what ``Visual``/``Skeleton`` +
+    ``GlobalPooling2D`` hand to the fusion net (models/central/ntu.py:35-50,129-183;
+    ntu_searchable.py:211-225) plus labels (datasets/ntu.py:254)."""
+
+    def __init__(self, taps: Dict[str, torch.Tensor], label: torch.Tensor,
+                 vlogit: Optional[torch.Tensor] = None, slogit: Optional[torch.Tensor] = None):
+        dev = label.device
+        if dev.type != "cuda":
+            raise RuntimeError("FeatureTable must live on a HIP device (cuda:N); there is no CPU path")
+        dts = {t.dtype for t in taps.values()}
+        if len(dts) != 1:
+            raise ValueError("all taps must share one dtype")
+        self.dtype = dts.pop()
+        if self.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"unsupported tap dtype {self.dtype}")
+        self.N = int(label.shape[0])
+        self.taps = {k: v.contiguous() for k, v in taps.items()}
+        for k, v in self.taps.items():
+            if v.shape[0] != self.N or v.dim() != 2 or v.device != dev:
+                raise ValueError(f"tap {k}: expected (N, width) on {dev}")
+        self.label = label.to(torch.int32).contiguous()
+        self.vlogit = None if vlogit is None else vlogit.to(torch.float32).contiguous()
+        self.slogit = None if slogit is None else slogit.to(torch.float32).contiguous()
+        self.device = dev
+
+    def __len__(self):
+        return self.N
+
+    @classmethod
+    def from_numpy(cls, table: Dict[str, np.ndarray], device, dtype=torch.float32) -> "FeatureTable":
+        taps = {k: torch.from_numpy(np.ascontiguousarray(table[k])).to(device=device, dtype=dtype)
+                for k in TAPS if k in table}
+        lab = torch.from_numpy(np.asarray(table["label"]).astype(np.int32)).to(device)
+        vl = torch.from_numpy(table["vlogit"]).to(device) if "vlogit" in table else None
+        sl = torch.from_numpy(table["slogit"]).to(device) if "slogit" in table else None
+        return cls(taps, lab, vl, sl)
+
+    def to_c(self) -> _lib.mfas_table:
+        t = _lib.mfas_table()
+        some = next(iter(self.taps.values())).data_ptr()
+        for j in range(4):      # taps a population never selects may be absent: any valid pointer will do
+            t.s[j] = self.taps[f"s{j}"].data_ptr() if f"s{j}" in self.taps else some
+            t.v[j] = self.taps[f"v{j}"].data_ptr() if f"v{j}" in self.taps else some
+        t.vlogit = None if self.vlogit is None else self.vlogit.data_ptr()
+        t.slogit = None if self.slogit is None else self.slogit.data_ptr()
+        t.label = self.label.data_ptr()
+        t.N = self.N
+        t.dtype = _lib.MFAS_DT[str(self.dtype).replace("torch.", "")]
+        return t
+
+    def elem_size(self) -> int:
+        return 4 if self.dtype == torch.float32 else 2
+
+
+class FeatureLoader:
+    """What ``dataloaders['train'|'dev'|'test']`` is for the engine: the reference iterates a
+    DataLoader of {'rgb','ske','label'} batches (train_searchable/ntu.py:35-43); here the whole
+    table already sits in HBM and only the batch order remains of the loader."""
+
+    def __init__(self, table: FeatureTable, batch_size: int, shuffle: bool = True):
+        self.table = table
+        self.dataset = table            # len(loader.dataset) is read at ntu_searchable.py:29
+        self.batch_size = int(batch_size)
+        self.shuffle = bool(shuffle)
+
+    def __len__(self):
+        return -(-len(self.table) // self.batch_size)
+
+
+# ------------------------------------------------------------------------------------------------
+class Population:
+    """K candidates trained in lockstep on one GPU (handle on ``mfas_population``)."""
+
+    def __init__(self, hp: Hyper, confs: Sequence[np.ndarray], device, drop_seeds=None, chunk_cols=0):
+        self.lib = _lib.lib()
+        self.hp = hp
+        self.confs = [np.asarray(c, dtype=np.int64).reshape(-1, 3) for c in confs]
+        self.K = len(self.confs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the MFAS engine runs on a HIP device only (no CPU fallback)")
+        cf = np.zeros((self.K, 4, 3), np.int32)
+        nc = np.zeros(self.K, np.int32)
+        for k, c in enumerate(self.confs):
+            if not 1 <= len(c) <= 4:
+                raise ValueError("a configuration has 1..4 fusion cells")
+            cf[k, :len(c)] = c
+            nc[k] = len(c)
+        ds = None if drop_seeds is None else np.asarray(drop_seeds, np.uint32)
+        self._h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(idx):
+            stream = torch.cuda.current_stream().cuda_stream
+            hc = hp.to_c()
+            _lib.check(self.lib.mfas_population_create(
+                C.byref(hc), cf.ctypes.data, nc.ctypes.data, None if ds is None else ds.ctypes.data,
+                self.K, idx, C.c_void_p(stream), int(chunk_cols), C.byref(self._h)))
+        self._idx = idx
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.mfas_population_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def param_count(self, k: int) -> int:
+        n = self.lib.mfas_population_param_count(self._h, k)
+        if n < 0:
+            _lib.check(int(n))
+        return int(n)
+
+    def set_params(self, k: int, flat: torch.Tensor):
+        flat = flat.to(device=self.device, dtype=torch.float32).contiguous()
+        assert flat.numel() == self.param_count(k), (flat.numel(), self.param_count(k))
+        _lib.check(self.lib.mfas_population_set_params(self._h, k, C.c_void_p(flat.data_ptr())))
+        torch.cuda.current_stream(self._idx).synchronize()   # flat may be freed by the caller
+
+    def get_params(self, k: int, plane: int = 0) -> torch.Tensor:
+        out = torch.empty(self.param_count(k), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mfas_population_get_params(self._h, k, plane, C.c_void_p(out.data_ptr())))
+        return out
+
+    def set_state_dict(self, k: int, sd: Dict[str, "np.ndarray | torch.Tensor"]):
+        layout, n = flat_layout(self.confs[k], self.hp)
+        flat = torch.zeros(n, dtype=torch.float32)
+        for key, shape, off in layout:
+            if key in sd:
+                v = sd[key]
+                v = torch.from_numpy(np.asarray(v)) if not torch.is_tensor(v) else v.detach().cpu()
+                flat[off:off + v.numel()] = v.reshape(-1).to(torch.float32)
+            elif key.endswith(("2.weight", "running_var")):
+                flat[off:off + int(np.prod(shape))] = 1.0
+        self.set_params(k, flat)
+
+    def get_state_dict(self, k: int, plane: int = 0) -> Dict[str, torch.Tensor]:
+        layout, _ = flat_layout(self.confs[k], self.hp)
+        flat = self.get_params(k, plane).cpu()
+        return {key: flat[off:off + int(np.prod(shape))].reshape(shape).clone() for key, shape, off in layout}
+
+    def init(self, seeds: Sequence[int]):
+        s = np.asarray(seeds, np.uint32)
+        assert len(s) == self.K
+        _lib.check(self.lib.mfas_population_init(self._h, s.ctypes.data))
+
+    def train(self, train: FeatureTable, dev: Optional[FeatureTable], epochs: int, etas: np.ndarray,
+              order: Optional[torch.Tensor] = None, max_steps: int = -1, snapshot_best: bool = False):
+        """Runs train_ntu_track_acc for the whole population.  Returns (stats, status): stats is a
+        structured array [K, epochs] with train_loss_sum, dev_loss_sum, train_corrects, dev_corrects."""
+        nb = -(-len(train) // self.hp.B)
+        etas = np.asarray(etas, np.float64)
+        if len(etas) < epochs * nb and max_steps < 0:
+            raise ValueError("eta table shorter than epochs * batches")
+        sc = np.ascontiguousarray(adam_step_scalars(etas, self.hp.beta1, self.hp.beta2))
+        if order is not None:
+            order = order.to(device=self.device, dtype=torch.int32).contiguous()
+            assert order.numel() >= epochs * len(train)
+        stats = np.zeros((self.K, epochs), dtype=[("train_loss_sum", "f8"), ("dev_loss_sum", "f8"),
+                                                  ("train_corrects", "i8"), ("dev_corrects", "i8")])
+        status = np.zeros(self.K, np.int32)
+        tt = train.to_c()
+        td = dev.to_c() if dev is not None else None
+        with torch.cuda.device(self._idx):
+            _lib.check(self.lib.mfas_population_train(
+                self._h, C.byref(tt), C.byref(td) if td is not None else None,
+                None if order is None else C.c_void_p(order.data_ptr()), sc.ctypes.data, int(epochs),
+                int(max_steps), int(snapshot_best), stats.ctypes.data, status.ctypes.data))
+        return stats, status
+
+    def forward(self, k: int, table: FeatureTable, row0: int = 0, nrows: Optional[int] = None,
+                count: bool = False):
+        nrows = len(table) - row0 if nrows is None else nrows
+        logits = torch.empty((nrows, self.hp.C), dtype=torch.float32, device=self.device)
+        corr = C.c_int64(0)
+        tc = table.to_c()
+        with torch.cuda.device(self._idx):
+            _lib.check(self.lib.mfas_population_forward(self._h, k, C.byref(tc), row0, nrows,
+                                                        C.c_void_p(logits.data_ptr()),
+                                                        C.byref(corr) if count else None))
+        return (logits, int(corr.value)) if count else logits
+
+    def set_profiling(self, on: bool):
+        _lib.check(self.lib.mfas_population_set_profiling(self._h, int(on)))
+
+    def sweep_profile(self):
+        n, ms, by = C.c_int64(0), C.c_double(0), C.c_double(0)
+        _lib.check(self.lib.mfas_population_sweep_profile(self._h, C.byref(n), C.byref(ms), C.byref(by)))
+        return int(n.value), float(ms.value), float(by.value)
+
+
+def best_dev_accuracy(stats_row, n_dev: int) -> float:
+    """max over epochs with strict '>' from 0 (train_searchable/ntu.py:18,82-83); float64 ratio (:76)."""
+    best = 0.0
+    for e in range(len(stats_row)):
+        acc = float(stats_row["dev_corrects"][e]) / float(n_dev)
+        if acc > best:
+            best = acc
+    return best

@@ -1,0 +1,364 @@
+"""Host-side mirror of /root/reference/models/search/ntu_searchable.py for the HIP engine.
+
+Same names, argument meaning and error behaviour as the reference for the hot path:
+
+* ``train_sampled_models``               ntu_searchable.py:23-102   (population loop -> lockstep engine)
+* ``get_possible_layer_configurations``  ntu_searchable.py:105-119
+* ``get_central_states`` / ``set_central_states``   ntu_searchable.py:123-174   (weight sharing)
+* ``Searchable_Skeleton_Image_Net``      ntu_searchable.py:178-301  (nn.Module surface)
+
+Departures: backbones are feature tables (``FeatureTap`` stands in for
+``Visual``/``Skeleton``; north_star: precomputed features); candidates of one call train in
+lockstep and share the epoch's batch order; dropout uses the engine's counter-based stream.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import population as popmod
+from .engine import (S_SIZES, V_SIZES, FeatureLoader, FeatureTable, Hyper, Population, best_dev_accuracy,
+                     flat_layout)
+from .scheduler import LRCosineAnnealingScheduler
+
+
+# ------------------------------------------------------------------------------------------------ small modules
+class GlobalPooling2D(nn.Module):
+    """models/auxiliary/aux_models.py:54-64: mean over all trailing dims (identity on pooled (B,C) taps)."""
+
+    def forward(self, x):
+        x = x.view(x.size(0), x.size(1), -1)
+        return torch.mean(x, 2).view(x.size(0), -1)
+
+
+class AlphaScalarMultiplication(nn.Module):
+    """aux_models.py:94-111: x*sigmoid(alpha), y*(1-sigmoid(alpha)); one scalar per cell.  The arithmetic
+    runs inside the engine; this module only owns the parameter."""
+
+    def __init__(self, size_alpha_x, size_alpha_y):
+        super().__init__()
+        self.size_alpha_x = size_alpha_x
+        self.size_alpha_y = size_alpha_y
+        self.alpha_x = nn.Parameter(torch.zeros(1, dtype=torch.float32))
+
+
+class FeatureTap(nn.Module):
+    """Stand-in for the frozen backbones ``Visual`` / ``Skeleton`` (models/central/ntu.py:17,53): the
+    taps are precomputed, so this module has no parameters and simply hands the batch's taps on."""
+
+    def __init__(self, prefix):
+        super().__init__()
+        self.prefix = prefix
+
+    def forward(self, x):
+        return x
+
+
+# ------------------------------------------------------------------------------------------------ the fusion net
+class Searchable_Skeleton_Image_Net(nn.Module):
+    """Module surface of ntu_searchable.py:178-301: attributes ``conf, args, rgbnet, skenet, alphas, gp_v,
+    gp_s, fusion_layers, central_classifier``; ``forward``; ``central_params``.
+
+    conf: one row per fusion cell: [ske tap, rgb tap, non-linearity (0 ReLU / 1 Sigmoid / 2 LeakyReLU)].
+    """
+
+    def __init__(self, args, conf):
+        super().__init__()
+        self.conf = np.asarray(conf)
+        self.args = args
+        self.rgbnet = FeatureTap("v")
+        self.skenet = FeatureTap("s")
+        self.alphas = self._create_alphas()
+        self.gp_v, self.gp_s = self._create_global_poolings()
+        self.fusion_layers = self._create_fc_layers()
+        self.central_classifier = nn.Linear(self.args.inner_representation_size, args.num_outputs)
+        for m in self.modules():
+            if isinstance(m, AlphaScalarMultiplication):
+                nn.init.normal_(m.alpha_x, 0.0, 0.1)
+        self._pop = None
+
+    # -- construction (ntu_searchable.py:258-301)
+    def _sizes(self):
+        hp = Hyper.from_args(self.args)
+        return hp.s_sizes, hp.v_sizes
+
+    def _create_alphas(self):
+        sizes_ske, sizes_ims = self._sizes()
+        return nn.ModuleList([AlphaScalarMultiplication(sizes_ske[int(c[0])], sizes_ims[int(c[1])])
+                              for c in self.conf])
+
+    def _create_global_poolings(self):
+        n = len(self.conf)
+        return (nn.ModuleList([GlobalPooling2D() for _ in range(n)]),
+                nn.ModuleList([GlobalPooling2D() for _ in range(n)]))
+
+    def _create_fc_layers(self):
+        layers = []
+        for i, conf in enumerate(self.conf):
+            in_size = self.alphas[i].size_alpha_x + self.alphas[i].size_alpha_y
+            if i > 0:
+                in_size += self.args.inner_representation_size
+            out_size = self.args.inner_representation_size
+            if conf[2] == 0:
+                nl = nn.ReLU()
+            elif conf[2] == 1:
+                nl = nn.Sigmoid()
+            elif conf[2] == 2:
+                nl = nn.LeakyReLU()
+            else:
+                raise ValueError(f"unknown non-linearity {conf[2]}")
+            drop, bn = self.args.drpt > 1e-10, bool(self.args.batchnorm)
+            if drop and bn:
+                op = nn.Sequential(nn.Linear(in_size, out_size), nl, nn.BatchNorm1d(out_size),
+                                   nn.Dropout(self.args.drpt))
+            elif drop:
+                op = nn.Sequential(nn.Linear(in_size, out_size), nl, nn.Dropout(self.args.drpt))
+            elif bn:
+                op = nn.Sequential(nn.Linear(in_size, out_size), nl, nn.BatchNorm1d(out_size))
+            else:   # the reference leaves `op` unassigned here (UnboundLocalError, :274-284)
+                raise ValueError("drpt < 1e-10 without --batchnorm is not a legal cell "
+                                 "(reference: UnboundLocalError at ntu_searchable.py:284)")
+            layers.append(op)
+        return nn.ModuleList(layers)
+
+    def central_params(self):
+        return [{"params": self.alphas.parameters()},
+                {"params": self.fusion_layers.parameters()},
+                {"params": self.central_classifier.parameters()}]
+
+    # -- engine plumbing
+    def hyper(self, multitask=None) -> Hyper:
+        hp = Hyper.from_args(self.args)
+        if multitask is not None:
+            hp.multitask = bool(multitask)
+        return hp
+
+    def flat_params(self) -> torch.Tensor:
+        layout, n = flat_layout(self.conf, self.hyper())
+        sd = self.state_dict()
+        flat = torch.zeros(n, dtype=torch.float32)
+        for key, shape, off in layout:
+            flat[off:off + int(np.prod(shape))] = sd[key].detach().reshape(-1).to("cpu", torch.float32)
+        return flat
+
+    def load_flat(self, flat: torch.Tensor):
+        layout, _ = flat_layout(self.conf, self.hyper())
+        sd = self.state_dict()
+        flat = flat.detach().cpu()
+        with torch.no_grad():
+            for key, shape, off in layout:
+                sd[key].copy_(flat[off:off + int(np.prod(shape))].reshape(shape))
+
+    def _engine(self, device, multitask):
+        hp = self.hyper(multitask)
+        key = (str(device), hp.multitask)
+        if self._pop is None or self._pop[0] != key:
+            self._pop = (key, Population(hp, [self.conf], device))
+        return self._pop[1]
+
+    def forward(self, tensor_tuple):
+        """tensor_tuple = (rgb, ske): dict-likes holding the pooled taps v0..v3 [+ 'vlogit'] and s0..s3
+        [+ 'slogit'] on a HIP device.  Eval mode only: training runs inside the engine
+        (train_sampled_models / train_ntu_track_acc)."""
+        if self.training:
+            raise NotImplementedError("training-mode forward lives in the HIP engine: use train_sampled_models / "
+                                      "train_ntu_track_acc; call .eval() for inference")
+        image, skeleton = tensor_tuple[0], tensor_tuple[1]
+        visual = self.rgbnet(image)
+        skel = self.skenet(skeleton)
+        taps = {k: v for k, v in visual.items() if k[0] == "v" and k[1:].isdigit()}
+        taps.update({k: v for k, v in skel.items() if k[0] == "s" and k[1:].isdigit()})
+        some = next(iter(taps.values()))
+        n = some.shape[0]
+        table = FeatureTable(taps, torch.zeros(n, dtype=torch.int32, device=some.device))
+        pop = self._engine(some.device, False)
+        pop.set_params(0, self.flat_params())
+        out = pop.forward(0, table)
+        if not self.args.multitask:
+            return out
+        return out, visual["vlogit"], skel["slogit"]
+
+
+# ------------------------------------------------------------------------------------------------ search helpers
+def get_possible_layer_configurations(progression_index):
+    """ntu_searchable.py:105-119: the (4,4,2) grid, non-linearity fastest."""
+    max_labels = (4, 4, 2)
+    return [[ti, vi, ni] for ti in range(max_labels[0]) for vi in range(max_labels[1])
+            for ni in range(max_labels[2])]
+
+
+def _share_name(idx_layer, layer, conf_row):
+    name = str(idx_layer) + ".L_" + str(layer[0].in_features) + "_" + str(layer[0].out_features)
+    return name + {0: ".A_relu", 1: ".A_sigmoid", 2: ".A_lrelu"}[int(conf_row[2])]
+
+
+def get_central_states(model, state_dict, using_dataparallel=False):
+    """ntu_searchable.py:123-149: publish every cell under ``"{idx}.L_{in}_{out}.A_{act}"``."""
+    model = model.module if using_dataparallel else model
+    for idx_layer, layer in enumerate(model.fusion_layers):
+        state_dict[_share_name(idx_layer, layer, model.conf[idx_layer])] = \
+            {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    return state_dict
+
+
+def set_central_states(model, state_dict, using_dataparallel=False):
+    """ntu_searchable.py:152-174: load every cell whose key exists."""
+    model = model.module if using_dataparallel else model
+    for idx_layer, layer in enumerate(model.fusion_layers):
+        name = _share_name(idx_layer, layer, model.conf[idx_layer])
+        if name in state_dict:
+            layer.load_state_dict(state_dict[name])
+
+
+# ------------------------------------------------------------------------------------------------ the driver
+def _require_loader(x, name) -> FeatureLoader:
+    if not isinstance(x, FeatureLoader):
+        raise TypeError(f"dataloaders['{name}'] must be a mfas_amd.FeatureLoader over a HIP-resident FeatureTable; "
+                        "there is no raw-video / CPU path")
+    return x
+
+
+def make_order(N, epochs, shuffle, seed, device):
+    """Per-epoch sample order shared by the population (DataLoader(shuffle=True), models/searchable.py:248)."""
+    if not shuffle:
+        return None
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    return torch.stack([torch.randperm(N, generator=gen, device=device) for _ in range(epochs)]).to(torch.int32)
+
+
+def train_sampled_models(sampled_configurations, searchable_type, dataloaders, args, device,
+                         return_model=[], premodels=[], preaccuracies=[],
+                         train_only_central_params=True, state_dict=dict()):
+    """Drop-in for ntu_searchable.py:23-102.  Every configuration is trained from scratch for
+    ``args.epochs`` epochs of {train over dataloaders['train'], eval over dataloaders['dev']} and its best dev
+    accuracy returned, in input order.  The whole (per-rank share of the) population trains in lockstep inside
+    the HIP engine; with torch.distributed initialised the population is sharded across ranks and the
+    accuracies are all-gathered (RCCL).
+    """
+    if preaccuracies:   # the reference forwards init_f1=, which train_ntu_track_acc does not accept (:86-89)
+        raise TypeError("train_ntu_track_acc() got an unexpected keyword argument 'init_f1' "
+                        "(reference behaviour, ntu_searchable.py:86-89)")
+    if not train_only_central_params:
+        raise NotImplementedError("backbone fine-tuning needs raw video; the engine trains central_params() only")
+    train_l = _require_loader(dataloaders["train"], "train")
+    dev_l = _require_loader(dataloaders["dev"], "dev")
+    device = torch.device(device)
+    hp = Hyper.from_args(args)
+    hp.multitask = False    # ntu_searchable.py:82-84 never forwards multitask to the train loop
+    if getattr(args, "multitask", False):
+        raise TypeError("max() received an invalid combination of arguments: the searchable returns a tuple "
+                        "with --multitask in search mode (reference behaviour, train_searchable/ntu.py:54)")
+    confs = [np.asarray(c).reshape(-1, 3) for c in sampled_configurations]
+    K = len(confs)
+    wanted = [i for i in range(K) if (not return_model or i in return_model)]
+    N_tr, N_dev, B, E = len(train_l.table), len(dev_l.table), int(args.batchsize), int(args.epochs)
+    nb = -(-N_tr // B)
+    num_batches_per_epoch = N_tr / B              # float, ntu_searchable.py:30
+
+    seed_base = popmod.broadcast_seed(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), device)
+    if getattr(args, "weightsharing", False):
+        return _train_weightsharing(confs, wanted, searchable_type, train_l, dev_l, args, device, hp, seed_base,
+                                    return_model, premodels, state_dict)
+
+    rank, world = popmod.dist_info()
+    costs = [popmod.candidate_cost(confs[i], hp.R, hp.s_sizes, hp.v_sizes, hp.C) for i in wanted]
+    owner = popmod.assign(costs, world)
+    mine = [i for i, o in zip(wanted, owner) if o == rank]
+
+    local_acc, models = [], {}
+    if mine:
+        pop = Population(hp, [confs[i] for i in mine], device,
+                         drop_seeds=[(seed_base * 7 + i) & 0xFFFFFFFF for i in mine],
+                         chunk_cols=int(getattr(args, "engine_chunk_cols", 0)))
+        mods = {}
+        if premodels:
+            for j, i in enumerate(mine):
+                src = premodels[i].module if getattr(args, "use_dataparallel", False) else premodels[i]
+                m = searchable_type(args, confs[i])
+                m.load_state_dict(src.state_dict())
+                pop.set_params(j, m.flat_params())
+                mods[i] = m
+        elif getattr(args, "engine_init", "torch") == "device":
+            pop.init([(seed_base + 2 + i) & 0x7FFFFFFF for i in mine])
+        else:
+            for j, i in enumerate(mine):
+                with torch.random.fork_rng(devices=[]):
+                    torch.manual_seed(seed_base + 2 + i)   # world-size independent per-candidate stream
+                    m = searchable_type(args, confs[i])
+                pop.set_params(j, m.flat_params())
+                if return_model:
+                    mods[i] = m
+        sched = LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, num_batches_per_epoch)
+        etas = sched.eta_table(E * nb)
+        order = make_order(N_tr, E, train_l.shuffle, seed_base + 1, device)
+        if getattr(args, "verbose", False):
+            print("Now training: ")
+            for i in mine:
+                print(confs[i])
+        stats, status = pop.train(train_l.table, dev_l.table, E, etas, order=order,
+                                  snapshot_best=bool(return_model))
+        for j, i in enumerate(mine):
+            if getattr(args, "verbose", False):
+                for e in range(E):
+                    print("train Loss: {:.4f} Acc: {:.4f}".format(stats["train_loss_sum"][j, e] / N_tr,
+                                                                  stats["train_corrects"][j, e] / N_tr))
+                    print("dev Loss: {:.4f} Acc: {:.4f}".format(stats["dev_loss_sum"][j, e] / N_dev,
+                                                                stats["dev_corrects"][j, e] / N_dev))
+            local_acc.append(best_dev_accuracy(stats[j], N_dev))
+            if return_model:
+                m = mods.get(i) or searchable_type(args, confs[i])
+                m.load_flat(pop.get_params(j))
+                _bump_bn_counters(m, E * nb)
+                m.to(device)
+                m.train(False)
+                models[i] = m
+        pop.close()
+    accs_all = popmod.gather_accuracies(mine, local_acc, K, device)
+    real_accuracies = [accs_all[i] for i in wanted]
+    if return_model:
+        # models live on the rank that trained them; other ranks get None placeholders
+        return real_accuracies, [models.get(i) for i in wanted]
+    return real_accuracies
+
+
+def _bump_bn_counters(model, steps):
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None:
+            m.num_batches_tracked += steps
+
+
+def _train_weightsharing(confs, wanted, searchable_type, train_l, dev_l, args, device, hp, seed_base,
+                         return_model, premodels, state_dict):
+    """--weightsharing makes candidates sequentially dependent (each starts from the cells the previous ones
+    published, ntu_searchable.py:74-75,91-92): "replicas only" — every rank trains the whole list serially."""
+    N_tr, N_dev, B, E = len(train_l.table), len(dev_l.table), int(args.batchsize), int(args.epochs)
+    nb = -(-N_tr // B)
+    accs, models = [], []
+    for i in wanted:
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(seed_base + 2 + i)
+            m = searchable_type(args, confs[i])
+        if premodels:
+            m.load_state_dict(premodels[i].state_dict())
+        set_central_states(m, state_dict, False)
+        pop = Population(hp, [confs[i]], device, drop_seeds=[(seed_base * 7 + i) & 0xFFFFFFFF])
+        pop.set_params(0, m.flat_params())
+        sched = LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, N_tr / B)
+        order = make_order(N_tr, E, train_l.shuffle, seed_base + 1 + 1000 * i, device)
+        stats, _ = pop.train(train_l.table, dev_l.table, E, sched.eta_table(E * nb), order=order,
+                             snapshot_best=True)
+        m.load_flat(pop.get_params(0))
+        _bump_bn_counters(m, E * nb)
+        pop.close()
+        get_central_states(m, state_dict, False)
+        accs.append(best_dev_accuracy(stats[0], N_dev))
+        if return_model:
+            m.to(device)
+            m.train(False)
+            models.append(m)
+    return (accs, models) if return_model else accs

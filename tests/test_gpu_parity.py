@@ -1,0 +1,315 @@
+"""GPU parity tests proper: the HIP engine (through the C ABI, via ctypes) against the numpy oracle on the
+same seeded inputs, and directly against the golden vectors of the unchanged reference.
+
+Tolerances (float32 path; north_star: dev top-1 within +-0.1 %):
+  * logits / losses: 2e-4 relative to the tensor scale (summation order differs from ATen's);
+  * parameters after k Adam steps: <=3 % of the elements may deviate by more than 1e-4 relative
+    (Adam divides by sqrt(v): an element whose gradient is at round-off level moves by ~lr in either
+    direction), every element within k*lr;
+  * dev correct COUNTS on the short deterministic trajectories: exact; accuracies within 0.1 % top-1 where
+    the set is large enough for that to be more than one sample.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from oracle import np_oracle as O
+from tests.helpers import CONFS, engine_hyper, etas_for, frac_bad, golden, oracle_steps, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs a HIP device"
+    return torch.device("cuda:0")
+
+
+def mk_pop(ohp, confs, dev, **kw):
+    from mfas_amd import Population
+    return Population(engine_hyper(ohp), [np.array(c) for c in confs], dev, **kw)
+
+
+def table(t, dev, dtype=torch.float32):
+    from mfas_amd import FeatureTable
+    return FeatureTable.from_numpy(t, dev, dtype)
+
+
+# ---------------------------------------------------------------------------------------- layout
+@pytest.mark.parametrize("R,bn", [(16, True), (128, True), (16, False), (24, True)])
+def test_param_roundtrip_and_device_init(dev, R, bn):
+    ohp = O.Hyper(R=R, B=16, bn=bn, drpt=0.5, alphas=True)
+    confs = [CONFS["c4"], CONFS["l1"], CONFS["l3"]]
+    pop = mk_pop(ohp, confs, dev)
+    for k, c in enumerate(confs):
+        p = O.init_params(c, ohp, 40 + k, perturb_bn=True)
+        pop.set_state_dict(k, p)
+    for k, c in enumerate(confs):
+        p = O.init_params(c, ohp, 40 + k, perturb_bn=True)
+        got = pop.get_state_dict(k)
+        for key, v in p.items():
+            if not bn and ".2." in key:
+                continue
+            assert np.array_equal(got[key].numpy(), v), key
+        for plane in (1, 2):
+            assert float(pop.get_params(k, plane).abs().max()) == 0.0
+    pop.init([7, 8, 9])          # device-side hash init == oracle init, bit for bit
+    for k, c in enumerate(confs):
+        p = O.init_params(c, ohp, 7 + k)
+        got = pop.get_state_dict(k)
+        for key, v in p.items():
+            if not bn and ".2." in key:
+                continue
+            assert np.array_equal(got[key].numpy(), v), key
+    pop.close()
+
+
+# ---------------------------------------------------------------------------------------- forward (eval) vs reference golden
+def test_eval_forward_vs_reference_golden(dev):
+    g = golden("g23_forward_backward.npz")
+    t = O.synth_table(16, 11, snr=0.3, with_logits=True)
+    tab = table(t, dev)
+    n = 0
+    for name in g["names"]:
+        cname, vname, R, seed = str(name).split("/")
+        if not vname.endswith("_eval"):
+            continue
+        R, seed = int(R), int(seed)
+        kw = {"bn_eval": dict(bn=True, drpt=0.0), "bndrop_eval": dict(bn=True, drpt=0.5),
+              "drop_eval": dict(bn=False, drpt=0.5)}[vname]
+        ohp = O.Hyper(R=R, B=16, **kw)
+        pop = mk_pop(ohp, [CONFS[cname]], dev)
+        pop.set_state_dict(0, O.init_params(CONFS[cname], ohp, seed, perturb_bn=True))
+        logits, corr = pop.forward(0, tab, count=True)
+        want = g[f"{cname}/{vname}/{R}/logits"]
+        assert rel_err(logits.cpu().numpy(), want) < 2e-4, name
+        assert corr == int((g[f"{cname}/{vname}/{R}/preds"] == t["label"]).sum()), name
+        pop.close()
+        n += 1
+    assert n >= 15
+
+
+# ---------------------------------------------------------------------------------------- k train steps vs oracle AND reference golden
+def check_state(pop, k, params, st, steps, lr=1e-3, tag=""):
+    got = pop.get_state_dict(k, 0)
+    gm = pop.get_state_dict(k, 1)
+    gv = pop.get_state_dict(k, 2)
+    for key, v in params.items():
+        if key.startswith("alphas") and key not in st.m:
+            continue
+        a = got[key].numpy()
+        assert frac_bad(a, v, 1e-4, 2e-6 * steps) <= 0.03, (tag, key, frac_bad(a, v, 1e-4, 2e-6 * steps))
+        assert np.abs(a - v).max() <= lr * steps, (tag, key)
+    for key in st.m:
+        sc = float(np.abs(st.m[key]).max()) + 1e-30
+        assert frac_bad(gm[key].numpy(), st.m[key], 2e-3, 2e-3 * sc) <= 0.03, (tag, "m", key)
+        sc = float(np.abs(st.v[key]).max()) + 1e-30
+        assert frac_bad(gv[key].numpy(), st.v[key], 4e-3, 2e-3 * sc) <= 0.03, (tag, "v", key)
+
+
+@pytest.mark.parametrize("cname,R", [("c4", 16), ("c4", 128), ("l2", 16)])
+@pytest.mark.parametrize("steps", [1, 2, 10])
+def test_train_steps_bn(dev, cname, R, steps):
+    ohp = O.Hyper(R=R, B=16, bn=True, drpt=0.0, epochs=3)
+    conf = np.array(CONFS[cname])
+    ttr = O.synth_table(64, 21, snr=0.3)
+    pop = mk_pop(ohp, [conf], dev)
+    pop.set_state_dict(0, O.init_params(conf, ohp, 5))
+    stats, status = pop.train(table(ttr, dev), None, 3, etas_for(ohp, 64), max_steps=steps)
+    params, st, losses = oracle_steps(conf, ohp, O.init_params(conf, ohp, 5), ttr, steps)
+    check_state(pop, 0, params, st, steps, tag=f"{cname}/{R}/{steps}")
+    # the same numbers straight from the reference
+    g = golden("g456_trajectory.npz")
+    pre = f"{cname}/{R}/step{steps}/p/"
+    got = pop.get_state_dict(0, 0)
+    for key in got:
+        if key.startswith("alphas"):
+            continue
+        full = pre + key in g
+        want = g[pre + key] if full else g[pre + key + "#s"]
+        a = got[key].numpy() if full else O.sample_view(got[key].numpy())
+        assert frac_bad(a, want, 1e-4, 2e-6 * steps) <= 0.03, key
+    nb = 4
+    loss_sum = sum(losses[e] * 16 for e in range(min(steps, nb)))
+    assert abs(stats["train_loss_sum"][0, 0] - loss_sum) < 2e-3 * max(1.0, loss_sum)
+    pop.close()
+
+
+@pytest.mark.parametrize("variant", ["drop", "bndrop", "lrelu_drop", "mt", "alphas", "ragged20"])
+def test_train_steps_variants(dev, variant):
+    kw = dict(R=16, B=16, bn=False, drpt=0.5, epochs=3)
+    cname, N = "c4", 64
+    with_logits = False
+    if variant == "bndrop":
+        kw.update(bn=True)
+    elif variant == "lrelu_drop":
+        cname = "l3"
+    elif variant == "mt":
+        kw.update(bn=True, drpt=0.0, multitask=True)
+        with_logits = True
+    elif variant == "alphas":
+        kw.update(bn=True, drpt=0.0, alphas=True)
+        cname = "l3"
+    elif variant == "ragged20":
+        kw.update(B=20, bn=True, drpt=0.4)
+        N = 70            # batches of 20,20,20,10
+    ohp = O.Hyper(**kw)
+    conf = np.array(CONFS[cname])
+    ttr = O.synth_table(N, 21, snr=0.3, with_logits=with_logits)
+    pop = mk_pop(ohp, [conf, conf], dev, drop_seeds=[11, 12])
+    for k in range(2):
+        pop.set_state_dict(k, O.init_params(conf, ohp, 5 + k))
+    steps = 6
+    stats, status = pop.train(table(ttr, dev), None, 3, etas_for(ohp, N), max_steps=steps)
+    for k in range(2):
+        params, st, losses = oracle_steps(conf, ohp, O.init_params(conf, ohp, 5 + k), ttr, steps, seed=11 + k)
+        check_state(pop, k, params, st, steps, tag=f"{variant}/{k}")
+    assert not status.any()
+    pop.close()
+
+
+# ---------------------------------------------------------------------------------------- full trajectories
+@pytest.mark.parametrize("cname,R", [("c4", 16), ("c4", 128), ("l2", 16)])
+def test_deterministic_trajectory_vs_reference(dev, cname, R):
+    g = golden("g456_trajectory.npz")
+    ohp = O.Hyper(R=R, B=16, bn=True, drpt=0.0, epochs=3)
+    conf = np.array(CONFS[cname])
+    ttr, tdv = O.synth_table(64, 21, snr=0.3), O.synth_table(48, 22, snr=0.3)
+    pop = mk_pop(ohp, [conf], dev)
+    pop.set_state_dict(0, O.init_params(conf, ohp, 5))
+    stats, status = pop.train(table(ttr, dev), table(tdv, dev), 3, etas_for(ohp, 64))
+    hist = g[f"{cname}/{R}/hist"]       # rows (phase, loss, acc) as printed by the reference (4 decimals)
+    for e in range(3):
+        assert abs(stats["train_loss_sum"][0, e] / 64 - hist[2 * e][1]) < 3e-4
+        assert abs(stats["train_corrects"][0, e] / 64 - hist[2 * e][2]) < 1e-4
+        assert abs(stats["dev_loss_sum"][0, e] / 48 - hist[2 * e + 1][1]) < 3e-4
+        assert abs(stats["dev_corrects"][0, e] / 48 - hist[2 * e + 1][2]) < 1e-4      # exact count
+    from mfas_amd import best_dev_accuracy
+    assert best_dev_accuracy(stats[0], 48) == pytest.approx(float(g[f"{cname}/{R}/best_acc"]), abs=1e-12)
+    pop.close()
+
+
+@pytest.mark.parametrize("B", [16, 20])
+def test_population_vs_reference(dev, B):
+    """train_sampled_models on 4 heterogeneous confs (L = 1..4); B=20 has ragged last batches."""
+    g = golden("g7_population.npz")
+    ttr, tdv = O.synth_table(256, 31, snr=0.5), O.synth_table(128, 32, snr=0.5)
+    confs = [g[f"conf{i}"] for i in range(4)]
+    ohp = O.Hyper(R=16, B=B, bn=True, drpt=0.0, epochs=3)
+    pop = mk_pop(ohp, confs, dev)
+    for k, c in enumerate(confs):
+        pop.set_state_dict(k, O.init_params(c, ohp, 9 + k))
+    stats, _ = pop.train(table(ttr, dev), table(tdv, dev), 3, etas_for(ohp, 256))
+    from mfas_amd import best_dev_accuracy
+    accs = [best_dev_accuracy(stats[k], 128) for k in range(4)]
+    np.testing.assert_allclose(accs, g[f"B{B}/accs"], atol=1.0 / 128 + 1e-9)   # <= 1 sample of 128
+    assert sum(a == w for a, w in zip(accs, g[f"B{B}/accs"])) >= 3
+    pop.close()
+
+
+def test_multitask_and_alphas_vs_reference(dev):
+    g = golden("g7_population.npz")
+    from mfas_amd import best_dev_accuracy
+    ttr = O.synth_table(256, 31, snr=0.5, with_logits=True)
+    tdv = O.synth_table(128, 32, snr=0.5, with_logits=True)
+    ohp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=3, multitask=True)
+    conf = np.array(CONFS["c0"])
+    pop = mk_pop(ohp, [conf], dev)
+    pop.set_state_dict(0, O.init_params(conf, ohp, 13))
+    stats, _ = pop.train(table(ttr, dev), table(tdv, dev), 3, etas_for(ohp, 256))
+    assert abs(best_dev_accuracy(stats[0], 128) - float(g["mt_acc"])) <= 1.0 / 128 + 1e-9
+    for e in range(3):
+        assert abs(stats["dev_corrects"][0, e] / 128 - g["mt_hist"][2 * e + 1][2]) <= 1.0 / 128 + 1e-4
+    pop.close()
+    ohp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=3, alphas=True)
+    conf = np.array(CONFS["l3"])
+    pop = mk_pop(ohp, [conf], dev)
+    pop.set_state_dict(0, O.init_params(conf, ohp, 21))
+    t1, t2 = O.synth_table(256, 31, snr=0.5), O.synth_table(128, 32, snr=0.5)
+    stats, _ = pop.train(table(t1, dev), table(t2, dev), 3, etas_for(ohp, 256))
+    assert abs(best_dev_accuracy(stats[0], 128) - float(g["alpha_acc"])) <= 1.0 / 128 + 1e-9
+    got = pop.get_state_dict(0)
+    al = [float(got[f"alphas.{i}.alpha_x"][0]) for i in range(3)]
+    np.testing.assert_allclose(al, g["alpha_final"], rtol=5e-3, atol=2e-5)
+    pop.close()
+
+
+def test_dropout_trajectory_vs_oracle(dev):
+    """Dropout on: the engine and the oracle share the counter-based mask, so whole trajectories agree."""
+    ohp = O.Hyper(R=16, B=16, bn=False, drpt=0.5, epochs=2)
+    confs = [np.array(CONFS["c4"]), np.array(CONFS["l2"])]
+    ttr, tdv = O.synth_table(256, 1, snr=1.0), O.synth_table(256, 2, snr=1.0)
+    rng = np.random.default_rng(3)
+    order = np.stack([rng.permutation(256) for _ in range(2)])
+    pop = mk_pop(ohp, confs, dev, drop_seeds=[100, 101])
+    for k, c in enumerate(confs):
+        pop.set_state_dict(k, O.init_params(c, ohp, 50 + k))
+    stats, _ = pop.train(table(ttr, dev), table(tdv, dev), 2, etas_for(ohp, 256),
+                         order=torch.from_numpy(order.astype(np.int32)))
+    for k, c in enumerate(confs):
+        hist = []
+        O.train_candidate(c, ohp, O.init_params(c, ohp, 50 + k), ttr, tdv, order=order, seed=100 + k, history=hist)
+        for e in range(2):
+            assert abs(stats["train_loss_sum"][k, e] / 256 - hist[e]["train_loss"]) < 2e-3
+            assert abs(stats["dev_corrects"][k, e] - hist[e]["dev_corrects"]) <= 2      # <1 % of 256
+    pop.close()
+
+
+def test_bf16_tables(dev):
+    """bf16 storage of the taps (config 2): identical bf16-rounded values go to the oracle as f32."""
+    ohp = O.Hyper(R=128, B=16, bn=True, drpt=0.0, epochs=2)
+    conf = np.array(CONFS["c4"])
+    ttr, tdv = O.synth_table(128, 5, snr=0.3, quant="bf16"), O.synth_table(96, 6, snr=0.3, quant="bf16")
+    pop = mk_pop(ohp, [conf], dev)
+    pop.set_state_dict(0, O.init_params(conf, ohp, 77))
+    stats, _ = pop.train(table(ttr, dev, torch.bfloat16), table(tdv, dev, torch.bfloat16), 2, etas_for(ohp, 128))
+    hist = []
+    O.train_candidate(conf, ohp, O.init_params(conf, ohp, 77), ttr, tdv, history=hist)
+    for e in range(2):
+        assert abs(stats["train_loss_sum"][0, e] / 128 - hist[e]["train_loss"]) < 1e-3
+        assert abs(stats["dev_corrects"][0, e] - hist[e]["dev_corrects"]) <= 1
+    pop.close()
+
+
+# ---------------------------------------------------------------------------------------- size-independent properties
+def test_lockstep_independence_and_determinism(dev):
+    """A candidate's result must not depend on who else is in the population, on its slot, or on the chunking."""
+    ohp = O.Hyper(R=16, B=20, bn=False, drpt=0.5, epochs=2)
+    confs = [np.array(CONFS[c]) for c in ("c4", "l1", "l2", "l3", "c0")]
+    ttr, tdv = O.synth_table(500, 1, snr=1.0), O.synth_table(300, 2, snr=1.0)
+    ta, tb = table(ttr, dev), table(tdv, dev)
+    etas = etas_for(ohp, 500)
+
+    def run(idx, chunk):
+        pop = mk_pop(ohp, [confs[i] for i in idx], dev, drop_seeds=[200 + i for i in idx], chunk_cols=chunk)
+        pop.init([300 + i for i in idx])
+        stats, _ = pop.train(ta, tb, 2, etas)
+        out = {i: (stats["dev_corrects"][j].tolist(), stats["train_loss_sum"][j].tolist()) for j, i in enumerate(idx)}
+        pop.close()
+        return out
+
+    a = run([0, 1, 2, 3, 4], 0)
+    b = run([4, 2, 0], 0)
+    c = run([0, 1, 2, 3, 4], 0)
+    for i in (0, 2, 4):
+        assert a[i] == b[i], i          # bit-identical: same kernels, same order of operations
+    assert a == c
+    d = run([0, 1, 2, 3, 4], 64)        # different chunking changes summation order only
+    for i in range(5):
+        assert max(abs(x - y) for x, y in zip(a[i][0], d[i][0])) <= 3
+        assert max(abs(x - y) for x, y in zip(a[i][1], d[i][1])) < 0.5
+
+
+def test_error_behaviour(dev):
+    from mfas_amd import Hyper, Population
+    with pytest.raises(RuntimeError, match="illegal cell variant"):
+        Population(Hyper(R=16, bn=False, drpt=0.0), [np.array(CONFS["l1"])], dev)
+    with pytest.raises(RuntimeError):
+        Population(Hyper(R=16, bn=True, drpt=0.0), [np.array([[5, 0, 0]])], dev)
+    ohp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=1)
+    pop = mk_pop(ohp, [CONFS["l1"]], dev)
+    pop.init([1])
+    t17 = O.synth_table(17, 1)          # final train batch of size 1 with BN: the reference raises
+    with pytest.raises(RuntimeError, match="size 1"):
+        pop.train(table(t17, dev), table(t17, dev), 1, etas_for(ohp, 17))
+    pop.close()

@@ -1,0 +1,180 @@
+"""CPU-only tests of the host logic and of the C-ABI library surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from tests.helpers import CONFS, golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def mkargs(**kw):
+    a = dict(vid_len=(8, 32), num_outputs=60, drpt=0.5, inner_representation_size=16, batchnorm=True,
+             alphas=False, multitask=False, weightsharing=False, batchsize=16, eta_max=1e-3, eta_min=1e-6,
+             Ti=1, Tm=2, use_dataparallel=False, verbose=False, epochs=2)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from mfas_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mfas_hip.h")).read()
+    declared = set(re.findall(r"\b(mfas_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _lib.lib().mfas_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    from mfas_amd import _lib
+    assert ctypes.sizeof(_lib.mfas_hyper) == 6 * 4 + 7 * 8 + 8 * 4
+    assert ctypes.sizeof(_lib.mfas_table) == 11 * 8 + 8 + 8
+    assert ctypes.sizeof(_lib.mfas_epoch_stats) == 32
+
+
+def test_no_engine_without_gpu():
+    """The product path fails loudly instead of falling back to CPU."""
+    from mfas_amd import Hyper, Population
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        Population(Hyper(R=16, bn=True), [np.array(CONFS["l1"])], "cpu")
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "mfas_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_scheduler_matches_reference_golden():
+    from mfas_amd import LRCosineAnnealingScheduler
+    g = golden("g1_scheduler.npz")
+    for j in range(4):
+        Ti, Tm, nbpe, n = g[f"cfg{j}"]
+        s = LRCosineAnnealingScheduler(1e-3, 1e-6, Ti, Tm, nbpe)
+        np.testing.assert_allclose(s.eta_table(int(n)), g[f"eta{j}"], rtol=1e-12)
+    s = LRCosineAnnealingScheduler(1e-3, 1e-6, 1, 2, 4.0)
+    seq = [s.step() or s.eta for _ in range(16)]
+    assert s.Ti == 4     # SURVEY §3.3 known answer: Ti ends at 4
+
+
+def test_adam_step_scalars():
+    from mfas_amd.scheduler import adam_step_scalars
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, 4.0, 12)
+    sc = adam_step_scalars(etas)
+    hp = O.Hyper()
+    for t in range(12):
+        ss, b2 = O.adam_scalars(float(etas[t]), t + 1, hp)
+        assert sc[t, 0] == ss and sc[t, 1] == b2
+
+
+def test_layer_configurations_and_module_surface():
+    import mfas_amd as M
+    g = golden("g8_controller.npz")
+    assert np.array_equal(np.array(M.get_possible_layer_configurations(0)), g["layer_confs"])
+    args = mkargs(batchnorm=True, drpt=0.5, inner_representation_size=16, alphas=True)
+    conf = np.array(CONFS["c4"])
+    m = M.Searchable_Skeleton_Image_Net(args, conf)
+    for attr in ("conf", "args", "rgbnet", "skenet", "alphas", "gp_v", "gp_s", "fusion_layers",
+                 "central_classifier"):
+        assert hasattr(m, attr)
+    keys = set(m.state_dict().keys())
+    ohp = O.Hyper(R=16, B=16, bn=True, drpt=0.5, alphas=True)
+    want = set(O.init_params(conf, ohp, 0).keys())
+    assert want <= keys
+    assert keys - want == {f"fusion_layers.{i}.2.num_batches_tracked" for i in range(4)}
+    groups = m.central_params()
+    assert len(groups) == 3
+    n = sum(p.numel() for gr in groups for p in gr["params"])
+    assert n == 124732 + 4 * 32 + 4      # P (R=16, conf-4 taps) + BN affine + alphas
+    assert [l[0].in_features for l in m.fusion_layers] == [1536, 2320, 1296, 2576]
+    # flat layout round trip and agreement with the engine's documented order
+    flat = m.flat_params()
+    layout, total = M.flat_layout(conf, m.hyper())
+    assert total == flat.numel()
+    m2 = M.Searchable_Skeleton_Image_Net(args, conf)
+    m2.load_flat(flat)
+    for k, v in m.state_dict().items():
+        if "num_batches" not in k:
+            assert torch.equal(v, m2.state_dict()[k]), k
+    with pytest.raises(ValueError):
+        M.Searchable_Skeleton_Image_Net(mkargs(batchnorm=False, drpt=0.0), conf)
+    with pytest.raises(NotImplementedError):
+        m.train(True)
+        m(({}, {}))
+
+
+def test_weight_sharing_keys():
+    import mfas_amd as M
+    args = mkargs()
+    a = M.Searchable_Skeleton_Image_Net(args, np.array(CONFS["l2"]))
+    sd = M.get_central_states(a, {})
+    assert set(sd) == {"0.L_3072_16.A_sigmoid", "1.L_2192_16.A_lrelu"}
+    b = M.Searchable_Skeleton_Image_Net(args, np.array([[2, 3, 1], [1, 1, 0]]))
+    M.set_central_states(b, sd)
+    assert torch.equal(b.fusion_layers[0][0].weight, a.fusion_layers[0][0].weight)
+    assert not torch.equal(b.fusion_layers[1][0].weight[:, :16], a.fusion_layers[1][0].weight[:, :16])
+
+
+def test_assignment_is_balanced_and_deterministic():
+    from mfas_amd import population as P
+    rng = np.random.default_rng(0)
+    confs = [rng.integers(0, 4, (rng.integers(1, 5), 3)) % [4, 4, 2] for _ in range(50)]
+    costs = [P.candidate_cost(c, 16, O.S_SIZES, O.V_SIZES) for c in confs]
+    assert P.candidate_cost(CONFS["c4"], 16, O.S_SIZES, O.V_SIZES) == 124732
+    for world in (1, 2, 4, 8):
+        own = P.assign(costs, world)
+        assert own == P.assign(costs, world)
+        loads = [sum(c for c, o in zip(costs, own) if o == r) for r in range(world)]
+        assert max(loads) - min(loads) <= max(costs)
+        assert sorted(set(own)) == list(range(world))
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from mfas_amd import population as P
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = P.dist_info()
+K = 7
+costs = [100, 30, 70, 10, 90, 50, 20]
+own = P.assign(costs, world)
+mine = [i for i in range(K) if own[i] == rank]
+acc = [0.01 * (i + 1) for i in mine]          # stand-in for the engine's result of candidate i
+out = P.gather_accuracies(mine, acc, K)
+assert np.allclose(out, [0.01 * (i + 1) for i in range(K)]), out
+seed = P.broadcast_seed(1234 + rank)
+assert seed == 1234
+print("rank", rank, "ok", mine, flush=True)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2])
+def test_population_gather_gloo(tmp_path, world):
+    """N>1 path on CPU: 2 processes, gloo, 127.0.0.1 rendezvous; sharding + all_gather of accuracies."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
+        assert b"ok" in out
