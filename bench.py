@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — candidate-architectures trained / second on N MI355X (BASELINE.json metric).
+
+One "step" = one ``train_sampled_models`` call (the reference's plug-in boundary) on a population of
+--pop candidates PER GPU: build + init the candidates, train each for E epochs of {train over N_train,
+eval over N_dev}, gather the best dev accuracies.  Workload at N=1 = BASELINE configs[1]: NTU found conf 4
+(``--inner_representation_size 128 --batchnorm``), precomputed (synthetic, planted-signal) NTU-shaped taps
+stored bf16, B=16, drpt 0.5, E=10, N_train=10,000, N_dev=5,600.  Feature tables are
+resident in HBM before the timed region.  Weak scaling: every rank trains --pop candidates.
+
+Launch: ``python bench.py --gpus 1`` or
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+bench.py --gpus N --steps K --warmup W``.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONF4 = [[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]]      # main_found_ntu.py:182
+HBM_PEAK_GBS = 8000.0                                     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synth_tables(n_train, n_dev, device, dtype, snr=0.15, C=60):
+    """Planted-signal NTU-shaped taps x = relu(snr*mu[label] + eps) generated on the GPU (same on every rank)."""
+    import mfas_amd as M
+    g = torch.Generator(device=device)
+    g.manual_seed(123)
+    mus = {}
+    for name, sizes in (("s", M.engine.S_SIZES), ("v", M.engine.V_SIZES)):
+        for j, w in enumerate(sizes):
+            mus[f"{name}{j}"] = torch.randn(C, w, generator=g, device=device)
+    out = []
+    for n, seed in ((n_train, 1), (n_dev, 2)):
+        g.manual_seed(seed)
+        label = torch.randint(0, C, (n,), generator=g, device=device)
+        taps = {k: torch.relu(snr * mu[label] + torch.randn(n, mu.shape[1], generator=g, device=device)).to(dtype)
+                for k, mu in mus.items()}
+        out.append(M.FeatureTable(taps, label.to(torch.int32)))
+    return out
+
+
+def cpu_baseline(train, dev, args, budget_s=20.0):
+    """The numpy oracle (a port of the reference step sequence, oracle/np_oracle.py) timed on this box's host
+    cores on a bounded sample of the same workload; extrapolated linearly to one full candidate."""
+    from oracle import np_oracle as O
+    ohp = O.Hyper(R=args.R, B=args.batch, bn=True, drpt=args.drpt, epochs=1)
+    n_tr = min(len(train), 1600)
+    n_dv = min(len(dev), 1600)
+    ttr = {k: v[:n_tr].float().cpu().numpy() for k, v in train.taps.items()}
+    ttr["label"] = train.label[:n_tr].cpu().numpy().astype(np.int64)
+    tdv = {k: v[:n_dv].float().cpu().numpy() for k, v in dev.taps.items()}
+    tdv["label"] = dev.label[:n_dv].cpu().numpy().astype(np.int64)
+    conf = np.array(CONF4)
+    params = O.init_params(conf, ohp, 1)
+    keys = O.trainable_keys(conf, ohp)
+    st = O.AdamState()
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, len(train) / args.batch, n_tr // args.batch)
+    t0 = time.perf_counter()
+    steps = 0
+    for bi in range(n_tr // args.batch):
+        idx = np.arange(bi * args.batch, (bi + 1) * args.batch)
+        feats = {k: v[idx] for k, v in ttr.items() if k != "label"}
+        logits, cache = O.forward(params, conf, ohp, feats, True, seed=1, step=bi)
+        loss, dlog, _ = O.ce_loss(logits, ttr["label"][idx])
+        grads = O.backward(params, ohp, cache, dlog)
+        O.bn_update_running(params, ohp, cache)
+        O.adam_step(params, grads, st, float(etas[bi]), ohp, keys)
+        steps += 1
+        if time.perf_counter() - t0 > budget_s * 0.75:
+            break
+    t_step = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    rows = 0
+    for bi in range(n_dv // args.batch):
+        idx = np.arange(bi * args.batch, (bi + 1) * args.batch)
+        feats = {k: v[idx] for k, v in tdv.items() if k != "label"}
+        logits, _ = O.forward(params, conf, ohp, feats, False)
+        O.ce_loss(logits, tdv["label"][idx])
+        rows += len(idx)
+        if time.perf_counter() - t0 > budget_s * 0.25:
+            break
+    t_row = (time.perf_counter() - t0) / rows
+    nb = -(-len(train) // args.batch)
+    t_cand = args.epochs * (nb * t_step + len(dev) * t_row)
+    return {"value": 1.0 / t_cand, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{steps} train steps + {rows} dev rows of conf-4 R={args.R} B={args.batch} f32 "
+                      f"(numpy oracle, BLAS threads = all cores), extrapolated to E={args.epochs} x "
+                      f"({nb} steps + {len(dev)} dev rows): {t_step * 1e3:.2f} ms/step, {t_row * 1e6:.1f} us/dev-row"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pop", type=int, default=128, help="candidates per GPU per step")
+    ap.add_argument("--R", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--drpt", type=float, default=0.5)
+    ap.add_argument("--n-train", type=int, default=10000)
+    ap.add_argument("--n-dev", type=int, default=5600)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
+    ap.add_argument("--chunk-cols", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    import mfas_amd as M
+    from mfas_amd import ntu_searchable as NS
+
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
+    train, dev = synth_tables(a.n_train, a.n_dev, device, dtype)
+    loaders = {"train": M.FeatureLoader(train, a.batch, shuffle=True), "dev": M.FeatureLoader(dev, a.batch, shuffle=False)}
+    args = SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=a.drpt, inner_representation_size=a.R,
+                           batchnorm=True, alphas=False, multitask=False, weightsharing=False, batchsize=a.batch,
+                           eta_max=1e-3, eta_min=1e-6, Ti=1, Tm=2, use_dataparallel=False, verbose=False,
+                           epochs=a.epochs, engine_init="device", engine_profile=True,
+                           engine_chunk_cols=a.chunk_cols)
+    confs = [np.array(CONF4) for _ in range(a.pop * world)]
+    torch.manual_seed(0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    accs = None
+    for _ in range(a.warmup):
+        accs = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, loaders, args, device)
+    NS.PROFILE.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        accs = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, loaders, args, device)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n_launch = sum(p[0] for p in NS.PROFILE)
+        ms = sum(p[1] for p in NS.PROFILE)
+        bytes_per_launch = NS.PROFILE[-1][2] if NS.PROFILE else 0.0
+        achieved = bytes_per_launch / (ms / n_launch * 1e-3) / 1e9 if n_launch else None
+        total = a.pop * world * a.steps
+        line = {
+            "metric": "candidate-archs trained/sec (NTU inner loop)", "value": total / dt, "unit": "candidates/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"NTU found conf 4, R={a.R}, batchnorm, drpt {a.drpt}, B={a.batch}, E={a.epochs}, "
+                                   f"N_train={a.n_train}, N_dev={a.n_dev}, {a.dtype} precomputed taps, f32 state/compute",
+                       "candidates_per_gpu_per_step": a.pop, "parallelism": f"population-sharded x{world}",
+                       "mean_best_dev_acc": float(np.mean(accs))},
+            "roofline": {"bound": "hbm", "kernel": "k_sweep (fused dW + Adam + next-step forward)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "launches": n_launch, "avg_launch_us": (ms / n_launch * 1e3) if n_launch else None,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(train, dev, a)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

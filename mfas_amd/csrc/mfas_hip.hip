@@ -56,9 +56,10 @@ static int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------------
 struct SegDesc {          // one workgroup of k_sweep / k_pack
     int32_t cand, kind, cell, tap;
-    int32_t k0, cc;       // first column inside the segment, chunk columns (multiple of 16)
+    int32_t k0, cc;       // first column inside the segment and column count of this workgroup's k-range
+    int32_t rb, _padrb;   // 16-row block handled by this workgroup
     int32_t rows_p, width;  // padded rows; FEAT: table row width (elements)
-    int64_t w_off;        // float offset (within a plane) of this chunk: tiles [rb][kb][256]
+    int64_t w_off;        // float offset (within a plane) of this (k-split, row block) run: tiles [kb][256]
     int64_t wt_off;       // OUT/HEAD: float offset in the transposed arena, else -1
     int32_t part_idx;     // FEAT: chunk index within the cell's partial list
     int32_t rows, cols;   // true rows (R or C) / true columns of the whole segment
@@ -82,7 +83,7 @@ struct CandDev {
     int32_t part_cell_off[MFAS_MAX_CELLS];  // first partial-slot index of cell i
     int64_t step_off;                     // float offset of this candidate's step buffers
     uint32_t drop_seed;
-    int32_t _pad;
+    int32_t gidx;                         // index of this candidate in the population (stats / status slot)
     // flat (reference state_dict order) offsets of this candidate's parameters
     int64_t f_alpha, f_W[MFAS_MAX_CELLS], f_b[MFAS_MAX_CELLS], f_bn[MFAS_MAX_CELLS], f_Wc, f_bc;
     int32_t K_in[MFAS_MAX_CELLS];   // in_features of cell i
@@ -104,7 +105,7 @@ struct Geo {             // geometry shared by all candidates of a population
     float drop_scale, bn_eps, bn_mom;
     uint32_t drop_thr;
     // per-candidate step-buffer sub-offsets (floats)
-    int64_t sb_part, sb_dy, sb_xo, sb_dlog, sb_sav, sb_gsc, sb_size;
+    int64_t sb_part, sb_dy, sb_xo, sb_dlog, sb_sav, sb_yf, sb_gsc, sb_size;
     int32_t vec_cell_stride;   // 5*Rp + 16
     int32_t vec_head;          // offset of head bias inside the vector block
     int32_t sw[4], vw[4];      // tap widths (elements per table row)
@@ -235,7 +236,9 @@ __device__ __forceinline__ void stage_f32(float* dst, int stride, const float* s
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_sweep — fused dW + Adam + next-step forward over one weight chunk
+// k_sweep — fused dW + Adam + next-step forward.  One workgroup = ALL row blocks of one weight segment
+// over a chunk of `cc` columns: x_t / x_{t+1} / dy are staged ONCE in LDS, then every wave streams whole
+// row blocks (contiguous 1 KiB tiles), requesting the W/m/v tiles of 4 k-blocks before consuming them.
 // ------------------------------------------------------------------------------------------------
 struct SweepArgs {
     const SegDesc* desc;
@@ -253,12 +256,15 @@ struct SweepArgs {
     Geo g;
 };
 
-template <int MB>
-__global__ void __launch_bounds__(256) k_sweep(const SweepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const SegDesc d = a.desc[blockIdx.x];
+#define STEP_NW 8
+#define STEP_THREADS (STEP_NW * 64)
+
+template <int MB, bool NT>
+__device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, float* lds) {
+    const SegDesc d = a.desc[bid];
     const CandDev& cd = a.cands[d.cand];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
     constexpr int Bp = MB * 16;
     const int cc = d.cc, rows_p = d.rows_p, nrb = rows_p >> 4, nkb = cc >> 4;
     const int ST = cc + 16;   // x_t stride: conflict-free ds_read_b32 column reads
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepArgs a) {
     float* xt = lds;
     float* xn = xt + Bp * ST;
     float* dyl = xn + Bp * SN;
-    float* wred = dyl + Bp * SD;   // [4 waves][nrb][MB][256], only when the chunk is k-split over waves
+    float* wred = dyl + Bp * SD;   // [8 waves][nrb][MB][256], only when the chunk is k-split over waves
     const bool feat = d.kind <= KIND_V;
     const bool upd = a.do_update != 0;
     const bool fwd = (a.do_forward != 0) && feat;
@@ -277,82 +283,104 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepArgs a) {
     if (upd) {
         if (feat) {
             const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
-            stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_t, a.base_t, a.nvalid_t, Bp,
-                        tid, 256);
+            stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_t, a.base_t, a.nvalid_t, Bp, tid, STEP_THREADS);
         } else {
             const int xcell = d.kind == KIND_OUT ? d.cell - 1 : cd.L - 1;
-            stage_f32(xt, ST, sb + a.g.sb_xo + (int64_t)xcell * Bp * a.g.Rp, a.g.Rp, cc, Bp, tid, 256);
+            stage_f32(xt, ST, sb + a.g.sb_xo + (int64_t)xcell * Bp * a.g.Rp + d.k0, a.g.Rp, cc, Bp, tid, STEP_THREADS);
         }
         const float* dsrc = d.kind == KIND_HEAD ? sb + a.g.sb_dlog : sb + a.g.sb_dy + (int64_t)d.cell * Bp * a.g.Rp;
-        stage_f32(dyl, SD, dsrc, rows_p, rows_p, Bp, tid, 256);
+        stage_f32(dyl, SD, dsrc, rows_p, rows_p, Bp, tid, STEP_THREADS);
     }
     if (fwd) {
         const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
-        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_n, a.base_n, a.nvalid_n, Bp, tid,
-                    256);
+        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_n, a.base_n, a.nvalid_n, Bp, tid, STEP_THREADS);
     }
     __syncthreads();
 
     float* Wp = a.plane + d.w_off;
     float* Mp = Wp + a.plane_stride;
     float* Vp = Mp + a.plane_stride;
-    const int l15 = lane & 15, lg = lane >> 4;
     const AdamC ac = a.ac;
     // alpha scaling of the gradient of S / V columns (aux_models.py:103-111): sigma(alpha_t) as used by this
     // step's forward, published by k_chain (alpha itself has already been stepped); 1.0 when alphas are off
     float gsc = 1.0f;
     if (a.g.alphas && feat && upd) gsc = sb[a.g.sb_gsc + d.cell * 2 + d.kind];
 
-    // Work split: with >= 4 row blocks every wave owns whole row blocks (streams contiguous tiles, no
-    // reduction); with fewer (R = 16/32) the waves split the k blocks and reduce through LDS.
-    const bool split_k = nrb < 4;
-    const int rb0 = split_k ? 0 : wave, rbs = split_k ? 1 : 4;
-    const int kb0 = split_k ? wave : 0, kbs = split_k ? 4 : 1;
+    // Work split: with >= 8 row blocks every wave owns whole row blocks (streams contiguous tiles, no
+    // reduction); with fewer (R < 128) the waves split the k blocks and reduce through LDS.
+    const bool split_k = nrb < STEP_NW;
+    const int rb0 = split_k ? 0 : wave, rbs = split_k ? 1 : STEP_NW;
+    const int kb0 = split_k ? wave : 0, kbs = split_k ? STEP_NW : 1;
     float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * nrb * MB) << 8);
 
     for (int rb = rb0; rb < nrb; rb += rbs) {
         float dyf[MB * 4];
-        if (upd) {
 #pragma unroll
-            for (int j = 0; j < MB * 4; ++j) dyf[j] = dyl[(4 * j + lg) * SD + rb * 16 + l15];
-        }
+        for (int j = 0; j < MB * 4; ++j) dyf[j] = upd ? dyl[(4 * j + lg) * SD + rb * 16 + l15] : 0.f;
         f32x4 yacc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int kb = kb0; kb < nkb; kb += kbs) {
-            const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
-            f32x4 w4 = *reinterpret_cast<const f32x4*>(Wp + off);
-            if (upd) {
-                f32x4 m4 = *reinterpret_cast<const f32x4*>(Mp + off);
-                f32x4 v4 = *reinterpret_cast<const f32x4*>(Vp + off);
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kbb = kb0; kbb < nkb; kbb += 4 * kbs) {
+            // request the W/m/v tiles of up to 4 k-blocks before any is consumed
+            f32x4 w4[4], m4[4], v4[4];
 #pragma unroll
-                for (int j = 0; j < MB * 4; ++j)
-                    acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float w = w4[q], m = m4[q], v = v4[q];
-                    adam1(w, m, v, acc[q] * gsc, ac);
-                    w4[q] = w;
-                    m4[q] = m;
-                    v4[q] = v;
-                }
-                *reinterpret_cast<f32x4*>(Wp + off) = w4;
-                *reinterpret_cast<f32x4*>(Mp + off) = m4;
-                *reinterpret_cast<f32x4*>(Vp + off) = v4;
-                if (d.wt_off >= 0) {   // keep the transposed copy used by the backward chain in step
-                    float* T = a.wt + d.wt_off + ((int64_t)kb * nrb + rb) * 256;
-                    const int base = (((l15 >> 2) * 16 + 4 * lg) << 2) + (l15 & 3);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) T[base + 4 * q] = w4[q];
+            for (int u = 0; u < 4; ++u) {
+                const int kb = kbb + u * kbs;
+                if (kb < nkb) {
+                    const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+                    // state larger than the Infinity Cache is streamed once per step: nontemporal (+5 % HBM rate)
+                    w4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Wp + off))
+                               : *reinterpret_cast<const f32x4*>(Wp + off);
+                    if (upd) {
+                        m4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mp + off))
+                                   : *reinterpret_cast<const f32x4*>(Mp + off);
+                        v4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vp + off))
+                                   : *reinterpret_cast<const f32x4*>(Vp + off);
+                    }
                 }
             }
-            if (fwd) {
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * SN + kb * 16 + 4 * lg);
+            for (int u = 0; u < 4; ++u) {
+                const int kb = kbb + u * kbs;
+                if (kb < nkb) {
+                    const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+                    if (upd) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[q], yacc[mb]);
+                        for (int j = 0; j < MB * 4; ++j)
+                            acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float w = w4[u][q], m = m4[u][q], v = v4[u][q];
+                            adam1(w, m, v, acc[q] * gsc, ac);
+                            w4[u][q] = w;
+                            m4[u][q] = m;
+                            v4[u][q] = v;
+                        }
+                        if (NT) {
+                            __builtin_nontemporal_store(w4[u], reinterpret_cast<f32x4*>(Wp + off));
+                            __builtin_nontemporal_store(m4[u], reinterpret_cast<f32x4*>(Mp + off));
+                            __builtin_nontemporal_store(v4[u], reinterpret_cast<f32x4*>(Vp + off));
+                        } else {
+                            *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
+                            *reinterpret_cast<f32x4*>(Mp + off) = m4[u];
+                            *reinterpret_cast<f32x4*>(Vp + off) = v4[u];
+                        }
+                        if (d.wt_off >= 0) {   // keep the transposed copy used by the backward chain in step
+                            float* T = a.wt + d.wt_off + ((int64_t)((d.k0 >> 4) + kb) * nrb + rb) * 256;
+                            const int base = (((l15 >> 2) * 16 + 4 * lg) << 2) + (l15 & 3);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) T[base + 4 * q] = w4[u][q];
+                        }
+                    }
+                    if (fwd) {
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * SN + kb * 16 + 4 * lg);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][q], yacc[mb]);
+                        }
+                    }
                 }
             }
         }
@@ -368,19 +396,21 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepArgs a) {
     }
     if (!fwd || !split_k) return;
     __syncthreads();
-    // deterministic cross-wave reduction (fixed order 0..3)
-    for (int e = tid; e < nrb * MB * 64; e += 256) {
+    // deterministic cross-wave reduction (fixed order 0..7)
+    for (int e = tid; e < nrb * MB * 64; e += STEP_THREADS) {
         const int slot = e >> 6, ln = e & 63;
         f32x4 s = *reinterpret_cast<const f32x4*>(wred + (slot << 8) + ln * 4);
 #pragma unroll
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < STEP_NW; ++w)
             s += *reinterpret_cast<const f32x4*>(wred + ((w * nrb * MB + slot) << 8) + ln * 4);
         *reinterpret_cast<f32x4*>(part + (slot << 8) + ln * 4) = s;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_chain — one workgroup per candidate: forward chain, CE loss, backward chain (train step)
+// k_chain — one 8-wave workgroup per candidate: forward chain, CE loss, backward chain (train step).
+// Latency-bound by construction (serial in the cells), so: every wave owns one 16-column block, weight
+// tiles of a product are requested in one batch before the MFMAs, saved activations live in LDS.
 // ------------------------------------------------------------------------------------------------
 struct ChainArgs {
     const CandDev* cands;
@@ -393,11 +423,15 @@ struct ChainArgs {
     int64_t pos_t;
     int32_t base_t, nvalid;
     int32_t gstep, epoch, E;
+    int32_t yf_in_lds, _pad;
     AdamC ac;
     Geo g;
     DevStats* stats;
     int32_t* status;
 };
+
+#define CHAIN_NW STEP_NW
+#define CHAIN_THREADS STEP_THREADS
 
 __device__ __forceinline__ bool drop_keep(uint32_t h0, int cell, uint32_t idx, uint32_t thr) {
     // oracle/np_oracle.py:dropout_keep
@@ -405,27 +439,55 @@ __device__ __forceinline__ bool drop_keep(uint32_t h0, int cell, uint32_t idx, u
     return (lowbias32(key ^ h0) >> 8) >= thr;
 }
 
+// acc[mb] += X[b][0..16*nk) . tile(k)   (X in LDS row-major with stride sx; tiles: 256 floats each, stride tstride)
 template <int MB>
-__global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const CandDev& cd = a.cands[blockIdx.x];
+__device__ __forceinline__ void lds_x_times_tiles(f32x4 (&acc)[MB], const float* X, int sx, const float* tiles,
+                                                  int64_t tstride, int nk, int lane) {
+    const int l15 = lane & 15, lg = lane >> 4;
+    for (int k0 = 0; k0 < nk; k0 += 8) {
+        f32x4 w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nk) w8[u] = *reinterpret_cast<const f32x4*>(tiles + (int64_t)(k0 + u) * tstride + lane * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nk) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(X + (mb * 16 + l15) * sx + (k0 + u) * 16 + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w8[u][q], acc[mb]);
+                }
+            }
+    }
+}
+
+template <int MB>
+__device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, float* lds) {
+    const CandDev& cd = a.cands[bid];
     const Geo& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     constexpr int Bp = MB * 16;
     const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
     const int SX = Rp + 4, SC = Cp + 4;
+    // LDS kept close to the sweep's so both bodies can share one launch: ping-pong activation buffers (out_i
+    // going forward, reused for dy_i coming back), logits, reduced feature sums; saved activations go to L2 scratch.
     float* xo_l = lds;                       // [2][Bp][SX]  ping-pong out_i (A operand of the next cell)
-    float* dy_l = xo_l + 2 * Bp * SX;        // [2][Bp][SX]  ping-pong dy_i (A operand of the backward chain)
-    float* lg_l = dy_l + 2 * Bp * SX;        // [Bp][SC]     logits -> dlogits
+    float* dy_l = xo_l;                      // backward reuses the same two buffers for dy_i
+    float* lg_l = xo_l + 2 * Bp * SX;        // [Bp][SC]  logits -> dlogits
     float* rstd_l = lg_l + Bp * SC;          // [L][Rp]
-    float* red_l = rstd_l + MFAS_MAX_CELLS * Rp;   // [2*Bp] loss / correct per row
-    int* lab_l = reinterpret_cast<int*>(red_l + 2 * Bp);   // [Bp]
+    float* red_l = rstd_l + MFAS_MAX_CELLS * Rp;   // [2*Bp] loss / correct per row (+ alpha partials)
+    int* lab_l = reinterpret_cast<int*>(red_l + 2 * Bp + 16);   // [Bp]
+    const int64_t sav_plane = (int64_t)MFAS_MAX_CELLS * nrb * MB * 256;
 
     float* W = a.plane;
     float* Mv = a.plane + a.plane_stride;
     float* Vv = Mv + a.plane_stride;
     float* sb = a.stepbuf + cd.step_off;
+    float* sav = sb + g.sb_sav;              // [3][L][nrb][MB][256]: act, xhat, (yS - yV)
+    // reduced feature sums [1 or 2][L][nrb][MB][256]: LDS when it fits the shared budget, else scratch
+    float* yf_l = a.yf_in_lds ? reinterpret_cast<float*>(lab_l + Bp) : sb + g.sb_yf;
     const int nvalid = a.nvalid;
     const float nf = (float)nvalid;
     const AdamC ac = a.ac;
@@ -440,14 +502,42 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
         lab_l[tid] = lab;
     }
 
+    // ------------------------------------------------------------------ phase 0: all 512 threads reduce the
+    // sweep's column-chunk partial sums of EVERY cell (fixed order) into LDS, loads batched 8 deep
+    {
+        const int per_cell = nrb * MB * 64;   // float4 items per cell
+        for (int e = tid; e < L * per_cell; e += CHAIN_THREADS) {
+            const int i = e / per_cell, it = e - i * per_cell;
+            const int ns = cd.nch_s[i], nch = ns + cd.nch_v[i];
+            const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8) + it * 4;
+            f32x4 accS = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
+            for (int ch0 = 0; ch0 < nch; ch0 += 8) {
+                f32x4 p8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (ch0 + u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)(ch0 + u) * nrb * MB) << 8));
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (ch0 + u < nch) {
+                        if (ch0 + u < ns) accS += p8[u]; else accV += p8[u];
+                    }
+            }
+            if (g.alphas) {
+                *reinterpret_cast<f32x4*>(yf_l + (int64_t)i * per_cell * 4 + it * 4) = accS;
+                *reinterpret_cast<f32x4*>(yf_l + sav_plane + (int64_t)i * per_cell * 4 + it * 4) = accV;
+            } else {
+                *reinterpret_cast<f32x4*>(yf_l + (int64_t)i * per_cell * 4 + it * 4) = accS + accV;
+            }
+        }
+    }
+    __syncthreads();
+
     // ------------------------------------------------------------------ forward chain
     for (int i = 0; i < L; ++i) {
         const float* xprev = xo_l + ((i + 1) & 1) * Bp * SX;
         float* xcur = xo_l + (i & 1) * Bp * SX;
         const int nl = cd.conf[i][2];
         const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
-        const int nch = cd.nch_s[i] + cd.nch_v[i];
-        const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8);
         float sgS = 1.0f, sgV = 1.0f;
         if (g.alphas) {
             const float sg = 1.0f / (1.0f + expf(-W[vb + 5 * Rp]));
@@ -458,44 +548,26 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
                 sb[g.sb_gsc + i * 2 + 1] = sgV;
             }
         }
-        for (int rb = wave; rb < nrb; rb += 4) {
-            f32x4 acc[MB], accv[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                accv[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            for (int ch = 0; ch < nch; ++ch) {
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const f32x4 p = *reinterpret_cast<const f32x4*>(part + ((((int64_t)ch * nrb + rb) * MB + mb) << 8) + lane * 4);
-                    if (ch < cd.nch_s[i]) acc[mb] += p; else accv[mb] += p;
-                }
-            }
-            if (g.alphas) {   // keep raw S-V difference for d(alpha); scale the two modality sums
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    *reinterpret_cast<f32x4*>(sb + g.sb_sav + ((((int64_t)(2 * MFAS_MAX_CELLS + i) * nrb + rb) * MB + mb) << 8) + lane * 4) = acc[mb] - accv[mb];
-                    acc[mb] = acc[mb] * sgS + accv[mb] * sgV;
-                }
-            } else {
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[mb] += accv[mb];
-            }
-            if (i > 0) {
-                for (int kb = 0; kb < nrb; ++kb) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][2], Rp, Rp, rb, kb) + lane * 4);
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xprev + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w4[q], acc[mb]);
-                    }
-                }
-            }
+        for (int rb = wave; rb < nrb; rb += CHAIN_NW) {
             const int r = rb * 16 + l15;
             const bool colok = r < R;
+            // independent loads first: vector parameters of this column
             const float bias = W[vb + VEC_B * Rp + r];
+            float gam = 1.f, bet = 0.f;
+            if (g.bn) { gam = W[vb + VEC_G * Rp + r]; bet = W[vb + VEC_BE * Rp + r]; }
+            f32x4 acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int64_t o = ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4;
+                acc[mb] = *reinterpret_cast<const f32x4*>(yf_l + o);
+                if (g.alphas) {   // keep raw S-V difference for d(alpha); scale the two modality sums
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yf_l + sav_plane + o);
+                    *reinterpret_cast<f32x4*>(sav + 2 * sav_plane + o) = acc[mb] - yv;
+                    acc[mb] = acc[mb] * sgS + yv * sgV;
+                }
+            }
+            if (i > 0)
+                lds_x_times_tiles<MB>(acc, xprev, SX, W + cd.seg_off[i][2] + (int64_t)rb * nrb * 256, 256, nrb, lane);
             float av[MB][4];
             float s = 0.f;
 #pragma unroll
@@ -503,8 +575,7 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int b = mb * 16 + 4 * lg + q;
-                    const float y = acc[mb][q] + bias;
-                    const float v = act_fwd(y, nl);
+                    const float v = act_fwd(acc[mb][q] + bias, nl);
                     av[mb][q] = v;
                     if (b < nvalid) s += v;
                 }
@@ -522,7 +593,6 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
                     }
                 const float var = colsum(s2) / nf;
                 const float rstd = 1.0f / sqrtf(var + g.bn_eps);
-                const float gam = W[vb + VEC_G * Rp + r], bet = W[vb + VEC_BE * Rp + r];
                 f32x4 xh4[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
@@ -545,7 +615,7 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
                 }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
-                    *reinterpret_cast<f32x4*>(sb + g.sb_sav + ((((int64_t)(MFAS_MAX_CELLS + i) * nrb + rb) * MB + mb) << 8) + lane * 4) = xh4[mb];
+                    *reinterpret_cast<f32x4*>(sav + sav_plane + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4) = xh4[mb];
             } else {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
@@ -557,7 +627,7 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
                 f32x4 a4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a4[q] = av[mb][q];
-                *reinterpret_cast<f32x4*>(sb + g.sb_sav + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4) = a4;
+                *reinterpret_cast<f32x4*>(sav + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4) = a4;
             }
             float* xo_g = sb + g.sb_xo + (int64_t)i * Bp * Rp;
 #pragma unroll
@@ -579,21 +649,13 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
     // ------------------------------------------------------------------ head + CE loss
     {
         const float* xl = xo_l + ((L - 1) & 1) * Bp * SX;
-        for (int cb = wave; cb < ncb; cb += 4) {
+        for (int cb = wave; cb < ncb; cb += CHAIN_NW) {
             f32x4 acc[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int kb = 0; kb < nrb; ++kb) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.head_off, Cp, Rp, cb, kb) + lane * 4);
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xl + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w4[q], acc[mb]);
-                }
-            }
             const int c = cb * 16 + l15;
             const float bias = W[cd.vec_off + g.vec_head + c];
+            lds_x_times_tiles<MB>(acc, xl, SX, W + cd.head_off + (int64_t)cb * nrb * 256, 256, nrb, lane);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -601,62 +663,68 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
         }
     }
     __syncthreads();
-    if (tid < Bp) {
-        float* row = lg_l + tid * SC;
-        float loss = 0.f, corr = 0.f;
-        if (tid < nvalid) {
-            const int lab = lab_l[tid];
-            float mx = row[0];
-            for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
-            float se = 0.f;
-            for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
-            loss = -(row[lab] - mx - logf(se));
-            // argmax, first max on ties (torch.max(dim=1)); multitask: central + visual + skeleton logits
-            int best = 0;
-            float bv;
-            if (g.multitask) {
-                const int64_t grow = a.order ? (int64_t)a.order[a.pos_t + tid] : (int64_t)(a.base_t + tid);
-                const float* vl = a.tab.vlogit + grow * C;
-                const float* sl = a.tab.slogit + grow * C;
-                bv = (row[0] + vl[0]) + sl[0];
-                for (int c = 1; c < C; ++c) {
-                    const float t = (row[c] + vl[c]) + sl[c];
-                    if (t > bv) { bv = t; best = c; }
-                }
-            } else {
-                bv = row[0];
-                for (int c = 1; c < C; ++c)
-                    if (row[c] > bv) { bv = row[c]; best = c; }
-            }
-            corr = best == lab ? 1.f : 0.f;
-            for (int c = 0; c < Cp; ++c) {
-                float dl = 0.f;
-                if (c < C) {
-                    dl = expf(row[c] - mx) / se;
-                    if (c == lab) dl -= 1.0f;
-                    dl = dl / nf;
-                }
-                row[c] = dl;
-            }
-        } else {
-            for (int c = 0; c < Cp; ++c) row[c] = 0.f;
+    if (tid < 4 * Bp) {   // 4 lanes per row: classes c = sub, sub+4, ...
+        const int b = tid >> 2, sub = tid & 3;
+        float* row = lg_l + b * SC;
+        const bool ok = b < nvalid;
+        const int lab = lab_l[b];
+        float mx = -3.0e38f;
+        for (int c = sub; c < C; c += 4) mx = fmaxf(mx, row[c]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        float se = 0.f;
+        for (int c = sub; c < C; c += 4) se += expf(row[c] - mx);
+        se += __shfl_xor(se, 1);
+        se += __shfl_xor(se, 2);
+        // argmax, first max on ties (torch.max(dim=1)); multitask: central + visual + skeleton logits
+        float bv = -3.0e38f;
+        int bi = 0x7FFFFFFF;
+        const float* vl = nullptr;
+        const float* sl = nullptr;
+        if (g.multitask && ok) {
+            const int64_t grow = a.order ? (int64_t)a.order[a.pos_t + b] : (int64_t)(a.base_t + b);
+            vl = a.tab.vlogit + grow * C;
+            sl = a.tab.slogit + grow * C;
         }
-        red_l[tid] = loss;
-        red_l[Bp + tid] = corr;
+        for (int c = sub; c < C; c += 4) {
+            float t = row[c];
+            if (vl) t = (t + vl[c]) + sl[c];
+            if (t > bv) { bv = t; bi = c; }
+        }
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) {
+            const float pv = __shfl_xor(bv, o);
+            const int pi = __shfl_xor(bi, o);
+            if (pv > bv || (pv == bv && pi < bi)) { bv = pv; bi = pi; }
+        }
+        const float lse = mx + logf(se);
+        if (sub == 0) {
+            red_l[b] = ok ? -(row[lab] - lse) : 0.f;
+            red_l[Bp + b] = (ok && bi == lab) ? 1.f : 0.f;
+        }
+        for (int c = sub; c < Cp; c += 4) {
+            float dl = 0.f;
+            if (ok && c < C) {
+                dl = expf(row[c] - mx) / se;
+                if (c == lab) dl -= 1.0f;
+                dl = dl / nf;
+            }
+            row[c] = dl;
+        }
     }
     __syncthreads();
     if (tid == 0) {
         float ls = 0.f, cs = 0.f;
         for (int b = 0; b < Bp; ++b) { ls += red_l[b]; cs += red_l[Bp + b]; }
-        DevStats& st = a.stats[(int64_t)blockIdx.x * a.E + a.epoch];
+        DevStats& st = a.stats[(int64_t)cd.gidx * a.E + a.epoch];
         st.train_loss += (double)ls;
         st.train_corr += (long long)cs;
-        if (!(fabsf(ls) <= 3.0e38f)) a.status[blockIdx.x] = 1;
+        if (!(fabsf(ls) <= 3.0e38f)) a.status[cd.gidx] = 1;
     }
-    // dlogits -> global (x operand dy of the HEAD segment); head-bias Adam
+    // dlogits -> global (dy operand of the HEAD segment); head-bias Adam
     {
         float* dlg = sb + g.sb_dlog;
-        for (int e = tid; e < Bp * Cp; e += 256) {
+        for (int e = tid; e < Bp * Cp; e += CHAIN_THREADS) {
             const int b = e / Cp, c = e - b * Cp;
             dlg[e] = lg_l[b * SC + c];
         }
@@ -681,28 +749,36 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
         const float* T = a.wt + (from_head ? cd.headT_off : cd.outT_off[i + 1]);
         float* dcur = dy_l + (i & 1) * Bp * SX;
         float dalpha = 0.f;
-        for (int rb = wave; rb < nrb; rb += 4) {
+        for (int rb = wave; rb < nrb; rb += CHAIN_NW) {
+            const int r = rb * 16 + l15;
+            const bool colok = r < R;
+            // independent loads first
+            float gr = 0.f;
+            if (g.bn) gr = W[vb + VEC_G * Rp + r] * rstd_l[i * Rp + r];
+            int64_t ob = vb + VEC_B * Rp + r, og = vb + VEC_G * Rp + r, obe = vb + VEC_BE * Rp + r;
+            float pw[3] = {0.f, 0.f, 0.f}, pm[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f};
+            if (lg == 0 && colok) {
+                pw[0] = W[ob]; pm[0] = Mv[ob]; pv[0] = Vv[ob];
+                if (g.bn) {
+                    pw[1] = W[og]; pm[1] = Mv[og]; pv[1] = Vv[og];
+                    pw[2] = W[obe]; pm[2] = Mv[obe]; pv[2] = Vv[obe];
+                }
+            }
+            f32x4 a4[MB], xh4[MB], df4[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                a4[mb] = *reinterpret_cast<const f32x4*>(sav + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4);
+                xh4[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                df4[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (g.bn)
+                    xh4[mb] = *reinterpret_cast<const f32x4*>(sav + sav_plane + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4);
+                if (g.alphas)
+                    df4[mb] = *reinterpret_cast<const f32x4*>(sav + 2 * sav_plane + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4);
+            }
             f32x4 acc[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int kb = 0; kb < nkk; ++kb) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(T + (((int64_t)rb * nkk + kb) << 8) + lane * 4);
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(src + (mb * 16 + l15) * sstride + kb * 16 + 4 * lg);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w4[q], acc[mb]);
-                }
-            }
-            const int r = rb * 16 + l15;
-            const bool colok = r < R;
-            f32x4 a4[MB], xh4[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                a4[mb] = *reinterpret_cast<const f32x4*>(sb + g.sb_sav + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4);
-                if (g.bn)
-                    xh4[mb] = *reinterpret_cast<const f32x4*>(sb + g.sb_sav + ((((int64_t)(MFAS_MAX_CELLS + i) * nrb + rb) * MB + mb) << 8) + lane * 4);
-            }
+            lds_x_times_tiles<MB>(acc, src, sstride, T + (int64_t)rb * nkk * 256, 256, nkk, lane);
             float dz[MB][4];
             float sdz = 0.f, sdzx = 0.f;
 #pragma unroll
@@ -722,7 +798,6 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
             if (g.bn) {
                 dbet = colsum(sdz);
                 dgam = colsum(sdzx);
-                const float gr = W[vb + VEC_G * Rp + r] * rstd_l[i * Rp + r];
                 const float k1 = dbet / nf, k2 = dgam / nf;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
@@ -736,46 +811,37 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
             float sdy = 0.f;
             float* dy_g = sb + g.sb_dy + (int64_t)i * Bp * Rp;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                f32x4 df = {0.f, 0.f, 0.f, 0.f};
-                if (g.alphas)
-                    df = *reinterpret_cast<const f32x4*>(sb + g.sb_sav + ((((int64_t)(2 * MFAS_MAX_CELLS + i) * nrb + rb) * MB + mb) << 8) + lane * 4);
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int b = mb * 16 + 4 * lg + q;
                     float dy = act_bwd(a4[mb][q], dz[mb][q], nl);
                     if (!colok) dy = 0.f;
                     sdy += dy;
-                    dalpha += dy * df[q];
+                    dalpha += dy * df4[mb][q];
                     dcur[b * SX + r] = dy;
                     dy_g[b * Rp + r] = dy;
                 }
-            }
             const float db = colsum(sdy);
             if (lg == 0 && colok) {   // Adam on the column's vector parameters (one owner lane per column)
-                int64_t o = vb + VEC_B * Rp + r;
-                float w = W[o], m = Mv[o], v = Vv[o];
-                adam1(w, m, v, db, ac);
-                W[o] = w; Mv[o] = m; Vv[o] = v;
+                adam1(pw[0], pm[0], pv[0], db, ac);
+                W[ob] = pw[0]; Mv[ob] = pm[0]; Vv[ob] = pv[0];
                 if (g.bn) {
-                    o = vb + VEC_G * Rp + r;
-                    w = W[o]; m = Mv[o]; v = Vv[o];
-                    adam1(w, m, v, dgam, ac);
-                    W[o] = w; Mv[o] = m; Vv[o] = v;
-                    o = vb + VEC_BE * Rp + r;
-                    w = W[o]; m = Mv[o]; v = Vv[o];
-                    adam1(w, m, v, dbet, ac);
-                    W[o] = w; Mv[o] = m; Vv[o] = v;
+                    adam1(pw[1], pm[1], pv[1], dgam, ac);
+                    W[og] = pw[1]; Mv[og] = pm[1]; Vv[og] = pv[1];
+                    adam1(pw[2], pm[2], pv[2], dbet, ac);
+                    W[obe] = pw[2]; Mv[obe] = pm[2]; Vv[obe] = pv[2];
                 }
             }
         }
         if (g.alphas) {   // d(alpha_i) = sigma'(alpha) * sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]
             for (int o = 32; o > 0; o >>= 1) dalpha += __shfl_xor(dalpha, o);
-            if (lane == 0) red_l[wave] = dalpha;
+            if (lane == 0) red_l[2 * Bp + wave] = dalpha;
         }
         __syncthreads();
         if (g.alphas && tid == 0) {
-            const float tot = (red_l[0] + red_l[1]) + (red_l[2] + red_l[3]);
+            float tot = 0.f;
+            for (int w = 0; w < CHAIN_NW; ++w) tot += red_l[2 * Bp + w];
             const int64_t o = vb + 5 * Rp;
             float w = W[o], m = Mv[o], v = Vv[o];
             const float sg = 1.0f / (1.0f + expf(-w));
@@ -784,6 +850,24 @@ __global__ void __launch_bounds__(256) k_chain(const ChainArgs a) {
         }
         if (g.alphas) __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_step — ONE launch per half-step: blocks [0, nchain) run the chain of one candidate group while the other
+// blocks run the sweep of the OTHER group (candidates are independent).  The latency-bound chain hides under
+// the HBM-bound sweep; kernel boundaries carry every dependency (chain(t) -> sweep(t) -> chain(t+1) of a group).
+// ------------------------------------------------------------------------------------------------
+struct StepArgs {
+    SweepArgs sa;
+    ChainArgs ca;
+    int32_t nchain, _pad;
+};
+
+template <int MB, bool NT>
+__global__ void __launch_bounds__(STEP_THREADS, (MB == 1 ? 4 : 2)) k_step(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x < a.nchain) chain_body<MB>(a.ca, (int)blockIdx.x, lds);
+    else sweep_body<MB, NT>(a.sa, (int)blockIdx.x - a.nchain, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1044,7 +1128,7 @@ __global__ void __launch_bounds__(256) k_pack(const PackArgs a) {
         Wp[2 * a.plane_stride + e] = 0.f;
         if (d.wt_off >= 0) {
             const int l15 = lane & 15, lg = lane >> 4;
-            float* T = a.wt + d.wt_off + ((int64_t)kb * nrb + rb) * 256;
+            float* T = a.wt + d.wt_off + ((int64_t)((d.k0 >> 4) + kb) * nrb + rb) * 256;
             T[((((l15 >> 2) * 16 + 4 * lg) + q) << 2) + (l15 & 3)] = val;
         }
     }
@@ -1139,18 +1223,23 @@ struct mfas_population {
     int64_t plane_stride = 0, wt_size = 0, step_total = 0;
     CandDev* d_cands = nullptr;
     SegDesc* d_descs = nullptr;
+    struct Group { int c0 = 0, nc = 0, ndesc = 0; SegDesc* d_descs = nullptr; double alg_state = 0, alg_feat = 0; };
+    std::vector<Group> groups;           // 1 or 2 contiguous candidate ranges, each with its own sweep work list
     DevStats* d_stats = nullptr;
     int32_t* d_status = nullptr;
     uint32_t* d_seeds = nullptr;
     long long* d_corr = nullptr;
-    size_t lds_sweep = 0, lds_chain = 0, lds_eval = 0;
+    size_t lds_step = 0, lds_eval = 0;
     int mbe = 4, nrbw = 1;
+    bool yf_in_lds = false;
+    bool nontemporal = false;
     int stats_cap = 0;
     // profiling of the dominant kernel
     bool profiling = false;
+    int prof_every = 16;            // HIP events bracket every prof_every-th sweep launch (event records are not free)
     std::vector<hipEvent_t> ev;     // pairs
     int64_t prof_launches = 0;
-    double prof_ms = 0.0, bytes_per_launch = 0.0;
+    double prof_ms = 0.0, bytes_per_launch = 0.0, prof_bytes = 0.0;
     double alg_state_bytes = 0.0, alg_feat_elems = 0.0;
 };
 
@@ -1208,7 +1297,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     for (int j = 0; j < 4; ++j) { g.sw[j] = hp->s_sizes[j]; g.vw[j] = hp->v_sizes[j]; }
     const int vec_size = (g.vec_head + g.Cp + 63) & ~63;
 
-    // ---- chunk target: enough workgroups to fill 256 CUs several times over
+    // ---- column chunk per workgroup: enough workgroups to fill 256 CUs several times over
     int target = chunk_cols;
     if (target <= 0) {
         double totF = 0;
@@ -1216,10 +1305,9 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             for (int i = 0; i < n_cells[k]; ++i)
                 totF += hp->s_sizes[confs[(k * 4 + i) * 3] & 3] + hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 3];
         target = 256;
-        while (target > 64 && totF / target < 1024.0) target >>= 1;
+        while (target > 64 && totF / target < 1536.0) target >>= 1;
     }
     target = std::max(16, (target / 16) * 16);
-
     p->cands.resize(K);
     p->desc_start.assign(K + 1, 0);
     p->nparams.resize(K);
@@ -1237,6 +1325,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         if (L < 1 || L > MFAS_MAX_CELLS) { delete p; return fail(MFAS_EINVAL, "n_cells must be in [1,4]"); }
         c.L = L;
         c.drop_seed = drop_seeds ? drop_seeds[k] : (uint32_t)k;
+        c.gidx = k;
         p->desc_start[k] = (int)p->descs.size();
         p->cand_plane_base[k] = plane_off;
         c.vec_off = plane_off;
@@ -1277,7 +1366,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
                     SegDesc d;
                     memset(&d, 0, sizeof(d));
                     d.cand = k; d.kind = j; d.cell = i; d.tap = j < 2 ? c.conf[i][j] : 0;
-                    d.k0 = ch * cc; d.cc = cc; d.rows_p = g.Rp; d.width = j < 2 ? widths[j] : g.Rp;
+                    d.k0 = ch * cc; d.cc = cc; d.rb = -1; d.rows_p = g.Rp; d.width = j < 2 ? widths[j] : g.Rp;
                     d.w_off = plane_off + (int64_t)ch * g.Rp * cc;
                     d.wt_off = j == 2 ? wt_off : -1;
                     d.part_idx = j < 2 ? (j == 0 ? ch : c.nch_s[i] + ch) : 0;
@@ -1302,7 +1391,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             SegDesc d;
             memset(&d, 0, sizeof(d));
             d.cand = k; d.kind = KIND_HEAD; d.cell = L - 1; d.tap = 0;
-            d.k0 = 0; d.cc = g.Rp; d.rows_p = g.Cp; d.width = g.Rp;
+            d.k0 = 0; d.cc = g.Rp; d.rb = -1; d.rows_p = g.Cp; d.width = g.Rp;
             d.w_off = plane_off; d.wt_off = wt_off; d.part_idx = 0;
             d.rows = hp->C; d.cols = hp->R;
             d.src_off = c.f_Wc; d.src_ld = hp->R; d.src_col0 = 0;
@@ -1327,6 +1416,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         g.sb_xo = o; o += MFAS_MAX_CELLS * br;
         g.sb_dlog = o; o += (int64_t)g.Bp * g.Cp;
         g.sb_sav = o; o += 3 * MFAS_MAX_CELLS * br;
+        g.sb_yf = o; o += 2 * MFAS_MAX_CELLS * br;
         g.sb_gsc = o; o += 16;
         g.sb_size = (o + 63) & ~63LL;
         for (int k = 0; k < K; ++k) { p->cands[k].step_off = step_off; step_off += g.sb_size; }
@@ -1339,15 +1429,20 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     p->bytes_per_launch = alg_bytes + 4.0 * alg_feat;
 
     // ---- LDS budgets
-    size_t ls = 0;
-    for (const SegDesc& d : p->descs) {
-        const int nrb = d.rows_p / 16;
-        size_t fl = (size_t)g.Bp * (d.cc + 16) + (size_t)g.Bp * (d.cc + 4) + (size_t)g.Bp * (d.rows_p + 16);
-        if (nrb < 4) fl += (size_t)4 * nrb * g.MB * 256;
-        ls = std::max(ls, fl * 4);
+    {
+        size_t ls = 0;
+        for (const SegDesc& d : p->descs) {
+            const int nrb = d.rows_p / 16;
+            size_t fl = (size_t)g.Bp * (d.cc + 16) + (size_t)g.Bp * (d.cc + 4) + (size_t)g.Bp * (d.rows_p + 16);
+            if (nrb < STEP_NW) fl += (size_t)STEP_NW * nrb * g.MB * 256;
+            ls = std::max(ls, fl * 4);
+        }
+        // chain: ping-pong activations + logits + misc (+ reduced feature sums when they fit next to the sweep's need)
+        const size_t base = ((size_t)2 * g.Bp * (g.Rp + 4) + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * g.Rp + 3 * g.Bp + 16) * 4;
+        const size_t yf = (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.nrb * g.MB * 256 * 4;
+        p->yf_in_lds = base + yf <= std::max<size_t>(ls, 64 * 1024);
+        p->lds_step = std::max(ls, base + (p->yf_in_lds ? yf : 0));
     }
-    p->lds_sweep = ls;
-    p->lds_chain = ((size_t)4 * g.Bp * (g.Rp + 4) + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * g.Rp + 3 * g.Bp + 16) * 4;
     p->nrbw = (g.nrb + 3) / 4;
     if (p->nrbw == 3) p->nrbw = 4;
     for (p->mbe = 4; p->mbe >= 1; p->mbe >>= 1) {
@@ -1355,7 +1450,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         p->lds_eval = ((size_t)ME * (EVAL_CE + 4) + (size_t)2 * ME * (g.Rp + 4) + (size_t)ME * (g.Cp + 4)) * 4;
         if (p->lds_eval <= 120 * 1024) break;
     }
-    if (p->mbe < 1 || p->nrbw > 8 || p->lds_sweep > 150 * 1024 || p->lds_chain > 150 * 1024) {
+    if (p->mbe < 1 || p->nrbw > 8 || p->lds_step > 150 * 1024) {
         delete p;
         return fail(MFAS_EINVAL, "geometry does not fit the 160 KiB LDS (R / batchsize too large)");
     }
@@ -1379,15 +1474,47 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(hipMalloc(&p->d_corr, sizeof(long long)));
     CREATE_CHK(hipMemcpy(p->d_cands, p->cands.data(), sizeof(CandDev) * K, hipMemcpyHostToDevice));
     CREATE_CHK(hipMemcpy(p->d_descs, p->descs.data(), sizeof(SegDesc) * p->descs.size(), hipMemcpyHostToDevice));
+    {   // candidate groups: two halves balanced by work (descriptor columns), contiguous ranges
+        const int ngroups = (K >= 2 && !getenv("MFAS_ONE_GROUP")) ? 2 : 1;
+        int split = K;
+        if (ngroups == 2) {
+            double tot = 0, run = 0;
+            for (const SegDesc& d : p->descs) tot += (double)d.cc * d.rows_p;
+            split = 1;
+            for (int k = 0; k < K - 1; ++k) {
+                for (int j = p->desc_start[k]; j < p->desc_start[k + 1]; ++j) run += (double)p->descs[j].cc * p->descs[j].rows_p;
+                split = k + 1;
+                if (run >= tot / 2) break;
+            }
+        }
+        for (int gi = 0; gi < ngroups; ++gi) {
+            mfas_population::Group gr;
+            gr.c0 = gi == 0 ? 0 : split;
+            gr.nc = gi == 0 ? split : K - split;
+            std::vector<SegDesc> sorted(p->descs.begin() + p->desc_start[gr.c0], p->descs.begin() + p->desc_start[gr.c0 + gr.nc]);
+            std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) { return x.cc * x.rows_p > y.cc * y.rows_p; });
+            gr.ndesc = (int)sorted.size();
+            for (const SegDesc& d : sorted) {
+                gr.alg_state += 24.0 * d.rows * std::min(d.cc, d.cols - d.k0);
+                if (d.kind <= KIND_V) gr.alg_feat += (double)hp->B * d.cc;
+            }
+            CREATE_CHK(hipMalloc(&gr.d_descs, sizeof(SegDesc) * sorted.size()));
+            CREATE_CHK(hipMemcpy(gr.d_descs, sorted.data(), sizeof(SegDesc) * sorted.size(), hipMemcpyHostToDevice));
+            p->groups.push_back(gr);
+        }
+    }
     CREATE_CHK(hipMemsetAsync(p->plane, 0, sizeof(float) * 3 * (size_t)p->plane_stride, p->stream));
     CREATE_CHK(hipMemsetAsync(p->wt, 0, sizeof(float) * (size_t)std::max<int64_t>(p->wt_size, 64), p->stream));
     CREATE_CHK(hipMemsetAsync(p->stepbuf, 0, sizeof(float) * (size_t)p->step_total, p->stream));
-    CREATE_CHK(set_lds(k_sweep<1>, p->lds_sweep));
-    CREATE_CHK(set_lds(k_sweep<2>, p->lds_sweep));
-    CREATE_CHK(set_lds(k_sweep<4>, p->lds_sweep));
-    CREATE_CHK(set_lds(k_chain<1>, p->lds_chain));
-    CREATE_CHK(set_lds(k_chain<2>, p->lds_chain));
-    CREATE_CHK(set_lds(k_chain<4>, p->lds_chain));
+    CREATE_CHK(set_lds((k_step<1, false>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<2, false>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<4, false>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<1, true>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<2, true>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<4, true>), p->lds_step));
+    // W/m/v beyond what the 256 MiB Infinity Cache can keep between steps are streamed nontemporally
+    p->nontemporal = (double)p->plane_stride * 12.0 > 200.0 * 1024 * 1024;
+    if (const char* e = getenv("MFAS_NT")) p->nontemporal = atoi(e) != 0;
     CREATE_CHK(hipStreamSynchronize(p->stream));
     *out = p;
     return MFAS_OK;
@@ -1399,6 +1526,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->ev) hipEventDestroy(e);
     hipFree(p->plane); hipFree(p->wt); hipFree(p->stepbuf); hipFree(p->best);
+    for (auto& gr : p->groups) hipFree(gr.d_descs);
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
     hipFree(p->d_seeds); hipFree(p->d_corr);
     delete p;
@@ -1465,27 +1593,18 @@ static int check_table(const mfas_population* p, const mfas_table* t, bool need_
     return MFAS_OK;
 }
 
-template <int MB>
-static void launch_sweep(mfas_population* p, const SweepArgs& a) {
-    hipLaunchKernelGGL(k_sweep<MB>, dim3((unsigned)p->descs.size()), dim3(256), p->lds_sweep, p->stream, a);
-}
-template <int MB>
-static void launch_chain(mfas_population* p, const ChainArgs& a) {
-    hipLaunchKernelGGL(k_chain<MB>, dim3(p->K), dim3(256), p->lds_chain, p->stream, a);
-}
-
 template <int MBE, int NRBW>
-static hipError_t launch_eval_t(mfas_population* p, const EvalArgs& a, int ncand) {
+static hipError_t launch_eval_t(mfas_population* p, const EvalArgs& a, int ncand, hipStream_t st) {
     hipError_t e = set_lds(k_eval<MBE, NRBW>, p->lds_eval);
     if (e != hipSuccess) return e;
     const int ME = MBE * 16;
     const unsigned nblk = (unsigned)((a.nrows + ME - 1) / ME);
-    hipLaunchKernelGGL((k_eval<MBE, NRBW>), dim3(nblk, ncand), dim3(256), p->lds_eval, p->stream, a);
+    hipLaunchKernelGGL((k_eval<MBE, NRBW>), dim3(nblk, ncand), dim3(256), p->lds_eval, st, a);
     return hipGetLastError();
 }
 
-static hipError_t launch_eval(mfas_population* p, const EvalArgs& a, int ncand) {
-#define EV_CASE(M, N) if (p->mbe == M && p->nrbw == N) return launch_eval_t<M, N>(p, a, ncand);
+static hipError_t launch_eval(mfas_population* p, const EvalArgs& a, int ncand, hipStream_t st) {
+#define EV_CASE(M, N) if (p->mbe == M && p->nrbw == N) return launch_eval_t<M, N>(p, a, ncand, st);
     EV_CASE(4, 1) EV_CASE(4, 2) EV_CASE(4, 4) EV_CASE(4, 8)
     EV_CASE(2, 1) EV_CASE(2, 2) EV_CASE(2, 4) EV_CASE(2, 8)
     EV_CASE(1, 1) EV_CASE(1, 2) EV_CASE(1, 4) EV_CASE(1, 8)
@@ -1526,31 +1645,51 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     ac.w1 = (float)(1.0 - hp.beta1); ac.b2 = (float)hp.beta2; ac.w2 = (float)(1.0 - hp.beta2);
     ac.eps = (float)hp.adam_eps; ac.wd = (float)hp.wd; ac.ss = 0.f; ac.bc2s = 1.f;
 
-    SweepArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.desc = p->d_descs; sa.cands = p->d_cands; sa.plane = p->plane; sa.plane_stride = p->plane_stride;
-    sa.wt = p->wt; sa.stepbuf = p->stepbuf; sa.tab = *train; sa.order = order; sa.g = g; sa.ac = ac;
-    ChainArgs ca;
-    memset(&ca, 0, sizeof(ca));
-    ca.cands = p->d_cands; ca.plane = p->plane; ca.plane_stride = p->plane_stride; ca.wt = p->wt;
-    ca.stepbuf = p->stepbuf; ca.tab = *train; ca.order = order; ca.E = epochs; ca.g = g;
-    ca.stats = p->d_stats; ca.status = p->d_status; ca.ac = ac;
+    // Candidate groups A/B: every launch pairs the sweep of one group with the chain of the other (k_step).
+    const int NG = (int)p->groups.size();
+    StepArgs st;
+    memset(&st, 0, sizeof(st));
+    st.sa.cands = p->d_cands; st.sa.plane = p->plane; st.sa.plane_stride = p->plane_stride; st.sa.wt = p->wt;
+    st.sa.stepbuf = p->stepbuf; st.sa.tab = *train; st.sa.order = order; st.sa.g = g; st.sa.ac = ac;
+    st.ca.plane = p->plane; st.ca.plane_stride = p->plane_stride; st.ca.wt = p->wt; st.ca.stepbuf = p->stepbuf;
+    st.ca.tab = *train; st.ca.order = order; st.ca.E = epochs; st.ca.g = g; st.ca.stats = p->d_stats;
+    st.ca.status = p->d_status; st.ca.ac = ac; st.ca.yf_in_lds = p->yf_in_lds ? 1 : 0;
 
-    p->prof_launches = 0; p->prof_ms = 0.0;
-    size_t ev_used = 0;
     const int elt = train->dtype == MFAS_DT_F32 ? 4 : 2;
-    // algorithmic HBM bytes of one update+forward sweep: 24 B/param (read+write W,m,v) + the batch's taps + labels
-    p->bytes_per_launch = p->alg_state_bytes + p->alg_feat_elems * elt + 8.0 * B * K;
+    p->prof_launches = 0; p->prof_ms = 0.0; p->prof_bytes = 0.0;
+    size_t ev_used = 0;
+    std::vector<double> ev_bytes;
+    int64_t nlaunch = 0;
 
-    auto sweep = [&](int upd, int fwd, int64_t ep, int64_t t, float ss, float bc2s) {
-        sa.do_update = upd; sa.do_forward = fwd;
-        sa.pos_t = ep * N + t * B; sa.base_t = (int)(t * B);
-        sa.nvalid_t = (int)std::min<int64_t>(B, N - t * B);
-        const int64_t tn = fwd ? (upd ? t + 1 : t) : t;
-        sa.pos_n = ep * N + tn * B; sa.base_n = (int)(tn * B);
-        sa.nvalid_n = (int)std::min<int64_t>(B, N - tn * B);
-        sa.ac.ss = ss; sa.ac.bc2s = bc2s;
-        const bool prof = p->profiling && upd && fwd;
+    // one fused launch: sweep of group gs at step ts (gs < 0: none) + chain of group gc at step tc (gc < 0: none)
+    auto step = [&](int gs, int upd, int fwd, int64_t ep, int64_t ts, int gc, int64_t tc) {
+        unsigned nsw = 0, nch = 0;
+        if (gs >= 0) {
+            SweepArgs& s = st.sa;
+            s.desc = p->groups[gs].d_descs;
+            s.do_update = upd; s.do_forward = fwd;
+            s.pos_t = ep * N + ts * B; s.base_t = (int)(ts * B);
+            s.nvalid_t = (int)std::min<int64_t>(B, N - ts * B);
+            const int64_t tn = fwd ? (upd ? ts + 1 : ts) : ts;
+            s.pos_n = ep * N + tn * B; s.base_n = (int)(tn * B);
+            s.nvalid_n = (int)std::min<int64_t>(B, N - tn * B);
+            const int64_t gstep = ep * nb + ts;
+            s.ac.ss = upd ? step_scalars[2 * gstep] : 0.f;
+            s.ac.bc2s = upd ? step_scalars[2 * gstep + 1] : 1.f;
+            nsw = (unsigned)p->groups[gs].ndesc;
+        }
+        if (gc >= 0) {
+            ChainArgs& c = st.ca;
+            c.cands = p->d_cands + p->groups[gc].c0;
+            c.pos_t = ep * N + tc * B; c.base_t = (int)(tc * B);
+            c.nvalid = (int)std::min<int64_t>(B, N - tc * B);
+            const int64_t gstep = ep * nb + tc;
+            c.gstep = (int)gstep; c.epoch = (int)ep;
+            c.ac.ss = step_scalars[2 * gstep]; c.ac.bc2s = step_scalars[2 * gstep + 1];
+            nch = (unsigned)p->groups[gc].nc;
+        }
+        st.nchain = (int)nch;
+        const bool prof = p->profiling && gs >= 0 && upd && fwd && ((nlaunch++ % p->prof_every) == 0);
         if (prof) {
             if (p->ev.size() < ev_used + 2) {
                 hipEvent_t e0, e1;
@@ -1559,38 +1698,45 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             }
             hipEventRecord(p->ev[ev_used], p->stream);
         }
-        if (g.MB == 1) launch_sweep<1>(p, sa);
-        else if (g.MB == 2) launch_sweep<2>(p, sa);
-        else launch_sweep<4>(p, sa);
-        if (prof) { hipEventRecord(p->ev[ev_used + 1], p->stream); ev_used += 2; }
+#define STEP_LAUNCH(M, T) hipLaunchKernelGGL((k_step<M, T>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
+        if (p->nontemporal) { if (g.MB == 1) STEP_LAUNCH(1, true); else if (g.MB == 2) STEP_LAUNCH(2, true); else STEP_LAUNCH(4, true); }
+        else { if (g.MB == 1) STEP_LAUNCH(1, false); else if (g.MB == 2) STEP_LAUNCH(2, false); else STEP_LAUNCH(4, false); }
+#undef STEP_LAUNCH
+        if (prof) {
+            hipEventRecord(p->ev[ev_used + 1], p->stream);
+            ev_used += 2;
+            // algorithmic HBM bytes of this group's update+forward sweep: 24 B/param + the batch's taps + labels
+            ev_bytes.push_back(p->groups[gs].alg_state + p->groups[gs].alg_feat * elt + 8.0 * B * p->groups[gs].nc);
+        }
     };
 
-    int64_t gstep = 0;
-    bool stop = false;
-    for (int ep = 0; ep < epochs && !stop; ++ep) {
-        // prologue: forward partial sums for the first batch of the epoch
-        sweep(0, 1, ep, 0, 0.f, 1.f);
-        for (int64_t t = 0; t < nb; ++t) {
-            if (max_steps >= 0 && gstep >= max_steps) { stop = true; break; }
-            const float ss = step_scalars[2 * gstep], bc2s = step_scalars[2 * gstep + 1];
-            ca.pos_t = (int64_t)ep * N + t * B; ca.base_t = (int)(t * B);
-            ca.nvalid = (int)std::min<int64_t>(B, N - t * B);
-            ca.gstep = (int)gstep; ca.epoch = ep;
-            ca.ac.ss = ss; ca.ac.bc2s = bc2s;
-            if (g.MB == 1) launch_chain<1>(p, ca);
-            else if (g.MB == 2) launch_chain<2>(p, ca);
-            else launch_chain<4>(p, ca);
-            const bool last = (t + 1 == nb) || (max_steps >= 0 && gstep + 1 >= max_steps);
-            sweep(1, last ? 0 : 1, ep, t, ss, bc2s);
-            ++gstep;
+    int64_t done = 0;   // train steps completed (max_steps bookkeeping)
+    for (int ep = 0; ep < epochs; ++ep) {
+        int64_t T = nb;
+        if (max_steps >= 0) T = std::min<int64_t>(nb, max_steps - done);
+        if (T <= 0) break;
+        for (int gi = 0; gi < NG; ++gi) step(gi, 0, 1, ep, 0, -1, 0);   // prologue: forward sums of batch 0
+        if (NG == 1) {
+            for (int64_t t = 0; t < T; ++t) {
+                step(-1, 0, 0, ep, 0, 0, t);
+                step(0, 1, (t + 1 < T) ? 1 : 0, ep, t, -1, 0);
+            }
+        } else {
+            step(-1, 0, 0, ep, 0, 0, 0);   // chain(A, 0)
+            for (int64_t t = 0; t < T; ++t) {
+                const int fwd = (t + 1 < T) ? 1 : 0;
+                step(0, 1, fwd, ep, t, 1, t);                       // sweep(A, t)  ||  chain(B, t)
+                step(1, 1, fwd, ep, t, fwd ? 0 : -1, t + 1);        // sweep(B, t)  ||  chain(A, t+1)
+            }
         }
+        done += T;
         HIPCHK(hipGetLastError());
         if (do_dev) {
             EvalArgs ea;
             memset(&ea, 0, sizeof(ea));
             ea.cands = p->d_cands; ea.plane = p->plane; ea.tab = *dev; ea.row0 = 0; ea.nrows = dev->N;
             ea.cand0 = 0; ea.epoch = ep; ea.E = epochs; ea.g = g; ea.stats = p->d_stats;
-            HIPCHK(launch_eval(p, ea, K));
+            HIPCHK(launch_eval(p, ea, K, p->stream));
             if (snapshot_best) {
                 HIPCHK(hipMemcpyAsync(hstats.data(), p->d_stats, sizeof(DevStats) * K * epochs, hipMemcpyDeviceToHost, p->stream));
                 HIPCHK(hipStreamSynchronize(p->stream));
@@ -1626,8 +1772,11 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     if (p->profiling) {
         for (size_t i = 0; i + 1 < ev_used; i += 2) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) == hipSuccess) { p->prof_ms += ms; p->prof_launches++; }
+            if (hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) == hipSuccess) {
+                p->prof_ms += ms; p->prof_launches++; p->prof_bytes += ev_bytes[i / 2];
+            }
         }
+        p->bytes_per_launch = p->prof_launches ? p->prof_bytes / p->prof_launches : 0.0;
     }
     return MFAS_OK;
 }
@@ -1647,7 +1796,7 @@ extern "C" int mfas_population_forward(mfas_population* p, int32_t k, const mfas
         HIPCHK(hipMemsetAsync(p->d_corr, 0, sizeof(long long), p->stream));
         ea.corr_out = p->d_corr;
     }
-    HIPCHK(launch_eval(p, ea, 1));
+    HIPCHK(launch_eval(p, ea, 1, p->stream));
     if (corrects) {
         long long h = 0;
         HIPCHK(hipMemcpyAsync(&h, p->d_corr, sizeof(long long), hipMemcpyDeviceToHost, p->stream));
@@ -1660,6 +1809,7 @@ extern "C" int mfas_population_forward(mfas_population* p, int32_t k, const mfas
 extern "C" int mfas_population_set_profiling(mfas_population* p, int32_t on) {
     if (!p) return fail(MFAS_EINVAL, "null");
     p->profiling = on != 0;
+    if (const char* e = getenv("MFAS_PROF_EVERY")) p->prof_every = std::max(1, atoi(e));
     return MFAS_OK;
 }
 

@@ -215,6 +215,9 @@ def set_central_states(model, state_dict, using_dataparallel=False):
 
 
 # ------------------------------------------------------------------------------------------------ the driver
+PROFILE: List[tuple] = []   # (launches, total ms, algorithmic bytes/launch) of k_sweep per call when args.engine_profile
+
+
 def _require_loader(x, name) -> FeatureLoader:
     if not isinstance(x, FeatureLoader):
         raise TypeError(f"dataloaders['{name}'] must be a mfas_amd.FeatureLoader over a HIP-resident FeatureTable; "
@@ -300,8 +303,12 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
             print("Now training: ")
             for i in mine:
                 print(confs[i])
+        if getattr(args, "engine_profile", False):
+            pop.set_profiling(True)
         stats, status = pop.train(train_l.table, dev_l.table, E, etas, order=order,
                                   snapshot_best=bool(return_model))
+        if getattr(args, "engine_profile", False):
+            PROFILE.append(pop.sweep_profile())
         for j, i in enumerate(mine):
             if getattr(args, "verbose", False):
                 for e in range(E):
