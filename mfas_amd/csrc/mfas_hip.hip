@@ -259,6 +259,8 @@ struct SweepArgs {
 #define STEP_NW 8
 #define STEP_THREADS (STEP_NW * 64)
 
+#define SWEEP_U 2   // tiles of W/m/v in flight per wave (x3 planes); 4 spills at the 128-VGPR budget, no gain
+
 template <int MB, bool NT>
 __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, float* lds) {
     const SegDesc d = a.desc[bid];
@@ -320,11 +322,11 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, fl
         f32x4 yacc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int kbb = kb0; kbb < nkb; kbb += 4 * kbs) {
-            // request the W/m/v tiles of up to 4 k-blocks before any is consumed
-            f32x4 w4[4], m4[4], v4[4];
+        for (int kbb = kb0; kbb < nkb; kbb += SWEEP_U * kbs) {
+            // request the W/m/v tiles of SWEEP_U k-blocks before any is consumed
+            f32x4 w4[SWEEP_U], m4[SWEEP_U], v4[SWEEP_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SWEEP_U; ++u) {
                 const int kb = kbb + u * kbs;
                 if (kb < nkb) {
                     const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
@@ -340,7 +342,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, fl
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SWEEP_U; ++u) {
                 const int kb = kbb + u * kbs;
                 if (kb < nkb) {
                     const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
@@ -1475,7 +1477,10 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(hipMemcpy(p->d_cands, p->cands.data(), sizeof(CandDev) * K, hipMemcpyHostToDevice));
     CREATE_CHK(hipMemcpy(p->d_descs, p->descs.data(), sizeof(SegDesc) * p->descs.size(), hipMemcpyHostToDevice));
     {   // candidate groups: two halves balanced by work (descriptor columns), contiguous ranges
-        const int ngroups = (K >= 2 && !getenv("MFAS_ONE_GROUP")) ? 2 : 1;
+        // Two groups (chain of one hidden under the sweep of the other) pay off once a group's sweep outlasts the
+        // ~50 us chain, i.e. from ~12 candidates per group; smaller populations run chain and sweep back to back.
+        int ngroups = K >= 24 ? 2 : 1;
+        if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
         int split = K;
         if (ngroups == 2) {
             double tot = 0, run = 0;

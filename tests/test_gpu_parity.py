@@ -289,6 +289,13 @@ def test_lockstep_independence_and_determinism(dev):
         return out
 
     a = run([0, 1, 2, 3, 4], 0)
+    import os
+    os.environ["MFAS_GROUPS"] = "2"       # fused two-group schedule (chain of one group under the other's sweep)
+    try:
+        f = run([0, 1, 2, 3, 4], 0)
+    finally:
+        del os.environ["MFAS_GROUPS"]
+    assert f == a                         # scheduling must not change a single bit
     b = run([4, 2, 0], 0)
     c = run([0, 1, 2, 3, 4], 0)
     for i in (0, 2, 4):
