@@ -131,6 +131,61 @@ class FeatureTable:
         sl = torch.from_numpy(table["slogit"]).to(device) if "slogit" in table else None
         return cls(taps, lab, vl, sl)
 
+    # ---- on-disk format: one .npy per tap; bf16 stored as its uint16 bit pattern
+    def save(self, directory: str, split: str):
+        import os
+        os.makedirs(directory, exist_ok=True)
+        for k, v in self.taps.items():
+            a = v.cpu()
+            if a.dtype == torch.bfloat16:
+                np.save(os.path.join(directory, f"{split}_{k}.bf16.npy"), a.view(torch.int16).numpy().view(np.uint16))
+            else:
+                np.save(os.path.join(directory, f"{split}_{k}.npy"), a.numpy())
+        np.save(os.path.join(directory, f"{split}_label.npy"), self.label.cpu().numpy())
+        if self.vlogit is not None:
+            np.save(os.path.join(directory, f"{split}_vlogit.npy"), self.vlogit.cpu().numpy())
+            np.save(os.path.join(directory, f"{split}_slogit.npy"), self.slogit.cpu().numpy())
+
+    @classmethod
+    def load(cls, directory: str, split: str, device) -> "FeatureTable":
+        import os
+        taps = {}
+        for k in TAPS:
+            p16 = os.path.join(directory, f"{split}_{k}.bf16.npy")
+            p = os.path.join(directory, f"{split}_{k}.npy")
+            if os.path.exists(p16):
+                taps[k] = torch.from_numpy(np.load(p16).view(np.int16)).view(torch.bfloat16).to(device)
+            elif os.path.exists(p):
+                taps[k] = torch.from_numpy(np.load(p)).to(device)
+        if not taps:
+            raise FileNotFoundError(f"no '{split}_<tap>.npy' feature files under {directory}")
+        lab = torch.from_numpy(np.load(os.path.join(directory, f"{split}_label.npy")).astype(np.int32)).to(device)
+        vl = sl = None
+        if os.path.exists(os.path.join(directory, f"{split}_vlogit.npy")):
+            vl = torch.from_numpy(np.load(os.path.join(directory, f"{split}_vlogit.npy"))).to(device)
+            sl = torch.from_numpy(np.load(os.path.join(directory, f"{split}_slogit.npy"))).to(device)
+        return cls(taps, lab, vl, sl)
+
+    @classmethod
+    def synthetic(cls, N: int, seed: int, device, dtype=torch.bfloat16, snr=0.15, C=60, with_logits=False,
+                  s_sizes=S_SIZES, v_sizes=V_SIZES, mu_seed=123) -> "FeatureTable":
+        """Planted-signal NTU-shaped taps x = relu(snr*mu[label] + eps) generated on the device."""
+        g = torch.Generator(device=device)
+        g.manual_seed(mu_seed)
+        mus = {}
+        for name, sizes in (("s", s_sizes), ("v", v_sizes)):
+            for j, w in enumerate(sizes):
+                mus[f"{name}{j}"] = torch.randn(C, w, generator=g, device=device)
+        mul = [torch.randn(C, C, generator=g, device=device) for _ in range(2)]
+        g.manual_seed(seed)
+        label = torch.randint(0, C, (N,), generator=g, device=device)
+        taps = {k: torch.relu(snr * mu[label] + torch.randn(N, mu.shape[1], generator=g, device=device)).to(dtype)
+                for k, mu in mus.items()}
+        vl = sl = None
+        if with_logits:
+            vl, sl = [0.5 * m[label] + torch.randn(N, C, generator=g, device=device) for m in mul]
+        return cls(taps, label.to(torch.int32), vl, sl)
+
     def to_c(self) -> _lib.mfas_table:
         t = _lib.mfas_table()
         some = next(iter(self.taps.values())).data_ptr()

@@ -1,0 +1,124 @@
+"""Search drivers: own, importable counterpart of /root/reference/models/searchable.py (which cannot be imported as
+shipped: it pulls `models.aux.scheduler`).
+
+ModelSearcher._epnas :48-137 (sequential model-based search with an LSTM surrogate and temperature sampling),
+._randsearch :139-174, NTUSearcher :233-260.  The inner candidate training is the HIP engine
+(mfas_amd.train_sampled_models); data are HBM-resident feature tables instead of raw-video DataLoaders.
+"""
+import numpy as np
+import torch
+import torch.optim as op
+
+from .. import ntu_searchable as ntu
+from ..engine import FeatureLoader
+from . import surrogate as surr
+from . import tools
+
+
+class ModelSearcher:
+    def __init__(self, args):
+        self.args = args
+
+    def search(self):
+        pass
+
+    def _epnas(self, model_type, surrogate_dict, dataloaders, dataset_searchmethods, device):
+        a = self.args
+        surrogate, s_crite = surrogate_dict["model"], surrogate_dict["criterion"]
+        s_data = surr.SurrogateDataloader()
+        s_optim = op.Adam(surrogate.parameters(), lr=a.lr_surrogate)
+        train_sampled_models = dataset_searchmethods["train_sampled_fun"]
+        get_layer_confs = dataset_searchmethods["get_layer_confs"]
+        temperature = a.initial_temperature
+        sampled_k_confs = []
+        shared_weights = dict()
+        for si in range(a.search_iterations):
+            if a.verbose:
+                print(50 * "=")
+                print("Search iteration {}/{} ".format(si, a.search_iterations))
+            for pi in range(a.max_progression_levels):
+                if a.verbose:
+                    print(25 * "-")
+                    print("Progressive step {}/{} ".format(pi, a.max_progression_levels))
+                all_confs = tools.merge_unfolded_with_sampled(sampled_k_confs, get_layer_confs(pi), pi)
+                first = si + pi == 0
+                if first:   # very first step: every single-layer conf is really trained (:87-93)
+                    all_accs = train_sampled_models(all_confs, model_type, dataloaders, a, device,
+                                                    state_dict=shared_weights)
+                    tools.update_surrogate_dataloader(s_data, all_confs, all_accs)
+                    tools.train_surrogate(surrogate, s_data, s_optim, s_crite, a, device)
+                    if a.verbose:
+                        print("Trained architectures: ")
+                        print(list(zip(all_confs, all_accs)))
+                else:       # afterwards the surrogate ranks the unfolded candidates (:98-102)
+                    all_accs = tools.predict_accuracies_with_surrogate(all_confs, surrogate, device)
+                    if a.verbose:
+                        print("Predicted accuracies: ")
+                        print(list(zip(all_confs, all_accs)))
+                sampled_k_confs = tools.sample_k_configurations(all_confs, all_accs, a.num_samples, temperature)
+                if first:
+                    if a.verbose:
+                        est = tools.predict_accuracies_with_surrogate(all_confs, surrogate, device)
+                        print("Error on accuracies = {}".format(np.abs(np.array(est) - np.array(all_accs))))
+                else:       # the K sampled ones are trained for real and fed back to the surrogate (:118-124)
+                    sampled_k_accs = train_sampled_models(sampled_k_confs, model_type, dataloaders, a, device,
+                                                          state_dict=shared_weights)
+                    tools.update_surrogate_dataloader(s_data, sampled_k_confs, sampled_k_accs)
+                    err = tools.train_surrogate(surrogate, s_data, s_optim, s_crite, a, device)
+                    if a.verbose:
+                        print("Trained architectures: ")
+                        print(list(zip(sampled_k_confs, sampled_k_accs)))
+                        print("with surrogate error: {}".format(err))
+                # NB the reference indexes the schedule with si*search_iterations (not *max_progression_levels), :132
+                temperature = tools.compute_temperature(si * a.search_iterations + pi, a)
+                if a.verbose:
+                    print("Temperature is being set to {}".format(temperature))
+        return s_data
+
+    def _randsearch(self, model_type, dataloaders, dataset_searchmethods, device):
+        a = self.args
+        s_data = surr.SurrogateDataloader()
+        train_sampled_models = dataset_searchmethods["train_sampled_fun"]
+        get_layer_confs = dataset_searchmethods["get_layer_confs"]
+        shared_weights = dict()
+        for si in range(a.search_iterations * a.max_progression_levels):
+            if a.verbose:
+                print(50 * "=")
+                print("Random Search iteration {}/{} ".format(si, a.search_iterations * a.max_progression_levels))
+            confs = tools.sample_k_configurations_directly(a.num_samples, a.max_progression_levels, get_layer_confs)
+            accs = train_sampled_models(confs, model_type, dataloaders, a, device, state_dict=shared_weights)
+            tools.update_surrogate_dataloader(s_data, confs, accs)
+            if a.verbose:
+                print("Trained architectures: ")
+                print(list(zip(confs, accs)))
+        return s_data
+
+
+class NTUSearcher(ModelSearcher):
+    """models/searchable.py:233-260 on feature tables: `tables` = {'train': FeatureTable ('trainexp' split),
+    'dev': FeatureTable}; both loaders shuffle like the reference's DataLoaders (:248)."""
+
+    def __init__(self, args, device, tables):
+        super().__init__(args)
+        self.device = device
+        self.dataloaders = {x: FeatureLoader(tables[x], args.batchsize, shuffle=True) for x in ("train", "dev")}
+
+    def search(self, surrogate_device="cpu"):
+        surrogate = surr.SimpleRecurrentSurrogate(100, 3, 100).to(surrogate_device)
+        surrogate_dict = {"model": surrogate, "criterion": torch.nn.MSELoss()}
+        methods = {"train_sampled_fun": ntu.train_sampled_models,
+                   "get_layer_confs": ntu.get_possible_layer_configurations}
+        # the (81k-parameter) surrogate lives where the caller wants it; the candidates train on self.device
+        if str(surrogate_device) != str(self.device):
+            return self._epnas_split(surrogate_dict, methods, self.device, surrogate_device)
+        return self._epnas(ntu.Searchable_Skeleton_Image_Net, surrogate_dict, self.dataloaders, methods, self.device)
+
+    def _epnas_split(self, surrogate_dict, methods, train_device, surrogate_device):
+        """_epnas with the candidates on `train_device` and the (tiny) surrogate on `surrogate_device`."""
+        inner = methods["train_sampled_fun"]
+
+        def train_on_gpu(confs, model_type, dataloaders, args, device, **kw):
+            return inner(confs, model_type, dataloaders, args, train_device, **kw)
+
+        m = dict(methods, train_sampled_fun=train_on_gpu)
+        return self._epnas(ntu.Searchable_Skeleton_Image_Net, surrogate_dict, self.dataloaders, m, surrogate_device)

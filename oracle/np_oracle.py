@@ -524,3 +524,13 @@ def sample_view(arr: np.ndarray, max_n: int = 1500) -> np.ndarray:
     flat = np.asarray(arr).ravel()
     stride = max(1, -(-flat.size // max_n))
     return flat[::stride].copy()
+
+
+def fake_accuracy(conf) -> float:
+    """Deterministic stand-in for a trained candidate's accuracy (controller tests only)."""
+    c = np.asarray(conf, np.int64).reshape(-1, 3)
+    h = 17
+    for row in c:
+        for v in row:
+            h = (h * 31 + int(v) + 7) % 1000003
+    return 0.25 + 0.7 * (h % 1000) / 1000.0

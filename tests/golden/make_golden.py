@@ -390,8 +390,8 @@ def g10():
                 ske = D({k: self.t[k][sl] for k in ("s0", "s1", "s2", "s3", "slogit")})
                 yield {"rgb": rgb, "ske": ske, "label": self.t["label"][sl]}
 
-    for tag, snr, R, bn, confs, nseed in (("A", 1.0, 16, False, [CONFS["c4"], CONFS["l1"], CONFS["l2"]], 12),
-                                          ("B", 0.15, 128, True, [CONFS["c4"]], 8)):
+    for tag, snr, R, bn, confs, nseed in (("A", 1.0, 16, False, [CONFS["c4"], CONFS["l1"], CONFS["l2"]], 32),
+                                          ("B", 0.15, 128, True, [CONFS["c4"]], 64)):
         ttr, tdv = table(N, 1, with_logits=False, snr=snr), table(Nd, 2, with_logits=False, snr=snr)
         out[tag + "/meta"] = np.array([N, Nd, snr, R, 16, 3, int(bn), 0.5])  # N,Ndev,snr,R,B,epochs,bn,drpt
         args = mkargs(inner_representation_size=R, batchnorm=bn, drpt=0.5, epochs=3, batchsize=16)
@@ -408,7 +408,62 @@ def g10():
     save("g10_stochastic.npz", **out)
 
 
+# ------------------------------------------------------------------ G9 controller run (next#1)
+def g9():
+    """The reference's ModelSearcher._epnas / _randsearch driven by a fake trainer (acc = np_oracle.fake_accuracy).
+    models.searchable needs import stubs for torchvision / cv2 and the alias models.aux -> models.auxiliary (D6)."""
+    import random
+    import types
+    for name in ("torchvision", "torchvision.transforms", "torchvision.datasets", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import models.auxiliary as aux_pkg
+    sys.modules.setdefault("models.aux", aux_pkg)
+    sys.modules.setdefault("models.aux.scheduler", sc)
+    import models.searchable as S
+    import models.search.surrogate as rsurr
+    out = {}
+    for tag, iters, levels, K in (("a", 2, 3, 5), ("b", 3, 4, 6)):
+        args = SimpleNamespace(search_iterations=iters, max_progression_levels=levels, num_samples=K,
+                               initial_temperature=10.0, final_temperature=0.2, temperature_decay=4.0,
+                               lr_surrogate=0.001, epochs_surrogate=8, verbose=False)
+        calls = []
+
+        def fake_train(confs, model_type, dataloaders, a, device, state_dict=None):
+            calls.append([np.array(c) for c in confs])
+            return [O.fake_accuracy(c) for c in confs]
+
+        np.random.seed(3)
+        torch.manual_seed(3)
+        random.seed(3)
+        surrogate = rsurr.SimpleRecurrentSurrogate(100, 3, 100)
+        searcher = S.ModelSearcher(args)
+        s_data = searcher._epnas(None, {"model": surrogate, "criterion": torch.nn.MSELoss()}, None,
+                                 {"train_sampled_fun": fake_train,
+                                  "get_layer_confs": ntu.get_possible_layer_configurations}, "cpu")
+        out[tag + "/call_sizes"] = np.array([len(c) for c in calls])
+        flat = [np.concatenate([c.reshape(-1), [-1]]) for call in calls for c in call]
+        out[tag + "/calls_flat"] = np.concatenate(flat)
+        confs, accs, _ = s_data.get_k_best(5)
+        out[tag + "/best_accs"] = np.sort(np.array(accs))
+        out[tag + "/final_pred"] = np.array([surrogate.eval_model(np.array(CONFS["c4"]), "cpu"),
+                                             surrogate.eval_model(np.array(CONFS["l2"]), "cpu")])
+    # random search
+    args = SimpleNamespace(search_iterations=2, max_progression_levels=3, num_samples=4, verbose=False)
+    calls = []
+
+    def fake_train2(confs, model_type, dataloaders, a, device, state_dict=None):
+        calls.append([np.array(c) for c in confs])
+        return [O.fake_accuracy(c) for c in confs]
+
+    np.random.seed(5)
+    random.seed(5)
+    S.ModelSearcher(args)._randsearch(None, None, {"train_sampled_fun": fake_train2,
+                                                   "get_layer_confs": ntu.get_possible_layer_configurations}, "cpu")
+    out["r/calls_flat"] = np.concatenate([np.concatenate([c.reshape(-1), [-1]]) for call in calls for c in call])
+    save("g9_controller_run.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g10"]
+    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

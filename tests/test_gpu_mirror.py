@@ -1,0 +1,159 @@
+"""GPU tests of the Python mirror of the reference interface (mfas_amd.train_sampled_models & friends) and of the
+stochastic (dropout + shuffle) parity gate against the reference's own seed statistics (G10)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from oracle import np_oracle as O
+from tests.helpers import CONFS, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs a HIP device"
+    return torch.device("cuda:0")
+
+
+def mkargs(**kw):
+    a = dict(vid_len=(8, 32), num_outputs=60, drpt=0.5, inner_representation_size=16, batchnorm=False,
+             alphas=False, multitask=False, weightsharing=False, batchsize=16, eta_max=1e-3, eta_min=1e-6,
+             Ti=1, Tm=2, use_dataparallel=False, verbose=False, epochs=3)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def loaders(ttr, tdv, dev, B, shuffle=True, dtype=torch.float32):
+    import mfas_amd as M
+    return {"train": M.FeatureLoader(M.FeatureTable.from_numpy(ttr, dev, dtype), B, shuffle=shuffle),
+            "dev": M.FeatureLoader(M.FeatureTable.from_numpy(tdv, dev, dtype), B, shuffle=False),
+            "test": M.FeatureLoader(M.FeatureTable.from_numpy(tdv, dev, dtype), B, shuffle=False)}
+
+
+def test_train_sampled_models_signature_and_determinism(dev):
+    import mfas_amd as M
+    args = mkargs(batchnorm=True, drpt=0.0, epochs=3)
+    ttr, tdv = O.synth_table(256, 31, snr=0.5), O.synth_table(128, 32, snr=0.5)
+    ld = loaders(ttr, tdv, dev, 16, shuffle=False)
+    confs = [np.array(CONFS[c]) for c in ("l1", "l2", "l3", "c4")]
+    torch.manual_seed(7)
+    a = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev, state_dict=dict())
+    torch.manual_seed(7)
+    b = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev)
+    assert a == b and len(a) == 4 and all(isinstance(x, float) and 0.0 <= x <= 1.0 for x in a)
+    assert np.array(a).shape == (4,) and max(a[0], a[1]) >= a[0]           # what tools.py / surrogate.py do with them
+    # device-side init path (bench) trains too
+    args2 = mkargs(batchnorm=True, drpt=0.0, epochs=3, engine_init="device")
+    torch.manual_seed(7)
+    c = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args2, dev)
+    assert len(c) == 4 and min(c) > 0.2
+    with pytest.raises(TypeError):
+        M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev, preaccuracies=[0.1] * 4)
+    with pytest.raises(TypeError):
+        M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, {"train": [1], "dev": [2]}, args, dev)
+
+
+def test_init_from_module_matches_oracle_run(dev):
+    """The module's torch-initialised parameters are what the engine trains: same params into the oracle ->
+    same dev counts."""
+    import mfas_amd as M
+    args = mkargs(batchnorm=True, drpt=0.0, epochs=2)
+    ttr, tdv = O.synth_table(128, 41, snr=0.5), O.synth_table(96, 42, snr=0.5)
+    ld = loaders(ttr, tdv, dev, 16, shuffle=False)
+    conf = np.array(CONFS["l2"])
+    torch.manual_seed(3)
+    model = M.Searchable_Skeleton_Image_Net(args, conf)
+    sd0 = {k: v.detach().numpy().copy() for k, v in model.state_dict().items() if "num_batches" not in k}
+    opt = torch.optim.Adam(model.central_params(), lr=args.eta_max, weight_decay=1e-4)
+    sched = M.LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, 128 / 16)
+    acc = M.train_ntu_track_acc(model, torch.nn.CrossEntropyLoss(), opt, sched, ld, {"train": 128, "dev": 96},
+                                device=dev, num_epochs=2)
+    ohp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=2)
+    hist = []
+    want = O.train_candidate(conf, ohp, {k: v.copy() for k, v in sd0.items()}, ttr, tdv, history=hist)
+    assert abs(float(acc) - want) <= 1.0 / 96 + 1e-9
+    assert acc.dtype == torch.float64 and not model.training
+    # best-epoch weights were restored into the module: test accuracy == best dev accuracy (same table)
+    tacc = M.test_ntu_track_acc(model, ld, {"test": 96}, device=dev)
+    assert abs(float(tacc) - float(acc)) < 1e-12
+    # eval-mode Module.forward runs on the engine and agrees with the oracle on the restored weights
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if "num_batches" not in k}
+    feats = {k: torch.from_numpy(tdv[k][:32]).to(dev) for k in tdv if k != "label"}
+    out = model(({k: v for k, v in feats.items() if k[0] == "v"}, {k: v for k, v in feats.items() if k[0] == "s"}))
+    ref, _ = O.forward(sd, conf, ohp, {k: tdv[k][:32] for k in tdv if k != "label"}, False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
+
+
+def test_return_model_and_weightsharing(dev):
+    import mfas_amd as M
+    args = mkargs(batchnorm=True, drpt=0.0, epochs=2)
+    ttr, tdv = O.synth_table(128, 41, snr=0.5), O.synth_table(96, 42, snr=0.5)
+    ld = loaders(ttr, tdv, dev, 16)
+    confs = [np.array(CONFS["l1"]), np.array(CONFS["l2"]), np.array(CONFS["l3"])]
+    torch.manual_seed(1)
+    accs, models = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev, return_model=[0, 2])
+    assert len(accs) == 2 and len(models) == 2
+    for a, m in zip(accs, models):
+        assert abs(float(M.test_ntu_track_acc(m, ld, {"test": 96}, device=dev)) - a) < 1e-12
+        assert int(m.fusion_layers[0][2].num_batches_tracked) == 2 * 8
+    # weight sharing: serial, cells published under "{idx}.L_{in}_{out}.A_{act}"
+    args_ws = mkargs(batchnorm=True, drpt=0.0, epochs=1, weightsharing=True)
+    shared = dict()
+    torch.manual_seed(1)
+    accs = M.train_sampled_models([confs[0], confs[0]], M.Searchable_Skeleton_Image_Net, ld, args_ws, dev,
+                                  state_dict=shared)
+    assert "0.L_640_16.A_relu" in shared and len(accs) == 2
+    assert accs[1] >= accs[0] - 0.05     # the second copy starts from the first one's trained cell
+
+
+def test_stochastic_parity_vs_reference_seed_statistics(dev):
+    """Parity gate, stochastic mode: dropout + shuffle streams cannot match torch's, so the MEAN best
+    dev accuracy over many engine seeds must sit inside the reference's own seed distribution (G10: mean +- 3 s.e.
+    of the reference sample, plus 0.1 % top-1)."""
+    import mfas_amd as M
+    g = golden("g10_stochastic.npz")
+    for tag in ("B", "A"):
+        N, Nd, snr, R, B, E, bn, drpt = g[tag + "/meta"]
+        ref = g[tag + "/accs"]                       # (seeds, confs)
+        ttr, tdv = O.synth_table(int(N), 1, snr=float(snr)), O.synth_table(int(Nd), 2, snr=float(snr))
+        ld = loaders(ttr, tdv, dev, int(B), shuffle=True)
+        args = mkargs(inner_representation_size=int(R), batchnorm=bool(bn), drpt=float(drpt), epochs=int(E),
+                      batchsize=int(B), engine_init="device")
+        nconf = ref.shape[1]
+        reps = 96
+        confs = [g[f"{tag}/conf{i}"] for i in range(nconf)] * reps
+        torch.manual_seed(11)
+        accs = np.array(M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev)).reshape(reps, nconf)
+        for i in range(nconf):
+            se_ref = ref[:, i].std(ddof=1) / np.sqrt(ref.shape[0])
+            se_eng = accs[:, i].std(ddof=1) / np.sqrt(reps)
+            tol = 3.0 * np.hypot(se_ref, se_eng) + 0.001
+            assert abs(accs[:, i].mean() - ref[:, i].mean()) <= tol, (tag, i, accs[:, i].mean(), ref[:, i].mean(), tol)
+            # the spread must be of the reference's order too (neither collapsed nor blown up)
+            assert 0.4 * ref[:, i].std(ddof=1) <= accs[:, i].std(ddof=1) <= 2.5 * ref[:, i].std(ddof=1), (tag, i)
+
+
+def test_cli_entry_points_and_table_io(dev, tmp_path):
+    """main_searchable_ntu / main_found_ntu counterparts run end to end on small synthetic tables; the on-disk
+    feature-table format round-trips bit-exactly."""
+    import mfas_amd as M
+    import main_found_ntu
+    import main_searchable_ntu
+    t = M.FeatureTable.synthetic(96, 5, dev, torch.bfloat16, snr=0.5, with_logits=True)
+    t.save(str(tmp_path), "train")
+    u = M.FeatureTable.load(str(tmp_path), "train", dev)
+    assert u.dtype == torch.bfloat16 and torch.equal(u.label, t.label)
+    for k in t.taps:
+        assert torch.equal(u.taps[k].view(torch.int16), t.taps[k].view(torch.int16))
+    assert torch.equal(u.vlogit, t.vlogit)
+    data = main_searchable_ntu.main(["--synthetic", "640", "320", "--epochs", "1", "--search_iterations", "1",
+                                     "--max_fusions", "2", "--num_samples", "4", "--epochs_surrogate", "3",
+                                     "--batchnorm", "--no-verbose", "--engine_init", "device"])
+    confs, accs, _ = data.get_k_best(3)
+    assert len(confs) == 3 and all(0.0 <= a <= 1.0 for a in accs)
+    acc = main_found_ntu.main(["--synthetic", "640", "320", "320", "--conf", "4", "--inner_representation_size", "32",
+                               "--batchnorm", "--epochs", "2", "--batchsize", "16", "--no-verbose"])
+    assert 0.0 <= float(acc) <= 1.0
