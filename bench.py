@@ -53,7 +53,7 @@ def cpu_baseline(train, dev, args, budget_s=20.0):
     """The numpy oracle (a port of the reference step sequence, oracle/np_oracle.py) timed on this box's host
     cores on a bounded sample of the same workload; extrapolated linearly to one full candidate."""
     from oracle import np_oracle as O
-    ohp = O.Hyper(R=args.R, B=args.batch, bn=True, drpt=args.drpt, epochs=1)
+    ohp = O.Hyper(R=args.R, B=args.batch, bn=not args.no_bn, drpt=args.drpt, epochs=1)
     n_tr = min(len(train), 1600)
     n_dv = min(len(dev), 1600)
     ttr = {k: v[:n_tr].float().cpu().numpy() for k, v in train.taps.items()}
@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
     ap.add_argument("--chunk-cols", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bn", action="store_true", help="search-script defaults: no BatchNorm")
+    ap.add_argument("--mixed-confs", action="store_true", help="population of sampled L=1..4 confs instead of conf 4")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,11 +134,15 @@ def main():
     train, dev = synth_tables(a.n_train, a.n_dev, device, dtype)
     loaders = {"train": M.FeatureLoader(train, a.batch, shuffle=True), "dev": M.FeatureLoader(dev, a.batch, shuffle=False)}
     args = SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=a.drpt, inner_representation_size=a.R,
-                           batchnorm=True, alphas=False, multitask=False, weightsharing=False, batchsize=a.batch,
+                           batchnorm=not a.no_bn, alphas=False, multitask=False, weightsharing=False, batchsize=a.batch,
                            eta_max=1e-3, eta_min=1e-6, Ti=1, Tm=2, use_dataparallel=False, verbose=False,
                            epochs=a.epochs, engine_init="device", engine_profile=True,
                            engine_chunk_cols=a.chunk_cols)
     confs = [np.array(CONF4) for _ in range(a.pop * world)]
+    if a.mixed_confs:
+        rng = np.random.default_rng(0)
+        confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1)
+                 for L in rng.integers(1, 5, a.pop * world)]
     torch.manual_seed(0)
 
     def barrier():

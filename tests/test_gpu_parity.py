@@ -14,7 +14,7 @@ import pytest
 
 torch = pytest.importorskip("torch")
 from oracle import np_oracle as O
-from tests.helpers import CONFS, engine_hyper, etas_for, frac_bad, golden, oracle_steps, rel_err
+from tests.helpers import CONFS, engine_hyper, etas_for, frac_bad, golden, oracle_steps, rel_err  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -319,4 +319,46 @@ def test_error_behaviour(dev):
     t17 = O.synth_table(17, 1)          # final train batch of size 1 with BN: the reference raises
     with pytest.raises(RuntimeError, match="size 1"):
         pop.train(table(t17, dev), table(t17, dev), 1, etas_for(ohp, 17))
+    pop.close()
+
+
+def test_baseline_config0_found_defaults(dev):
+    """BASELINE configs[0]: main_found_ntu.py --conf 0, batch 16, found-script defaults (R=256, drpt 0.4, multitask on,
+    no BN), head-only phase-1 semantics — engine vs oracle on identical tables (shared dropout stream)."""
+    ohp = O.Hyper(R=256, B=16, bn=False, drpt=0.4, multitask=True, epochs=2, Ti=5)
+    conf = np.array(CONFS["c0"])
+    ttr = O.synth_table(160, 61, snr=0.5, with_logits=True)
+    tdv = O.synth_table(96, 62, snr=0.5, with_logits=True)
+    pop = mk_pop(ohp, [conf], dev, drop_seeds=[5])
+    pop.set_state_dict(0, O.init_params(conf, ohp, 31))
+    stats, status = pop.train(table(ttr, dev), table(tdv, dev), 2, etas_for(ohp, 160))
+    hist = []
+    O.train_candidate(conf, ohp, O.init_params(conf, ohp, 31), ttr, tdv, seed=5, history=hist)
+    for e in range(2):
+        assert abs(stats["train_loss_sum"][0, e] / 160 - hist[e]["train_loss"]) < 2e-3
+        assert abs(stats["train_corrects"][0, e] - round(hist[e]["train_acc"] * 160)) <= 2
+        assert abs(stats["dev_corrects"][0, e] - hist[e]["dev_corrects"]) <= 1
+    assert not status.any()
+    pop.close()
+
+
+def test_odd_sizes_R24_B20(dev):
+    """R not a multiple of 16 (padded row/column blocks must stay inert) with a ragged B=20 stream."""
+    ohp = O.Hyper(R=24, B=20, bn=True, drpt=0.3, epochs=2)
+    conf = np.array(CONFS["l3"])
+    ttr, tdv = O.synth_table(130, 71, snr=0.5), O.synth_table(70, 72, snr=0.5)
+    pop = mk_pop(ohp, [conf], dev, drop_seeds=[9])
+    pop.set_state_dict(0, O.init_params(conf, ohp, 3))
+    stats, _ = pop.train(table(ttr, dev), table(tdv, dev), 2, etas_for(ohp, 130))
+    hist = []
+    params = O.init_params(conf, ohp, 3)
+    O.train_candidate(conf, ohp, params, ttr, tdv, seed=9, history=hist)
+    for e in range(2):
+        assert abs(stats["train_loss_sum"][0, e] / 130 - hist[e]["train_loss"]) < 2e-3
+        assert abs(stats["dev_corrects"][0, e] - hist[e]["dev_corrects"]) <= 1
+    got = pop.get_state_dict(0)
+    for key, v in params.items():
+        if key.startswith("alphas"):
+            continue
+        assert frac_bad(got[key].numpy(), v, 2e-3, 2e-5) <= 0.05, key
     pop.close()
