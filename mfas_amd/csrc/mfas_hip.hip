@@ -1299,15 +1299,23 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     for (int j = 0; j < 4; ++j) { g.sw[j] = hp->s_sizes[j]; g.vw[j] = hp->v_sizes[j]; }
     const int vec_size = (g.vec_head + g.Cp + 63) & ~63;
 
-    // ---- column chunk per workgroup: enough workgroups to fill 256 CUs several times over
+    // ---- column chunk per workgroup.  A workgroup should stream >= ~64 tiles (amortises staging / reduction and
+    // keeps the number of partial-sum chunks the chain has to reduce small), the launch should still have a few
+    // hundred workgroups, and x_t / x_{t+1} for the chunk must fit the LDS budget.
     int target = chunk_cols;
     if (target <= 0) {
-        double totF = 0;
+        double tot_cols = 0;
         for (int k = 0; k < K; ++k)
             for (int i = 0; i < n_cells[k]; ++i)
-                totF += hp->s_sizes[confs[(k * 4 + i) * 3] & 3] + hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 3];
-        target = 256;
-        while (target > 64 && totF / target < 1536.0) target >>= 1;
+                tot_cols += hp->s_sizes[confs[(k * 4 + i) * 3] & 3] + hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 3];
+        int lds_max = 64;                                   // largest power of two with Bp*(2cc+20)*4 <= 72 KiB
+        while ((size_t)g.Bp * (4 * lds_max + 20) * 4 <= 72 * 1024 && lds_max < 1024) lds_max <<= 1;
+        target = 64;
+        while (target * g.nrb < 64 * 16 && target < lds_max) target <<= 1;      // >= 64 tiles per workgroup
+        while (target > 64 && tot_cols / target < 320.0) target >>= 1;           // ... but keep >= ~320 workgroups
+        // R >= 128, measured on MI355X: 64-column chunks (finer, better-balanced workgroups) win once
+        // the chain is hidden under the other group's sweep (K >= 24); below that fewer partial chunks matter more
+        if (g.nrb >= 8) target = std::min(target, K >= 24 ? 64 : 128);
     }
     target = std::max(16, (target / 16) * 16);
     p->cands.resize(K);
