@@ -171,6 +171,13 @@ def main():
         bytes_per_launch = NS.PROFILE[-1][2] if NS.PROFILE else 0.0
         achieved = bytes_per_launch / (ms / n_launch * 1e-3) / 1e9 if n_launch else None
         total = a.pop * world * a.steps
+        traffic = None      # HBM bytes per launch from the committed PMC passes of this same workload (profiles/)
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp) and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1:
+            try:
+                traffic = json.load(open(tp))["per_launch"]["total_bytes"]
+            except Exception:
+                traffic = None
         line = {
             "metric": "candidate-archs trained/sec (NTU inner loop)", "value": total / dt, "unit": "candidates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -182,7 +189,7 @@ def main():
                        "mean_best_dev_acc": float(np.mean(accs))},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (fused dW + Adam + next-step forward)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "launches": n_launch, "avg_launch_us": (ms / n_launch * 1e3) if n_launch else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
