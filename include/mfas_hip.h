@@ -39,6 +39,12 @@ typedef struct mfas_hyper {
     double wd, beta1, beta2, adam_eps, bn_eps, bn_momentum;
     int32_t s_sizes[4]; /* skeleton tap widths (ntu_searchable.py:291) */
     int32_t v_sizes[4]; /* visual tap widths   (ntu_searchable.py:292) */
+    /* Head loss / dev metric.  0: CrossEntropyLoss + top-1 accuracy (NTU, ntu_searchable.py:31).
+     * 1: multi-label WeightedCrossEntropyWithLogits (models/central/mm_imdb.py:655-673) + F1 'samples' of
+     *    sigmoid(logits) > f1_threshold (models/search/train_searchable/mmimdb.py:86,105). */
+    int32_t loss_mode;
+    int32_t _pad;
+    double f1_threshold; /* th_fscore, mmimdb.py:16 (0.3) */
 } mfas_hyper;
 
 /* Pooled feature table = what Visual/Skeleton.forward + GlobalPooling2D hand to the fusion net
@@ -49,7 +55,8 @@ typedef struct mfas_table {
     const void* v[4];
     const float* vlogit; /* (N, C) unimodal logits for multitask, or NULL */
     const float* slogit;
-    const int32_t* label; /* (N) in [0, C) */
+    const int32_t* label; /* (N) in [0, C); loss_mode 0 */
+    const float* multilabel; /* (N, C) 0/1 targets; loss_mode 1 (else NULL) */
     int64_t N;
     int32_t dtype; /* MFAS_DT_* of s[]/v[] */
     int32_t _pad;
@@ -59,8 +66,8 @@ typedef struct mfas_table {
 typedef struct mfas_epoch_stats {
     double train_loss_sum; /* sum over samples of the CE loss (running_loss) */
     double dev_loss_sum;
-    int64_t train_corrects; /* running_corrects */
-    int64_t dev_corrects;
+    int64_t train_corrects; /* running_corrects (loss_mode 0) */
+    int64_t dev_corrects;   /* loss_mode 0: correct predictions; loss_mode 1: round(2^32 * sum over samples of F1) */
 } mfas_epoch_stats;
 
 typedef struct mfas_population mfas_population; /* opaque; owns its device workspace */
@@ -118,6 +125,9 @@ int mfas_population_forward(mfas_population* pop, int32_t k, const mfas_table* t
 int mfas_population_sweep_profile(const mfas_population* pop, int64_t* launches, double* total_ms,
                                   double* bytes_per_launch);
 int mfas_population_set_profiling(mfas_population* pop, int32_t on);
+
+/* loss_mode 1: per-class positive weights of WeightedCrossEntropyWithLogits (HOST float[C]; default all 1). */
+int mfas_population_set_pos_weight(mfas_population* pop, const float* pos_weight);
 
 #ifdef __cplusplus
 }

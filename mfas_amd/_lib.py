@@ -17,12 +17,13 @@ class mfas_hyper(C.Structure):
                 ("alphas", C.c_int32), ("multitask", C.c_int32), ("drpt", C.c_double),
                 ("wd", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
                 ("adam_eps", C.c_double), ("bn_eps", C.c_double), ("bn_momentum", C.c_double),
-                ("s_sizes", C.c_int32 * 4), ("v_sizes", C.c_int32 * 4)]
+                ("s_sizes", C.c_int32 * 4), ("v_sizes", C.c_int32 * 4), ("loss_mode", C.c_int32),
+                ("_pad", C.c_int32), ("f1_threshold", C.c_double)]
 
 
 class mfas_table(C.Structure):
     _fields_ = [("s", C.c_void_p * 4), ("v", C.c_void_p * 4), ("vlogit", C.c_void_p),
-                ("slogit", C.c_void_p), ("label", C.c_void_p), ("N", C.c_int64),
+                ("slogit", C.c_void_p), ("label", C.c_void_p), ("multilabel", C.c_void_p), ("N", C.c_int64),
                 ("dtype", C.c_int32), ("_pad", C.c_int32)]
 
 
@@ -60,6 +61,7 @@ def lib():
     L.mfas_population_forward.argtypes = [P, C.c_int32, C.POINTER(mfas_table), C.c_int64, C.c_int64, P, P]
     L.mfas_population_sweep_profile.argtypes = [P, P, P, P]
     L.mfas_population_set_profiling.argtypes = [P, C.c_int32]
+    L.mfas_population_set_pos_weight.argtypes = [P, P]
     _lib = L
     return L
 
@@ -67,7 +69,7 @@ def lib():
 EXPORTS = ["mfas_last_error", "mfas_version", "mfas_population_create", "mfas_population_destroy",
            "mfas_population_param_count", "mfas_population_set_params", "mfas_population_get_params",
            "mfas_population_init", "mfas_population_train", "mfas_population_forward",
-           "mfas_population_sweep_profile", "mfas_population_set_profiling"]
+           "mfas_population_sweep_profile", "mfas_population_set_profiling", "mfas_population_set_pos_weight"]
 
 
 def check(rc):

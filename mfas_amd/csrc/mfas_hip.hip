@@ -109,6 +109,8 @@ struct Geo {             // geometry shared by all candidates of a population
     int32_t vec_cell_stride;   // 5*Rp + 16
     int32_t vec_head;          // offset of head bias inside the vector block
     int32_t sw[4], vw[4];      // tap widths (elements per table row)
+    int32_t loss_mode;         // 0 softmax CE + accuracy, 1 weighted BCE + F1-samples
+    float f1_th;
 };
 
 // vector block of a candidate (inside every plane): per cell [b | gamma | beta | rm | rv | alpha(16)], then bc[Cp]
@@ -430,6 +432,7 @@ struct ChainArgs {
     Geo g;
     DevStats* stats;
     int32_t* status;
+    const float* pos_w;   // loss_mode 1: per-class positive weights
 };
 
 #define CHAIN_NW STEP_NW
@@ -461,6 +464,36 @@ __device__ __forceinline__ void lds_x_times_tiles(f32x4 (&acc)[MB], const float*
                     for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w8[u][q], acc[mb]);
                 }
             }
+    }
+}
+
+// WeightedCrossEntropyWithLogits (models/central/mm_imdb.py:655-673) on the LDS logits, 4 lanes per row:
+// L = mean_{b,c}[ w_c z (-log s) + (1 - z)(-log(1 - s)) ], s = sigmoid(x);  dlogit = (-w_c z (1 - s) + (1 - z) s) / (B*C).
+// red[b] receives the row's share of the BATCH-MEAN loss times nvalid (so that sum_b red[b] = loss * batch size,
+// train_searchable/mmimdb.py:96), red[Bp + b] = 0.
+__device__ __forceinline__ void bce_rows(float* lg_l, int SC, float* red, int Bp, const int* rowidx,
+                                         const float* multilabel, const float* pos_w, int C, int Cp, int nvalid, int tid) {
+    const int b = tid >> 2, sub = tid & 3;
+    float* row = lg_l + b * SC;
+    const bool ok = b < nvalid;
+    const float* z = ok ? multilabel + (int64_t)rowidx[b] * C : nullptr;
+    float ls = 0.f;
+    const float inv = 1.0f / ((float)nvalid * (float)C);
+    for (int c = sub; c < Cp; c += 4) {
+        float dl = 0.f;
+        if (ok && c < C) {
+            const float sg = 1.0f / (1.0f + expf(-row[c]));
+            const float zz = z[c], w = pos_w[c];
+            ls += w * zz * -logf(sg) + (1.0f - zz) * -logf(1.0f - sg);
+            dl = (-w * zz * (1.0f - sg) + (1.0f - zz) * sg) * inv;
+        }
+        row[c] = dl;
+    }
+    ls += __shfl_xor(ls, 1);
+    ls += __shfl_xor(ls, 2);
+    if (sub == 0) {
+        red[b] = ls / (float)C;      // sum_b red[b] / nvalid = batch-mean loss
+        red[Bp + b] = 0.f;
     }
 }
 
@@ -499,7 +532,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
         int lab = 0;
         if (tid < nvalid) {
             const int64_t row = a.order ? (int64_t)a.order[a.pos_t + tid] : (int64_t)(a.base_t + tid);
-            lab = a.tab.label[row];
+            lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
         }
         lab_l[tid] = lab;
     }
@@ -665,7 +698,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
         }
     }
     __syncthreads();
-    if (tid < 4 * Bp) {   // 4 lanes per row: classes c = sub, sub+4, ...
+    if (g.loss_mode == 1) {
+        if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
+    } else if (tid < 4 * Bp) {   // 4 lanes per row: classes c = sub, sub+4, ...
         const int b = tid >> 2, sub = tid & 3;
         float* row = lg_l + b * SC;
         const bool ok = b < nvalid;
@@ -886,6 +921,7 @@ struct EvalArgs {
     float* logits;        // optional (nrows, C) for candidate cand0
     DevStats* stats;      // optional: dev_corr / dev_loss of stats[cand*E + epoch]
     long long* corr_out;  // optional single counter
+    const float* pos_w;   // loss_mode 1
 };
 
 #define EVAL_CE 128   // staged feature columns per pass
@@ -1034,8 +1070,24 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
     }
     if (tid < ME) {   // ME <= 64: exactly wave 0
         float loss = 0.f;
-        int corr = 0;
-        if (tid < nvalid) {
+        long long corr = 0;
+        if (tid < nvalid && g.loss_mode == 1) {
+            // F1 'samples' (sklearn f1_score(average='samples')): per row 2|P&T| / (|P|+|T|), 0 when both are empty;
+            // accumulated as 32.32 fixed point so that the sum is order-independent
+            const float* row = lg_l + tid * SC;
+            const int64_t grow = brow + tid;
+            const float* z = a.tab.multilabel + grow * C;
+            int tp = 0, np = 0, nt = 0;
+            float ls = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float sg = 1.0f / (1.0f + expf(-row[c]));
+                const bool pr = sg > g.f1_th, tr = z[c] > 0.5f;
+                tp += (pr && tr) ? 1 : 0; np += pr ? 1 : 0; nt += tr ? 1 : 0;
+                ls += a.pos_w[c] * z[c] * -logf(sg) + (1.0f - z[c]) * -logf(1.0f - sg);
+            }
+            loss = ls / (float)C;
+            corr = (np + nt) > 0 ? (long long)((((unsigned long long)(2 * tp)) << 32) / (unsigned long long)(np + nt)) : 0;
+        } else if (tid < nvalid) {
             const float* row = lg_l + tid * SC;
             const int64_t grow = brow + tid;
             const int lab = a.tab.label[grow];
@@ -1231,6 +1283,7 @@ struct mfas_population {
     int32_t* d_status = nullptr;
     uint32_t* d_seeds = nullptr;
     long long* d_corr = nullptr;
+    float* d_posw = nullptr;        // loss_mode 1: per-class positive weights (default 1)
     size_t lds_step = 0, lds_eval = 0;
     int mbe = 4, nrbw = 1;
     bool yf_in_lds = false;
@@ -1271,6 +1324,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     if (!(hp->drpt > 1e-10) && !hp->bn)   // ntu_searchable.py:274-284: `op` never assigned
         return fail(MFAS_EINVAL, "illegal cell variant: drpt < 1e-10 without batchnorm (reference: UnboundLocalError)");
     if (hp->drpt >= 1.0) return fail(MFAS_EINVAL, "drpt must be < 1");
+    if (hp->loss_mode == 1 && hp->multitask) return fail(MFAS_EINVAL, "multitask applies to the single-label head only");
     for (int j = 0; j < 4; ++j)
         if (hp->s_sizes[j] < 16 || hp->s_sizes[j] % 16 || hp->v_sizes[j] < 16 || hp->v_sizes[j] % 16)
             return fail(MFAS_EINVAL, "tap widths must be positive multiples of 16");
@@ -1297,6 +1351,8 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     g.vec_cell_stride = 5 * g.Rp + 16;
     g.vec_head = MFAS_MAX_CELLS * g.vec_cell_stride;
     for (int j = 0; j < 4; ++j) { g.sw[j] = hp->s_sizes[j]; g.vw[j] = hp->v_sizes[j]; }
+    g.loss_mode = hp->loss_mode == 1 ? 1 : 0;
+    g.f1_th = (float)hp->f1_threshold;
     const int vec_size = (g.vec_head + g.Cp + 63) & ~63;
 
     // ---- column chunk per workgroup.  A workgroup should stream >= ~64 tiles (amortises staging / reduction and
@@ -1482,6 +1538,11 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(hipMalloc(&p->d_status, sizeof(int32_t) * K));
     CREATE_CHK(hipMalloc(&p->d_seeds, sizeof(uint32_t) * K));
     CREATE_CHK(hipMalloc(&p->d_corr, sizeof(long long)));
+    {
+        std::vector<float> ones(g.Cp, 1.0f);
+        CREATE_CHK(hipMalloc(&p->d_posw, sizeof(float) * g.Cp));
+        CREATE_CHK(hipMemcpy(p->d_posw, ones.data(), sizeof(float) * g.Cp, hipMemcpyHostToDevice));
+    }
     CREATE_CHK(hipMemcpy(p->d_cands, p->cands.data(), sizeof(CandDev) * K, hipMemcpyHostToDevice));
     CREATE_CHK(hipMemcpy(p->d_descs, p->descs.data(), sizeof(SegDesc) * p->descs.size(), hipMemcpyHostToDevice));
     {   // candidate groups: two halves balanced by work (descriptor columns), contiguous ranges
@@ -1541,7 +1602,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     hipFree(p->plane); hipFree(p->wt); hipFree(p->stepbuf); hipFree(p->best);
     for (auto& gr : p->groups) hipFree(gr.d_descs);
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
-    hipFree(p->d_seeds); hipFree(p->d_corr);
+    hipFree(p->d_seeds); hipFree(p->d_corr); hipFree(p->d_posw);
     delete p;
 }
 
@@ -1597,12 +1658,13 @@ extern "C" int mfas_population_init(mfas_population* p, const uint32_t* seeds) {
 }
 
 static int check_table(const mfas_population* p, const mfas_table* t, bool need_logits) {
-    if (!t || t->N <= 0 || !t->label) return fail(MFAS_EINVAL, "table: null or empty");
+    if (!t || t->N <= 0) return fail(MFAS_EINVAL, "table: null or empty");
+    if (p->g.loss_mode == 0 && !t->label) return fail(MFAS_EINVAL, "table: labels missing");
+    if (p->g.loss_mode == 1 && !t->multilabel) return fail(MFAS_EINVAL, "table: multi-hot targets missing (loss_mode 1)");
     if (t->dtype < 0 || t->dtype > 2) return fail(MFAS_EINVAL, "table: bad dtype");
     for (int j = 0; j < 4; ++j)
         if (!t->s[j] || !t->v[j]) return fail(MFAS_EINVAL, "table: null tap pointer");
     if (need_logits && (!t->vlogit || !t->slogit)) return fail(MFAS_EINVAL, "multitask needs vlogit/slogit");
-    (void)p;
     return MFAS_OK;
 }
 
@@ -1666,7 +1728,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     st.sa.stepbuf = p->stepbuf; st.sa.tab = *train; st.sa.order = order; st.sa.g = g; st.sa.ac = ac;
     st.ca.plane = p->plane; st.ca.plane_stride = p->plane_stride; st.ca.wt = p->wt; st.ca.stepbuf = p->stepbuf;
     st.ca.tab = *train; st.ca.order = order; st.ca.E = epochs; st.ca.g = g; st.ca.stats = p->d_stats;
-    st.ca.status = p->d_status; st.ca.ac = ac; st.ca.yf_in_lds = p->yf_in_lds ? 1 : 0;
+    st.ca.status = p->d_status; st.ca.ac = ac; st.ca.yf_in_lds = p->yf_in_lds ? 1 : 0; st.ca.pos_w = p->d_posw;
 
     const int elt = train->dtype == MFAS_DT_F32 ? 4 : 2;
     p->prof_launches = 0; p->prof_ms = 0.0; p->prof_bytes = 0.0;
@@ -1748,7 +1810,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             EvalArgs ea;
             memset(&ea, 0, sizeof(ea));
             ea.cands = p->d_cands; ea.plane = p->plane; ea.tab = *dev; ea.row0 = 0; ea.nrows = dev->N;
-            ea.cand0 = 0; ea.epoch = ep; ea.E = epochs; ea.g = g; ea.stats = p->d_stats;
+            ea.cand0 = 0; ea.epoch = ep; ea.E = epochs; ea.g = g; ea.stats = p->d_stats; ea.pos_w = p->d_posw;
             HIPCHK(launch_eval(p, ea, K, p->stream));
             if (snapshot_best) {
                 HIPCHK(hipMemcpyAsync(hstats.data(), p->d_stats, sizeof(DevStats) * K * epochs, hipMemcpyDeviceToHost, p->stream));
@@ -1804,7 +1866,7 @@ extern "C" int mfas_population_forward(mfas_population* p, int32_t k, const mfas
     EvalArgs ea;
     memset(&ea, 0, sizeof(ea));
     ea.cands = p->d_cands; ea.plane = p->plane; ea.tab = *tab; ea.row0 = row0; ea.nrows = nrows;
-    ea.cand0 = k; ea.epoch = 0; ea.E = 1; ea.g = p->g; ea.logits = logits;
+    ea.cand0 = k; ea.epoch = 0; ea.E = 1; ea.g = p->g; ea.logits = logits; ea.pos_w = p->d_posw;
     if (corrects) {
         HIPCHK(hipMemsetAsync(p->d_corr, 0, sizeof(long long), p->stream));
         ea.corr_out = p->d_corr;
@@ -1816,6 +1878,13 @@ extern "C" int mfas_population_forward(mfas_population* p, int32_t k, const mfas
         HIPCHK(hipStreamSynchronize(p->stream));
         *corrects = (int64_t)h;
     }
+    return MFAS_OK;
+}
+
+extern "C" int mfas_population_set_pos_weight(mfas_population* p, const float* w) {
+    if (!p || !w) return fail(MFAS_EINVAL, "null");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(p->d_posw, w, sizeof(float) * p->g.C, hipMemcpyHostToDevice));
     return MFAS_OK;
 }
 

@@ -39,6 +39,8 @@ class Hyper:
     bn_momentum: float = 0.1
     s_sizes: Sequence[int] = S_SIZES
     v_sizes: Sequence[int] = V_SIZES
+    loss_mode: int = 0          # 0 CE + top-1 (NTU); 1 weighted BCE-with-logits + F1-samples (MM-IMDB)
+    f1_threshold: float = 0.3   # th_fscore, train_searchable/mmimdb.py:16
 
     @classmethod
     def from_args(cls, args) -> "Hyper":
@@ -60,6 +62,8 @@ class Hyper:
         for j in range(4):
             h.s_sizes[j] = int(self.s_sizes[j])
             h.v_sizes[j] = int(self.v_sizes[j])
+        h.loss_mode = int(self.loss_mode)
+        h.f1_threshold = float(self.f1_threshold)
         return h
 
 
@@ -99,7 +103,10 @@ class FeatureTable:
     ntu_searchable.py:211-225) plus labels (datasets/ntu.py:254)."""
 
     def __init__(self, taps: Dict[str, torch.Tensor], label: torch.Tensor,
-                 vlogit: Optional[torch.Tensor] = None, slogit: Optional[torch.Tensor] = None):
+                 vlogit: Optional[torch.Tensor] = None, slogit: Optional[torch.Tensor] = None,
+                 multilabel: Optional[torch.Tensor] = None):
+        """label: (N,) class indices; for multi-label data pass multilabel (N, C) 0/1 targets as well (label may then
+        be any (N,) tensor on the device, e.g. zeros)."""
         dev = label.device
         if dev.type != "cuda":
             raise RuntimeError("FeatureTable must live on a HIP device (cuda:N); there is no CPU path")
@@ -117,6 +124,7 @@ class FeatureTable:
         self.label = label.to(torch.int32).contiguous()
         self.vlogit = None if vlogit is None else vlogit.to(torch.float32).contiguous()
         self.slogit = None if slogit is None else slogit.to(torch.float32).contiguous()
+        self.multilabel = None if multilabel is None else multilabel.to(torch.float32).contiguous()
         self.device = dev
 
     def __len__(self):
@@ -195,6 +203,7 @@ class FeatureTable:
         t.vlogit = None if self.vlogit is None else self.vlogit.data_ptr()
         t.slogit = None if self.slogit is None else self.slogit.data_ptr()
         t.label = self.label.data_ptr()
+        t.multilabel = None if self.multilabel is None else self.multilabel.data_ptr()
         t.N = self.N
         t.dtype = _lib.MFAS_DT[str(self.dtype).replace("torch.", "")]
         return t
@@ -334,6 +343,11 @@ class Population:
                                                         C.byref(corr) if count else None))
         return (logits, int(corr.value)) if count else logits
 
+    def set_pos_weight(self, w):
+        w = np.ascontiguousarray(np.asarray(w, np.float32))
+        assert w.size == self.hp.C
+        _lib.check(self.lib.mfas_population_set_pos_weight(self._h, w.ctypes.data))
+
     def set_profiling(self, on: bool):
         _lib.check(self.lib.mfas_population_set_profiling(self._h, int(on)))
 
@@ -341,6 +355,22 @@ class Population:
         n, ms, by = C.c_int64(0), C.c_double(0), C.c_double(0)
         _lib.check(self.lib.mfas_population_sweep_profile(self._h, C.byref(n), C.byref(ms), C.byref(by)))
         return int(n.value), float(ms.value), float(by.value)
+
+
+F1_FIXED_POINT = float(1 << 32)
+
+
+def best_dev_f1(stats_row, status_nan: bool, n_dev: int, init_f1: float = 0.0):
+    """train_mmimdb_track_f1's bookkeeping (train_searchable/mmimdb.py:18-137): best F1-samples over the epochs,
+    strict '>' from init_f1; a NaN train-epoch loss ends the run with the best so far; a NaN best becomes 0."""
+    best = init_f1
+    for e in range(len(stats_row)):
+        if status_nan and not np.isfinite(stats_row["train_loss_sum"][e]):
+            break
+        f1 = float(stats_row["dev_corrects"][e]) / F1_FIXED_POINT / float(n_dev)
+        if f1 > best:
+            best = f1
+    return 0.0 if best != best else best
 
 
 def best_dev_accuracy(stats_row, n_dev: int) -> float:

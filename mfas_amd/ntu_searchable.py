@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import population as popmod
 from .engine import (S_SIZES, V_SIZES, FeatureLoader, FeatureTable, Hyper, Population, best_dev_accuracy,
-                     flat_layout)
+                     best_dev_f1, flat_layout)
 from .scheduler import LRCosineAnnealingScheduler
 
 
@@ -236,7 +236,7 @@ def make_order(N, epochs, shuffle, seed, device):
 
 def train_sampled_models(sampled_configurations, searchable_type, dataloaders, args, device,
                          return_model=[], premodels=[], preaccuracies=[],
-                         train_only_central_params=True, state_dict=dict()):
+                         train_only_central_params=True, state_dict=dict(), _hp=None, _pos_weight=None):
     """Drop-in for ntu_searchable.py:23-102.  Every configuration is trained from scratch for
     ``args.epochs`` epochs of {train over dataloaders['train'], eval over dataloaders['dev']} and its best dev
     accuracy returned, in input order.  The whole (per-rank share of the) population trains in lockstep inside
@@ -251,9 +251,9 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
     train_l = _require_loader(dataloaders["train"], "train")
     dev_l = _require_loader(dataloaders["dev"], "dev")
     device = torch.device(device)
-    hp = Hyper.from_args(args)
+    hp = _hp if _hp is not None else Hyper.from_args(args)
     hp.multitask = False    # ntu_searchable.py:82-84 never forwards multitask to the train loop
-    if getattr(args, "multitask", False):
+    if getattr(args, "multitask", False) and _hp is None:
         raise TypeError("max() received an invalid combination of arguments: the searchable returns a tuple "
                         "with --multitask in search mode (reference behaviour, train_searchable/ntu.py:54)")
     confs = [np.asarray(c).reshape(-1, 3) for c in sampled_configurations]
@@ -265,6 +265,8 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
 
     seed_base = popmod.broadcast_seed(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), device)
     if getattr(args, "weightsharing", False):
+        if hp.loss_mode != 0:
+            raise NotImplementedError("weight sharing is wired for the single-label (NTU) searchable only")
         return _train_weightsharing(confs, wanted, searchable_type, train_l, dev_l, args, device, hp, seed_base,
                                     return_model, premodels, state_dict)
 
@@ -278,6 +280,8 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
         pop = Population(hp, [confs[i] for i in mine], device,
                          drop_seeds=[(seed_base * 7 + i) & 0xFFFFFFFF for i in mine],
                          chunk_cols=int(getattr(args, "engine_chunk_cols", 0)))
+        if _pos_weight is not None:
+            pop.set_pos_weight(_pos_weight)
         mods = {}
         if premodels:
             for j, i in enumerate(mine):
@@ -316,7 +320,8 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
                                                                   stats["train_corrects"][j, e] / N_tr))
                     print("dev Loss: {:.4f} Acc: {:.4f}".format(stats["dev_loss_sum"][j, e] / N_dev,
                                                                 stats["dev_corrects"][j, e] / N_dev))
-            local_acc.append(best_dev_accuracy(stats[j], N_dev))
+            local_acc.append(best_dev_f1(stats[j], bool(status[j]), N_dev) if hp.loss_mode == 1
+                             else best_dev_accuracy(stats[j], N_dev))
             if return_model:
                 m = mods.get(i) or searchable_type(args, confs[i])
                 m.load_flat(pop.get_params(j))

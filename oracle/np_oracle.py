@@ -62,6 +62,11 @@ class Hyper:
     bn_momentum: float = 0.1
     s_sizes: Sequence[int] = S_SIZES
     v_sizes: Sequence[int] = V_SIZES
+    # head loss / dev metric: 0 = CrossEntropy + top-1 (NTU); 1 = WeightedCrossEntropyWithLogits + F1-samples
+    # (models/central/mm_imdb.py:655-673; models/search/train_searchable/mmimdb.py:15-137)
+    loss_mode: int = 0
+    f1_threshold: float = 0.3
+    pos_weight: Optional[Sequence[float]] = None
 
     @property
     def use_dropout(self) -> bool:
@@ -289,6 +294,33 @@ def ce_loss(logits, labels):
     return loss, d, predict(logits)
 
 
+def bce_loss(logits, z, w):
+    """WeightedCrossEntropyWithLogits (models/central/mm_imdb.py:655-673): mean over batch and classes of
+    w_c*z*(-log s) + (1-z)*(-log(1-s)), s = sigmoid(logits).  Returns (loss, dlogits)."""
+    B, C = logits.shape
+    sg = _sigmoid(logits.astype(F32))
+    z = z.astype(F32)
+    w = np.asarray(w, F32)
+    L = (w * z * -np.log(sg, dtype=F32) + (F32(1.0) - z) * -np.log(F32(1.0) - sg, dtype=F32)).astype(F32)
+    loss = F32(L.mean(dtype=F32))
+    d = ((-w * z * (F32(1.0) - sg) + (F32(1.0) - z) * sg) / F32(B * C)).astype(F32)
+    return loss, d
+
+
+def f1_samples_fixed(logits, z, th) -> int:
+    """sum over samples of F1 (sklearn f1_score(average='samples'), 0 when prediction and target are both empty)
+    of sigmoid(logits) > th, as 32.32 fixed point (the engine's order-independent accumulator)."""
+    pr = _sigmoid(logits.astype(F32)) > F32(th)
+    tr = z > 0.5
+    tp = (pr & tr).sum(axis=1).astype(np.int64)
+    den = (pr.sum(axis=1) + tr.sum(axis=1)).astype(np.int64)
+    out = 0
+    for t, d in zip(tp, den):
+        if d > 0:
+            out += ((2 * int(t)) << 32) // int(d)
+    return out
+
+
 def predict(logits):
     return np.argmax(logits, axis=1)        # first max on ties, like torch.max(dim) on CPU
 
@@ -425,6 +457,8 @@ def train_candidate(conf, hp: Hyper, params, train, dev, order=None, seed=0, eta
     st = AdamState()
     best = 0.0
     gstep = 0
+    if hp.loss_mode == 1:
+        return _train_candidate_multilabel(conf, hp, params, train, dev, order, seed, etas, history, keys, st)
     for ep in range(hp.epochs):
         # ---- train phase
         run_loss, run_corr = 0.0, 0
@@ -465,6 +499,46 @@ def train_candidate(conf, hp: Hyper, params, train, dev, order=None, seed=0, eta
         if dev_acc > best:
             best = dev_acc
     return best
+
+
+def _train_candidate_multilabel(conf, hp, params, train, dev, order, seed, etas, history, keys, st):
+    """train_mmimdb_track_f1 (models/search/train_searchable/mmimdb.py:15-137) on feature tables: weighted BCE,
+    dev metric F1-samples at th_fscore, best F1 with strict '>' from 0, NaN train loss ends the run."""
+    N_tr, N_dev, B = len(train["multilabel"]), len(dev["multilabel"]), hp.B
+    nb_tr, nb_dev = -(-N_tr // B), -(-N_dev // B)
+    w = np.ones(hp.C, F32) if hp.pos_weight is None else np.asarray(hp.pos_weight, F32)
+    skip = ("label", "multilabel")
+    best, gstep = 0.0, 0
+    for ep in range(hp.epochs):
+        run_loss = 0.0
+        perm = np.arange(N_tr) if order is None else np.asarray(order[ep])
+        for bi in range(nb_tr):
+            idx = perm[bi * B:(bi + 1) * B]
+            feats = {k: v[idx] for k, v in train.items() if k not in skip}
+            logits, cache = forward(params, conf, hp, feats, True, seed=seed, step=gstep)
+            loss, dlog = bce_loss(logits, train["multilabel"][idx], w)
+            grads = backward(params, hp, cache, dlog)
+            bn_update_running(params, hp, cache)
+            adam_step(params, grads, st, float(etas[gstep]), hp, keys)
+            run_loss += float(loss) * len(idx)
+            gstep += 1
+        tr_loss = run_loss / N_tr
+        run_loss, f1fx = 0.0, 0
+        for bi in range(nb_dev):
+            idx = np.arange(bi * B, min((bi + 1) * B, N_dev))
+            feats = {k: v[idx] for k, v in dev.items() if k not in skip}
+            logits, _ = forward(params, conf, hp, feats, False)
+            loss, _ = bce_loss(logits, dev["multilabel"][idx], w)
+            run_loss += float(loss) * len(idx)
+            f1fx += f1_samples_fixed(logits, dev["multilabel"][idx], hp.f1_threshold)
+        f1 = f1fx / float(1 << 32) / N_dev
+        if history is not None:
+            history.append(dict(train_loss=tr_loss, dev_loss=run_loss / N_dev, dev_f1=f1, dev_f1_fixed=f1fx))
+        if tr_loss != tr_loss:
+            break
+        if f1 > best:
+            best = f1
+    return 0.0 if best != best else best
 
 
 def train_sampled_models(confs, hp: Hyper, train, dev, init_seed=0, order=None, drop_seed=0,
@@ -534,3 +608,30 @@ def fake_accuracy(conf) -> float:
         for v in row:
             h = (h * 31 + int(v) + 7) % 1000003
     return 0.25 + 0.7 * (h % 1000) / 1000.0
+
+
+MM_S_SIZES = (64, 128, 64, 128)      # text taps o1 (64-d), o3 (128-d) of MaxOut_MLP, models/central/mm_imdb.py:176-196
+MM_V_SIZES = (512, 512, 512, 512)    # image taps of GP_VGG (feature idx 20/26/33/36), models/central/mm_imdb.py:19-59
+
+
+def synth_table_mm(N, seed, C=23, snr=0.6, p_on=0.15, mu_seed=321, quant=None):
+    """MM-IMDB-shaped multi-label table: multi-hot targets, taps = relu(snr * sum of active class prototypes + eps)."""
+    z = (hash_u01(param_seed(seed, 900), N * C).reshape(N, C) < F32(p_on)).astype(F32)
+    t = {"multilabel": z, "label": np.zeros(N, np.int64)}
+    slot = 0
+    for name, sizes in (("s", MM_S_SIZES), ("v", MM_V_SIZES)):
+        for j, wd in enumerate(sizes):
+            slot += 1
+            mu = hash_noise(param_seed(mu_seed, slot), C * wd).reshape(C, wd)
+            eps = hash_noise(param_seed(seed, 100 + slot), N * wd).reshape(N, wd)
+            x = np.maximum(F32(snr) * (z @ mu).astype(F32) + eps, F32(0)).astype(F32)
+            if quant == "bf16":
+                x = bf16_round(x)
+            elif quant == "fp16":
+                x = x.astype(np.float16).astype(F32)
+            t[f"{name}{j}"] = x
+    return t
+
+
+def mm_pos_weight(C=23, seed=7):
+    return (F32(1.0) + F32(3.0) * hash_u01(param_seed(seed, 950), C)).astype(F32)

@@ -463,7 +463,95 @@ def g9():
     save("g9_controller_run.npz", **out)
 
 
+# ------------------------------------------------------------------ G11 MM-IMDB loss / metric / loop (next#3)
+def g11():
+    """Pins for the multi-label variant.  The reference has no Searchable_* for MM-IMDB, so the network
+    is the NTU searchable re-sized to MM-IMDB taps (text [64,128], image 4x512, C=23) — test glue; what IS the
+    reference's and is pinned here: WeightedCrossEntropyWithLogits (models/central/mm_imdb.py:655-673) and
+    train_mmimdb_track_f1 (models/search/train_searchable/mmimdb.py:15-137, needs the alias
+    models.train.scheduler -> models.auxiliary.scheduler and a stub torchvision.models)."""
+    import types
+    tv = sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    tvm = sys.modules.setdefault("torchvision.models", types.ModuleType("torchvision.models"))
+    tv.models = tvm
+    import models.auxiliary as aux_pkg
+    sys.modules.setdefault("models.train", aux_pkg)
+    sys.modules.setdefault("models.train.scheduler", sc)
+    import models.central.mm_imdb as mm
+    import models.search.train_searchable.mmimdb as trm
+    import models.auxiliary.aux_models as aux
+    out = {}
+    C = 23
+    w = O.mm_pos_weight(C)
+    # (a) the loss and its gradient
+    rng_logits = (O.hash_noise(77, 16 * C).reshape(16, C) * np.float32(2.0)).astype(np.float32)
+    z = (O.hash_u01(78, 16 * C).reshape(16, C) < 0.2).astype(np.float32)
+    lg = torch.from_numpy(rng_logits.copy()).requires_grad_(True)
+    loss = mm.WeightedCrossEntropyWithLogits(w.tolist())(lg, torch.from_numpy(z))
+    loss.backward()
+    out["loss"] = np.array(loss.item())
+    out["dlogits"] = lg.grad.numpy().copy()
+
+    # (b) the train loop on MM-IMDB-shaped tables
+    class TextImageNet(ntu.Searchable_Skeleton_Image_Net):
+        def _create_alphas(self):
+            return nn.ModuleList([aux.AlphaScalarMultiplication(O.MM_S_SIZES[c[0]], O.MM_V_SIZES[c[1]])
+                                  for c in self.conf])
+
+    class Wrap(nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, text, image):
+            return self.inner((image, text))
+
+    ttr, tdv = O.synth_table_mm(128, 41), O.synth_table_mm(96, 42)
+
+    class MMLoader:
+        def __init__(self, t, B):
+            self.t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in t.items()}
+            self.B = B
+            self.dataset = range(len(t["multilabel"]))
+
+        def __iter__(self):
+            N = len(self.dataset)
+            zero = torch.zeros(1)
+            for i in range(0, N, self.B):
+                sl = slice(i, min(i + self.B, N))
+                img = D({k: self.t[k][sl] for k in ("v0", "v1", "v2", "v3")})
+                img["vlogit"] = zero
+                txt = D({k: self.t[k][sl] for k in ("s0", "s1", "s2", "s3")})
+                txt["slogit"] = zero
+                yield {"image": img, "text": txt, "label": self.t["multilabel"][sl]}
+
+    for tag, conf, R in (("a", [[1, 2, 0], [0, 3, 1]], 16), ("b", [[0, 0, 1]], 32)):
+        conf = np.array(conf)
+        args = mkargs(inner_representation_size=R, batchnorm=True, drpt=0.0, epochs=3, batchsize=16, num_outputs=C)
+        inner = TextImageNet(args, conf)
+        hp = O.Hyper(R=R, C=C, B=16, bn=True, drpt=0.0, epochs=3, s_sizes=O.MM_S_SIZES, v_sizes=O.MM_V_SIZES,
+                     loss_mode=1)
+        p = O.init_params(conf, hp, 17)
+        sd = inner.state_dict()
+        for k, v in p.items():
+            assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+            sd[k].copy_(torch.from_numpy(v))
+        model = Wrap(inner)
+        opt = torch.optim.Adam(inner.central_params(), lr=args.eta_max, weight_decay=1e-4)
+        sched = sc.LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, 128 / 16)
+        crit = mm.WeightedCrossEntropyWithLogits(w.tolist())
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            best = trm.train_mmimdb_track_f1(model, crit, opt, sched, {"train": MMLoader(ttr, 16), "dev": MMLoader(tdv, 16)},
+                                             {"train": 128, "dev": 96}, device="cpu", num_epochs=3, verbose=True)
+        f1s = [float(m.group(1)) for m in re.finditer(r"dev F1: ([0-9.]+)", buf.getvalue())]
+        out[tag + "/best_f1"] = np.array(float(best))
+        out[tag + "/f1_per_epoch"] = np.array(f1s)
+        out[tag + "/conf"] = conf
+    save("g11_mmimdb.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

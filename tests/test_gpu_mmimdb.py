@@ -1,0 +1,106 @@
+"""GPU: the multi-label (MM-IMDB shaped) variant — engine vs oracle (itself pinned to the reference's loss + loop)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from oracle import np_oracle as O
+from tests.helpers import engine_hyper, etas_for, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def mm_table(t, dev, dtype=torch.float32):
+    from mfas_amd import FeatureTable
+    taps = {k: torch.from_numpy(t[k]).to(device=dev, dtype=dtype) for k in t if k[0] in "sv" and k[1:].isdigit()}
+    return FeatureTable(taps, torch.zeros(len(t["multilabel"]), dtype=torch.int32, device=dev),
+                        multilabel=torch.from_numpy(t["multilabel"]).to(dev))
+
+
+@pytest.mark.parametrize("tag,R", [("a", 16), ("b", 32)])
+def test_multilabel_engine_vs_reference_golden(dev, tag, R):
+    from mfas_amd import Population, best_dev_f1
+    g = golden("g11_mmimdb.npz")
+    conf = g[tag + "/conf"]
+    w = O.mm_pos_weight(23)
+    ohp = O.Hyper(R=R, C=23, B=16, bn=True, drpt=0.0, epochs=3, s_sizes=O.MM_S_SIZES, v_sizes=O.MM_V_SIZES,
+                  loss_mode=1, pos_weight=w)
+    hp = engine_hyper(ohp)
+    hp.loss_mode, hp.f1_threshold = 1, 0.3
+    ttr, tdv = O.synth_table_mm(128, 41), O.synth_table_mm(96, 42)
+    pop = Population(hp, [conf], dev)
+    pop.set_pos_weight(w)
+    pop.set_state_dict(0, O.init_params(conf, ohp, 17))
+    stats, status = pop.train(mm_table(ttr, dev), mm_table(tdv, dev), 3, etas_for(ohp, 128))
+    hist = []
+    O.train_candidate(conf, ohp, O.init_params(conf, ohp, 17), ttr, tdv, history=hist)
+    for e in range(3):
+        assert abs(stats["train_loss_sum"][0, e] / 128 - hist[e]["train_loss"]) < 1e-3
+        f1 = stats["dev_corrects"][0, e] / float(1 << 32) / 96
+        assert abs(f1 - hist[e]["dev_f1"]) <= 0.004              # a threshold flip moves one sample's F1 by <= 1/96*...
+        assert abs(f1 - g[tag + "/f1_per_epoch"][e]) <= 0.004     # the reference's own printed trajectory
+    assert abs(best_dev_f1(stats[0], bool(status[0]), 96) - float(g[tag + "/best_f1"])) <= 0.004
+    pop.close()
+
+
+def test_multilabel_steps_and_fp16(dev):
+    """A few train steps with dropout (shared mask stream) on fp16-stored taps: parameters track the oracle."""
+    from mfas_amd import Population
+    from tests.test_gpu_parity import check_state
+    from tests.helpers import oracle_steps
+    conf = np.array([[1, 3, 0], [0, 1, 1], [1, 0, 0]])
+    w = O.mm_pos_weight(23)
+    ohp = O.Hyper(R=16, C=23, B=20, bn=False, drpt=0.5, epochs=2, s_sizes=O.MM_S_SIZES, v_sizes=O.MM_V_SIZES,
+                  loss_mode=1, pos_weight=w)
+    hp = engine_hyper(ohp)
+    hp.loss_mode = 1
+    ttr = O.synth_table_mm(100, 51, quant="fp16")
+    pop = Population(hp, [conf], dev, drop_seeds=[3])
+    pop.set_pos_weight(w)
+    pop.set_state_dict(0, O.init_params(conf, ohp, 23))
+    pop.train(mm_table(ttr, dev, torch.float16), None, 2, etas_for(ohp, 100), max_steps=5)
+    # oracle: same 5 steps with the BCE head
+    params = O.init_params(conf, ohp, 23)
+    keys = O.trainable_keys(conf, ohp)
+    st = O.AdamState()
+    etas = etas_for(ohp, 100)
+    for gstep in range(5):
+        idx = np.arange(gstep * 20, (gstep + 1) * 20)
+        feats = {k: v[idx] for k, v in ttr.items() if k not in ("label", "multilabel")}
+        logits, cache = O.forward(params, conf, ohp, feats, True, seed=3, step=gstep)
+        _, dlog = O.bce_loss(logits, ttr["multilabel"][idx], w)
+        O.adam_step(params, O.backward(params, ohp, cache, dlog), st, float(etas[gstep]), ohp, keys)
+    check_state(pop, 0, params, st, 5, tag="mm")
+    pop.close()
+
+
+def test_mmimdb_mirror_population(dev):
+    import mfas_amd as M
+    from mfas_amd import mmimdb_searchable as MM
+    args = SimpleNamespace(vid_len=(8, 32), num_outputs=23, drpt=0.5, inner_representation_size=16, batchnorm=True,
+                           alphas=False, multitask=False, weightsharing=False, batchsize=16, eta_max=1e-3,
+                           eta_min=1e-6, Ti=1, Tm=2, use_dataparallel=False, verbose=False, epochs=3,
+                           pos_weight=O.mm_pos_weight(23).tolist())
+    ttr, tdv = O.synth_table_mm(512, 61), O.synth_table_mm(256, 62)
+    ld = {"train": M.FeatureLoader(mm_table(ttr, dev, torch.float16), 16, shuffle=True),
+          "dev": M.FeatureLoader(mm_table(tdv, dev, torch.float16), 16, shuffle=False)}
+    confs = [np.array(c) for c in ([[0, 0, 0]], [[1, 2, 1], [0, 3, 0]], [[1, 1, 0], [1, 3, 1], [0, 0, 0]])]
+    assert len(MM.get_possible_layer_configurations(0)) == 16
+    torch.manual_seed(2)
+    f1s = MM.train_sampled_models(confs, MM.Searchable_Text_Image_Net, ld, args, dev)
+    assert len(f1s) == 3 and all(0.05 < f < 1.0 for f in f1s)
+    # single-model loop with the reference's signature
+    torch.manual_seed(2)
+    model = MM.Searchable_Text_Image_Net(args, confs[1])
+    opt = torch.optim.Adam(model.central_params(), lr=1e-3, weight_decay=1e-4)
+    sched = M.LRCosineAnnealingScheduler(1e-3, 1e-6, 1, 2, 512 / 16)
+    best = MM.train_mmimdb_track_f1(model, MM.WeightedCrossEntropyWithLogits(args.pos_weight), opt, sched, ld,
+                                    {"train": 512, "dev": 256}, device=dev, num_epochs=3)
+    assert 0.05 < best < 1.0 and not model.training

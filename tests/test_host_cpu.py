@@ -37,11 +37,28 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().mfas_version() >= 100
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors must match what a C compiler makes of include/mfas_hip.h (sizes and key offsets)."""
     from mfas_amd import _lib
-    assert ctypes.sizeof(_lib.mfas_hyper) == 6 * 4 + 7 * 8 + 8 * 4
-    assert ctypes.sizeof(_lib.mfas_table) == 11 * 8 + 8 + 8
-    assert ctypes.sizeof(_lib.mfas_epoch_stats) == 32
+    src = tmp_path / "sz.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "mfas_hip.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mfas_hyper), sizeof(mfas_table), sizeof(mfas_epoch_stats),
+           offsetof(mfas_hyper, drpt), offsetof(mfas_hyper, s_sizes), offsetof(mfas_hyper, f1_threshold),
+           offsetof(mfas_table, multilabel), offsetof(mfas_table, dtype));
+    return 0;
+}
+""")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(_lib.mfas_hyper), ctypes.sizeof(_lib.mfas_table), ctypes.sizeof(_lib.mfas_epoch_stats),
+            _lib.mfas_hyper.drpt.offset, _lib.mfas_hyper.s_sizes.offset, _lib.mfas_hyper.f1_threshold.offset,
+            _lib.mfas_table.multilabel.offset, _lib.mfas_table.dtype.offset]
+    assert got == want, (got, want)
 
 
 def test_no_engine_without_gpu():
