@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmfas_hip.so")
+LIB_PATH = os.environ.get("MFAS_LIB") or os.path.join(_HERE, "csrc", "libmfas_hip.so")   # MFAS_LIB: debug builds
 
 MFAS_DT = {"float32": 0, "bfloat16": 1, "float16": 2}
 

@@ -427,7 +427,7 @@ struct ChainArgs {
     int64_t pos_t;
     int32_t base_t, nvalid;
     int32_t gstep, epoch, E;
-    int32_t yf_in_lds, _pad;
+    int32_t yf_in_lds, vec_in_lds;
     AdamC ac;
     Geo g;
     DevStats* stats;
@@ -448,7 +448,11 @@ __device__ __forceinline__ bool drop_keep(uint32_t h0, int cell, uint32_t idx, u
 template <int MB>
 __device__ __forceinline__ void lds_x_times_tiles(f32x4 (&acc)[MB], const float* X, int sx, const float* tiles,
                                                   int64_t tstride, int nk, int lane) {
+    // same arithmetic as mma_tiles: even / odd k-blocks in two independent chains, summed at the end
     const int l15 = lane & 15, lg = lane >> 4;
+    f32x4 acc2[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc2[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < nk; k0 += 8) {
         f32x4 w8[8];
 #pragma unroll
@@ -461,10 +465,53 @@ __device__ __forceinline__ void lds_x_times_tiles(f32x4 (&acc)[MB], const float*
                 for (int mb = 0; mb < MB; ++mb) {
                     const f32x4 x4 = *reinterpret_cast<const f32x4*>(X + (mb * 16 + l15) * sx + (k0 + u) * 16 + 4 * lg);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w8[u][q], acc[mb]);
+                    for (int q = 0; q < 4; ++q) {
+                        if (u & 1) acc2[mb] = MFMA16(x4[q], w8[u][q], acc2[mb]);
+                        else acc[mb] = MFMA16(x4[q], w8[u][q], acc[mb]);
+                    }
                 }
             }
     }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] += acc2[mb];
+}
+
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic (lgkmcnt) but NOT for its
+// outstanding global stores, which __syncthreads() would (s_waitcnt vmcnt(0) = a full store round trip per cell).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Software pipelining of the chain: the weight tiles of a product do not depend on the activations, so a wave
+// requests the NEXT product's tiles (<= 8 tiles = 32 VGPRs) before it starts the current one.
+__device__ __forceinline__ void issue_tiles(f32x4 (&w8)[8], const float* tiles, int nk, int lane) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nk) w8[u] = *reinterpret_cast<const f32x4*>(tiles + (int64_t)u * 256 + lane * 4);
+}
+
+// acc[mb] += X[b][0..16*nk) . w8[k]; even / odd k-blocks accumulate in two independent MFMA chains
+template <int MB>
+__device__ __forceinline__ void mma_tiles(f32x4 (&acc)[MB], const float* X, int sx, const f32x4 (&w8)[8], int nk, int lane) {
+    const int l15 = lane & 15, lg = lane >> 4;
+    f32x4 acc2[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc2[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nk) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(X + (mb * 16 + l15) * sx + u * 16 + 4 * lg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (u & 1) acc2[mb] = MFMA16(x4[q], w8[u][q], acc2[mb]);
+                    else acc[mb] = MFMA16(x4[q], w8[u][q], acc[mb]);
+                }
+            }
+        }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] += acc2[mb];
 }
 
 // WeightedCrossEntropyWithLogits (models/central/mm_imdb.py:655-673) on the LDS logits, 4 lanes per row:
@@ -497,13 +544,23 @@ __device__ __forceinline__ void bce_rows(float* lg_l, int SC, float* red, int Bp
     }
 }
 
-template <int MB>
+#ifdef MFAS_CHAIN_TIMING
+#define CT_STAMP(slot) do { if (threadIdx.x == 0 && bid == 0 && a.gstep == 3) a.status[64 + (slot)] = (int32_t)(__builtin_readcyclecounter() - ct0); } while (0)
+#else
+#define CT_STAMP(slot) do { } while (0)
+#endif
+
+template <int MB, bool PF>
 __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, float* lds) {
+#ifdef MFAS_CHAIN_TIMING
+    const unsigned long long ct0 = __builtin_readcyclecounter();
+#endif
     const CandDev& cd = a.cands[bid];
     const Geo& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     constexpr int Bp = MB * 16;
+    constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;   // softmax lanes per batch row
     const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
     const int SX = Rp + 4, SC = Cp + 4;
     // LDS kept close to the sweep's so both bodies can share one launch: ping-pong activation buffers (out_i
@@ -523,6 +580,21 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
     float* sav = sb + g.sb_sav;              // [3][L][nrb][MB][256]: act, xhat, (yS - yV)
     // reduced feature sums [1 or 2][L][nrb][MB][256]: LDS when it fits the shared budget, else scratch
     float* yf_l = a.yf_in_lds ? reinterpret_cast<float*>(lab_l + Bp) : sb + g.sb_yf;
+    // vector parameters (+ their Adam state): the standalone chain stages the candidate's whole vector block into LDS
+    // once, so that no dependent global load sits inside the serial cell loops; updates are written to global only
+    const int nvec = MFAS_MAX_CELLS * g.vec_cell_stride + Cp;
+    const float* vecW = W + cd.vec_off;
+    const float* vecM = Mv + cd.vec_off;
+    const float* vecV = Vv + cd.vec_off;
+    if (PF && a.vec_in_lds) {
+        float* vl = reinterpret_cast<float*>(lab_l + Bp) + (a.yf_in_lds ? (g.alphas ? 2 : 1) * sav_plane : 0);
+        for (int e = tid; e < nvec; e += CHAIN_THREADS) {
+            vl[e] = vecW[e];
+            vl[nvec + e] = vecM[e];
+            vl[2 * nvec + e] = vecV[e];
+        }
+        vecW = vl; vecM = vl + nvec; vecV = vl + 2 * nvec;   // visible after the phase-0 barrier below
+    }
     const int nvalid = a.nvalid;
     const float nf = (float)nvalid;
     const AdamC ac = a.ac;
@@ -546,13 +618,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             const int ns = cd.nch_s[i], nch = ns + cd.nch_v[i];
             const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8) + it * 4;
             f32x4 accS = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
-            for (int ch0 = 0; ch0 < nch; ch0 += 8) {
-                f32x4 p8[8];
+            constexpr int PB = PF ? 16 : 8;   // partial-sum loads in flight per thread
+            for (int ch0 = 0; ch0 < nch; ch0 += PB) {
+                f32x4 p8[PB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < PB; ++u)
                     if (ch0 + u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)(ch0 + u) * nrb * MB) << 8));
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < PB; ++u)
                     if (ch0 + u < nch) {
                         if (ch0 + u < ns) accS += p8[u]; else accV += p8[u];
                     }
@@ -567,15 +640,33 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
     }
     __syncthreads();
 
+    // one row block per wave and <= 8 k-blocks per product: register-prefetched tiles (wa = current, wb = next)
+    const bool pf = PF && nrb <= CHAIN_NW && ncb <= CHAIN_NW;
+    f32x4 wa[8], wb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { wa[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; wb[u] = wa[u]; }
+    // products in order: P_1..P_{L-1} (prev-out block of cell i), head, then backward: head^T, outT_{L-1}..outT_1
+    if (pf) {
+        if (L > 1) { if (wave < nrb) issue_tiles(wa, W + cd.seg_off[1][2] + (int64_t)wave * nrb * 256, nrb, lane); }
+        else if (wave < ncb) issue_tiles(wa, W + cd.head_off + (int64_t)wave * nrb * 256, nrb, lane);
+    }
+
+    CT_STAMP(0);
     // ------------------------------------------------------------------ forward chain
     for (int i = 0; i < L; ++i) {
+        CT_STAMP(1 + i);
+        if (pf && i >= 1) {   // wa holds P_i; request the NEXT product's tiles now: P_{i+1}, or the head after the last cell
+            if (i + 1 < L) { if (wave < nrb) issue_tiles(wb, W + cd.seg_off[i + 1][2] + (int64_t)wave * nrb * 256, nrb, lane); }
+            else if (wave < ncb) issue_tiles(wb, W + cd.head_off + (int64_t)wave * nrb * 256, nrb, lane);
+        }
         const float* xprev = xo_l + ((i + 1) & 1) * Bp * SX;
         float* xcur = xo_l + (i & 1) * Bp * SX;
         const int nl = cd.conf[i][2];
         const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
+        const int vbl = i * g.vec_cell_stride;
         float sgS = 1.0f, sgV = 1.0f;
         if (g.alphas) {
-            const float sg = 1.0f / (1.0f + expf(-W[vb + 5 * Rp]));
+            const float sg = 1.0f / (1.0f + expf(-vecW[vbl + 5 * Rp]));
             sgS = sg;
             sgV = 1.0f - sg;
             if (tid == 0) {
@@ -587,9 +678,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             const int r = rb * 16 + l15;
             const bool colok = r < R;
             // independent loads first: vector parameters of this column
-            const float bias = W[vb + VEC_B * Rp + r];
+            const float bias = vecW[vbl + VEC_B * Rp + r];
             float gam = 1.f, bet = 0.f;
-            if (g.bn) { gam = W[vb + VEC_G * Rp + r]; bet = W[vb + VEC_BE * Rp + r]; }
+            if (g.bn) { gam = vecW[vbl + VEC_G * Rp + r]; bet = vecW[vbl + VEC_BE * Rp + r]; }
             f32x4 acc[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -601,8 +692,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
                     acc[mb] = acc[mb] * sgS + yv * sgV;
                 }
             }
-            if (i > 0)
-                lds_x_times_tiles<MB>(acc, xprev, SX, W + cd.seg_off[i][2] + (int64_t)rb * nrb * 256, 256, nrb, lane);
+            if (i > 0) {
+                if (pf) mma_tiles<MB>(acc, xprev, SX, wa, nrb, lane);
+                else lds_x_times_tiles<MB>(acc, xprev, SX, W + cd.seg_off[i][2] + (int64_t)rb * nrb * 256, 256, nrb, lane);
+            }
             float av[MB][4];
             float s = 0.f;
 #pragma unroll
@@ -640,7 +733,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
                 if (lg == 0) {
                     rstd_l[i * Rp + r] = rstd;
                     if (colok) {   // running stats: momentum 0.1, unbiased variance
-                        float rm = W[vb + VEC_RM * Rp + r], rv = W[vb + VEC_RV * Rp + r];
+                        float rm = vecW[vbl + VEC_RM * Rp + r], rv = vecW[vbl + VEC_RV * Rp + r];
                         const float unb = var * (nf / (nf - 1.0f));
                         rm += g.bn_mom * (mu - rm);
                         rv += g.bn_mom * (unb - rv);
@@ -678,41 +771,62 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
                     xo_g[b * Rp + r] = o;
                 }
         }
-        __syncthreads();
+        if (pf && i >= 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wa[u] = wb[u];
+        }
+        lds_barrier();
     }
 
+    CT_STAMP(5);
     // ------------------------------------------------------------------ head + CE loss
     {
         const float* xl = xo_l + ((L - 1) & 1) * Bp * SX;
+        if (pf && wave < nrb)   // first backward product: d_out = dlogits . Wc  (transposed head tiles of this row block)
+            issue_tiles(wb, a.wt + cd.headT_off + (int64_t)wave * ncb * 256, ncb, lane);
         for (int cb = wave; cb < ncb; cb += CHAIN_NW) {
             f32x4 acc[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int c = cb * 16 + l15;
-            const float bias = W[cd.vec_off + g.vec_head + c];
-            lds_x_times_tiles<MB>(acc, xl, SX, W + cd.head_off + (int64_t)cb * nrb * 256, 256, nrb, lane);
+            const float bias = vecW[g.vec_head + c];
+            if (pf) mma_tiles<MB>(acc, xl, SX, wa, nrb, lane);
+            else lds_x_times_tiles<MB>(acc, xl, SX, W + cd.head_off + (int64_t)cb * nrb * 256, 256, nrb, lane);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) lg_l[(mb * 16 + 4 * lg + q) * SC + c] = acc[mb][q] + bias;
         }
     }
-    __syncthreads();
+    lds_barrier();
+    CT_STAMP(6);
     if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
-    } else if (tid < 4 * Bp) {   // 4 lanes per row: classes c = sub, sub+4, ...
-        const int b = tid >> 2, sub = tid & 3;
+    } else if (tid < LPR * Bp) {   // LPR lanes per row: classes c = sub, sub+LPR, ... (<= 8 classes per lane, exp kept)
+        const int b = tid / LPR, sub = tid % LPR;
         float* row = lg_l + b * SC;
         const bool ok = b < nvalid;
         const int lab = lab_l[b];
+        constexpr int NC = 8;                    // classes per lane (host guarantees Cp <= NC * LPR)
+        float xv[NC], ev[NC];
         float mx = -3.0e38f;
-        for (int c = sub; c < C; c += 4) mx = fmaxf(mx, row[c]);
-        mx = fmaxf(mx, __shfl_xor(mx, 1));
-        mx = fmaxf(mx, __shfl_xor(mx, 2));
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = sub + j * LPR;
+            xv[j] = c < C ? row[c] : -3.0e38f;
+            mx = fmaxf(mx, xv[j]);
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float se = 0.f;
-        for (int c = sub; c < C; c += 4) se += expf(row[c] - mx);
-        se += __shfl_xor(se, 1);
-        se += __shfl_xor(se, 2);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = sub + j * LPR;
+            ev[j] = c < C ? expf(xv[j] - mx) : 0.f;
+            se += ev[j];
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) se += __shfl_xor(se, o);
         // argmax, first max on ties (torch.max(dim=1)); multitask: central + visual + skeleton logits
         float bv = -3.0e38f;
         int bi = 0x7FFFFFFF;
@@ -723,13 +837,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             vl = a.tab.vlogit + grow * C;
             sl = a.tab.slogit + grow * C;
         }
-        for (int c = sub; c < C; c += 4) {
-            float t = row[c];
-            if (vl) t = (t + vl[c]) + sl[c];
-            if (t > bv) { bv = t; bi = c; }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = sub + j * LPR;
+            if (c < C) {
+                float t = xv[j];
+                if (vl) t = (t + vl[c]) + sl[c];
+                if (t > bv) { bv = t; bi = c; }
+            }
         }
 #pragma unroll
-        for (int o = 1; o <= 2; o <<= 1) {
+        for (int o = 1; o < LPR; o <<= 1) {
             const float pv = __shfl_xor(bv, o);
             const int pi = __shfl_xor(bi, o);
             if (pv > bv || (pv == bv && pi < bi)) { bv = pv; bi = pi; }
@@ -739,17 +857,21 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             red_l[b] = ok ? -(row[lab] - lse) : 0.f;
             red_l[Bp + b] = (ok && bi == lab) ? 1.f : 0.f;
         }
-        for (int c = sub; c < Cp; c += 4) {
-            float dl = 0.f;
-            if (ok && c < C) {
-                dl = expf(row[c] - mx) / se;
-                if (c == lab) dl -= 1.0f;
-                dl = dl / nf;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = sub + j * LPR;
+            if (c < Cp) {
+                float dl = 0.f;
+                if (ok && c < C) {
+                    dl = ev[j] / se;
+                    if (c == lab) dl -= 1.0f;
+                    dl = dl / nf;
+                }
+                row[c] = dl;
             }
-            row[c] = dl;
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         float ls = 0.f, cs = 0.f;
         for (int b = 0; b < Bp; ++b) { ls += red_l[b]; cs += red_l[Bp + b]; }
@@ -758,6 +880,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
         st.train_corr += (long long)cs;
         if (!(fabsf(ls) <= 3.0e38f)) a.status[cd.gidx] = 1;
     }
+    CT_STAMP(7);
     // dlogits -> global (dy operand of the HEAD segment); head-bias Adam
     {
         float* dlg = sb + g.sb_dlog;
@@ -769,16 +892,25 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             float gsum = 0.f;
             for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + tid];
             const int64_t o = cd.vec_off + g.vec_head + tid;
-            float w = W[o], m = Mv[o], v = Vv[o];
+            float w = vecW[g.vec_head + tid], m = vecM[g.vec_head + tid], v = vecV[g.vec_head + tid];
             adam1(w, m, v, gsum, ac);
             W[o] = w; Mv[o] = m; Vv[o] = v;
         }
     }
 
+    if (pf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wa[u] = wb[u];
+    }
+
     // ------------------------------------------------------------------ backward chain
     for (int i = L - 1; i >= 0; --i) {
+        CT_STAMP(8 + (L - 1 - i));
+        if (pf && i >= 1 && wave < nrb)   // next backward product (cell i-1) uses the transposed prev-out block of cell i
+            issue_tiles(wb, a.wt + cd.outT_off[i] + (int64_t)wave * nrb * 256, nrb, lane);
         const int nl = cd.conf[i][2];
         const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
+        const int vbl = i * g.vec_cell_stride;
         const bool from_head = (i == L - 1);
         const float* src = from_head ? lg_l : dy_l + ((i + 1) & 1) * Bp * SX;
         const int sstride = from_head ? SC : SX;
@@ -791,14 +923,15 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             const bool colok = r < R;
             // independent loads first
             float gr = 0.f;
-            if (g.bn) gr = W[vb + VEC_G * Rp + r] * rstd_l[i * Rp + r];
+            if (g.bn) gr = vecW[vbl + VEC_G * Rp + r] * rstd_l[i * Rp + r];
             int64_t ob = vb + VEC_B * Rp + r, og = vb + VEC_G * Rp + r, obe = vb + VEC_BE * Rp + r;
             float pw[3] = {0.f, 0.f, 0.f}, pm[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f};
             if (lg == 0 && colok) {
-                pw[0] = W[ob]; pm[0] = Mv[ob]; pv[0] = Vv[ob];
+                const int lb = vbl + VEC_B * Rp + r, lgm = vbl + VEC_G * Rp + r, lbe = vbl + VEC_BE * Rp + r;
+                pw[0] = vecW[lb]; pm[0] = vecM[lb]; pv[0] = vecV[lb];
                 if (g.bn) {
-                    pw[1] = W[og]; pm[1] = Mv[og]; pv[1] = Vv[og];
-                    pw[2] = W[obe]; pm[2] = Mv[obe]; pv[2] = Vv[obe];
+                    pw[1] = vecW[lgm]; pm[1] = vecM[lgm]; pv[1] = vecV[lgm];
+                    pw[2] = vecW[lbe]; pm[2] = vecM[lbe]; pv[2] = vecV[lbe];
                 }
             }
             f32x4 a4[MB], xh4[MB], df4[MB];
@@ -815,7 +948,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             f32x4 acc[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            lds_x_times_tiles<MB>(acc, src, sstride, T + (int64_t)rb * nkk * 256, 256, nkk, lane);
+            if (pf) mma_tiles<MB>(acc, src, sstride, wa, nkk, lane);
+            else lds_x_times_tiles<MB>(acc, src, sstride, T + (int64_t)rb * nkk * 256, 256, nkk, lane);
             float dz[MB][4];
             float sdz = 0.f, sdzx = 0.f;
 #pragma unroll
@@ -871,22 +1005,27 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
                 }
             }
         }
+        if (pf && i >= 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wa[u] = wb[u];
+        }
         if (g.alphas) {   // d(alpha_i) = sigma'(alpha) * sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]
             for (int o = 32; o > 0; o >>= 1) dalpha += __shfl_xor(dalpha, o);
             if (lane == 0) red_l[2 * Bp + wave] = dalpha;
         }
-        __syncthreads();
+        lds_barrier();
         if (g.alphas && tid == 0) {
             float tot = 0.f;
             for (int w = 0; w < CHAIN_NW; ++w) tot += red_l[2 * Bp + w];
             const int64_t o = vb + 5 * Rp;
-            float w = W[o], m = Mv[o], v = Vv[o];
+            float w = vecW[vbl + 5 * Rp], m = vecM[vbl + 5 * Rp], v = vecV[vbl + 5 * Rp];
             const float sg = 1.0f / (1.0f + expf(-w));
             adam1(w, m, v, tot * sg * (1.0f - sg), ac);
             W[o] = w; Mv[o] = m; Vv[o] = v;
         }
-        if (g.alphas) __syncthreads();
+        if (g.alphas) lds_barrier();
     }
+    CT_STAMP(12);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -903,8 +1042,16 @@ struct StepArgs {
 template <int MB, bool NT>
 __global__ void __launch_bounds__(STEP_THREADS, (MB == 1 ? 4 : 2)) k_step(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x < a.nchain) chain_body<MB>(a.ca, (int)blockIdx.x, lds);
+    if ((int)blockIdx.x < a.nchain) chain_body<MB, false>(a.ca, (int)blockIdx.x, lds);
     else sweep_body<MB, NT>(a.sa, (int)blockIdx.x - a.nchain, lds);
+}
+
+// Standalone chain launch (small populations: chain and sweep run back to back, so the chain's latency is on the
+// critical path): full register budget, next-product weight tiles prefetched into registers.
+template <int MB>
+__global__ void __launch_bounds__(STEP_THREADS, 2) k_chain(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    chain_body<MB, true>(a, (int)blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1284,7 +1431,8 @@ struct mfas_population {
     uint32_t* d_seeds = nullptr;
     long long* d_corr = nullptr;
     float* d_posw = nullptr;        // loss_mode 1: per-class positive weights (default 1)
-    size_t lds_step = 0, lds_eval = 0;
+    size_t lds_step = 0, lds_chain = 0, lds_eval = 0;
+    bool vec_in_lds = false;
     int mbe = 4, nrbw = 1;
     bool yf_in_lds = false;
     bool nontemporal = false;
@@ -1321,6 +1469,10 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     if (!hp || !confs || !n_cells || !out || K <= 0) return fail(MFAS_EINVAL, "null argument or K <= 0");
     if (hp->R < 1 || hp->R > 512 || hp->C < 1 || hp->C > 256) return fail(MFAS_EINVAL, "R must be in [1,512], C in [1,256]");
     if (hp->B < 2 || hp->B > 64) return fail(MFAS_EINVAL, "batchsize must be in [2,64]");
+    {
+        const int bp = ((hp->B + 15) / 16 == 3 ? 4 : (hp->B + 15) / 16) * 16, lpr = std::min(16, 512 / bp);
+        if (((hp->C + 15) & ~15) > 8 * lpr) return fail(MFAS_EINVAL, "num_outputs too large for this batch size (C_padded <= 8 * min(16, 512/B_padded))");
+    }
     if (!(hp->drpt > 1e-10) && !hp->bn)   // ntu_searchable.py:274-284: `op` never assigned
         return fail(MFAS_EINVAL, "illegal cell variant: drpt < 1e-10 without batchnorm (reference: UnboundLocalError)");
     if (hp->drpt >= 1.0) return fail(MFAS_EINVAL, "drpt must be < 1");
@@ -1371,7 +1523,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         while (target > 64 && tot_cols / target < 320.0) target >>= 1;           // ... but keep >= ~320 workgroups
         // R >= 128, measured on MI355X: 64-column chunks (finer, better-balanced workgroups) win once
         // the chain is hidden under the other group's sweep (K >= 24); below that fewer partial chunks matter more
-        if (g.nrb >= 8) target = std::min(target, K >= 24 ? 64 : 128);
+        if (g.nrb >= 8) target = std::min(target, K >= 24 ? 64 : 256);
     }
     target = std::max(16, (target / 16) * 16);
     p->cands.resize(K);
@@ -1508,6 +1660,9 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         const size_t yf = (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.nrb * g.MB * 256 * 4;
         p->yf_in_lds = base + yf <= std::max<size_t>(ls, 64 * 1024);
         p->lds_step = std::max(ls, base + (p->yf_in_lds ? yf : 0));
+        const size_t vec = (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp) * 4;
+        p->vec_in_lds = base + (p->yf_in_lds ? yf : 0) + vec <= 150 * 1024;
+        p->lds_chain = base + (p->yf_in_lds ? yf : 0) + (p->vec_in_lds ? vec : 0);
     }
     p->nrbw = (g.nrb + 3) / 4;
     if (p->nrbw == 3) p->nrbw = 4;
@@ -1535,7 +1690,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(hipMalloc(&p->stepbuf, sizeof(float) * (size_t)p->step_total));
     CREATE_CHK(hipMalloc(&p->d_cands, sizeof(CandDev) * K));
     CREATE_CHK(hipMalloc(&p->d_descs, sizeof(SegDesc) * p->descs.size()));
-    CREATE_CHK(hipMalloc(&p->d_status, sizeof(int32_t) * K));
+    CREATE_CHK(hipMalloc(&p->d_status, sizeof(int32_t) * (K + 128)));   // + debug timestamp slots (MFAS_CHAIN_TIMING builds)
     CREATE_CHK(hipMalloc(&p->d_seeds, sizeof(uint32_t) * K));
     CREATE_CHK(hipMalloc(&p->d_corr, sizeof(long long)));
     {
@@ -1586,6 +1741,9 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(set_lds((k_step<1, true>), p->lds_step));
     CREATE_CHK(set_lds((k_step<2, true>), p->lds_step));
     CREATE_CHK(set_lds((k_step<4, true>), p->lds_step));
+    CREATE_CHK(set_lds(k_chain<1>, p->lds_chain));
+    CREATE_CHK(set_lds(k_chain<2>, p->lds_chain));
+    CREATE_CHK(set_lds(k_chain<4>, p->lds_chain));
     // W/m/v beyond what the 256 MiB Infinity Cache can keep between steps are streamed nontemporally
     p->nontemporal = (double)p->plane_stride * 12.0 > 200.0 * 1024 * 1024;
     if (const char* e = getenv("MFAS_NT")) p->nontemporal = atoi(e) != 0;
@@ -1729,6 +1887,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     st.ca.plane = p->plane; st.ca.plane_stride = p->plane_stride; st.ca.wt = p->wt; st.ca.stepbuf = p->stepbuf;
     st.ca.tab = *train; st.ca.order = order; st.ca.E = epochs; st.ca.g = g; st.ca.stats = p->d_stats;
     st.ca.status = p->d_status; st.ca.ac = ac; st.ca.yf_in_lds = p->yf_in_lds ? 1 : 0; st.ca.pos_w = p->d_posw;
+    st.ca.vec_in_lds = p->vec_in_lds ? 1 : 0;
 
     const int elt = train->dtype == MFAS_DT_F32 ? 4 : 2;
     p->prof_launches = 0; p->prof_ms = 0.0; p->prof_bytes = 0.0;
@@ -1772,6 +1931,12 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
                 p->ev.push_back(e0); p->ev.push_back(e1);
             }
             hipEventRecord(p->ev[ev_used], p->stream);
+        }
+        if (nsw == 0) {   // chain only: the latency-tuned standalone kernel
+            if (g.MB == 1) hipLaunchKernelGGL(k_chain<1>, dim3(nch), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca);
+            else if (g.MB == 2) hipLaunchKernelGGL(k_chain<2>, dim3(nch), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca);
+            else hipLaunchKernelGGL(k_chain<4>, dim3(nch), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca);
+            return;
         }
 #define STEP_LAUNCH(M, T) hipLaunchKernelGGL((k_step<M, T>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
         if (p->nontemporal) { if (g.MB == 1) STEP_LAUNCH(1, true); else if (g.MB == 2) STEP_LAUNCH(2, true); else STEP_LAUNCH(4, true); }
@@ -1844,6 +2009,16 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         stats[i].dev_corrects = hstats[i].dev_corr;
     }
     if (status) memcpy(status, hstatus.data(), sizeof(int32_t) * K);
+#ifdef MFAS_CHAIN_TIMING
+    {
+        int32_t ts[16];
+        if (hipMemcpy(ts, p->d_status + 64, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[chain timing, shader cycles since kernel entry, candidate 0 step 3]");
+            for (int i = 0; i < 13; ++i) fprintf(stderr, " %d", ts[i]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     if (p->profiling) {
         for (size_t i = 0; i + 1 < ev_used; i += 2) {
             float ms = 0.f;
