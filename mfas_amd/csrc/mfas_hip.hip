@@ -1084,16 +1084,18 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
     constexpr int ME = MBE * 16;
     const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
     const int SX = Rp + 4, SC = Cp + 4, SS = EVAL_CE + 4;
-    float* xs = lds;                     // [ME][SS]
-    float* xo_l = xs + ME * SS;          // [2][ME][SX]
-    float* lg_l = xo_l + 2 * ME * SX;    // [ME][SC]
+    // LDS kept to <= 80 KiB so that two workgroups share a CU (one stages features while the other runs MFMAs):
+    // ONE activation buffer (extra barrier per cell) and the logits alias the feature staging tile.
+    float* xs = lds;                     // [ME][SS]   feature staging tile; later the logits [ME][SC]
+    float* xo_l = xs + ME * max(SS, SC); // [ME][SX]   out_{i-1} -> out_i
+    float* lg_l = xs;
     const float* W = a.plane;
     const int64_t brow = a.row0 + (int64_t)blockIdx.x * ME;
     const int nvalid = (int)min((int64_t)ME, a.row0 + a.nrows - brow);
 
     for (int i = 0; i < L; ++i) {
-        const float* xprev = xo_l + ((i + 1) & 1) * ME * SX;
-        float* xcur = xo_l + (i & 1) * ME * SX;
+        const float* xprev = xo_l;
+        float* xcur = xo_l;
         const int nl = cd.conf[i][2];
         const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
         float sgS = 1.0f, sgV = 1.0f;
@@ -1147,11 +1149,11 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
 #pragma unroll
                 for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * sgV;
         }
+        if (i > 0) {
 #pragma unroll
-        for (int j = 0; j < NRBW; ++j) {
-            const int rb = wave + 4 * j;
-            if (rb < nrb) {
-                if (i > 0) {
+            for (int j = 0; j < NRBW; ++j) {
+                const int rb = wave + 4 * j;
+                if (rb < nrb) {
                     for (int kb = 0; kb < nrb; ++kb) {
                         const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][2], Rp, Rp, rb, kb) + lane * 4);
 #pragma unroll
@@ -1162,6 +1164,13 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
                         }
                     }
                 }
+            }
+            __syncthreads();   // every wave is done reading out_{i-1} before out_i overwrites it
+        }
+#pragma unroll
+        for (int j = 0; j < NRBW; ++j) {
+            const int rb = wave + 4 * j;
+            if (rb < nrb) {
                 const int r = rb * 16 + l15;
                 const float bias = W[vb + VEC_B * Rp + r];
                 float sc = 1.0f, sh = 0.0f, rm = 0.0f;
@@ -1186,7 +1195,7 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
         __syncthreads();
     }
     {
-        const float* xl = xo_l + ((L - 1) & 1) * ME * SX;
+        const float* xl = xo_l;
         for (int cb = wave; cb < ncb; cb += 4) {
             f32x4 hacc[MBE];
 #pragma unroll
@@ -1668,8 +1677,8 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     if (p->nrbw == 3) p->nrbw = 4;
     for (p->mbe = 4; p->mbe >= 1; p->mbe >>= 1) {
         const int ME = p->mbe * 16;
-        p->lds_eval = ((size_t)ME * (EVAL_CE + 4) + (size_t)2 * ME * (g.Rp + 4) + (size_t)ME * (g.Cp + 4)) * 4;
-        if (p->lds_eval <= 120 * 1024) break;
+        p->lds_eval = ((size_t)ME * std::max(EVAL_CE + 4, g.Cp + 4) + (size_t)ME * (g.Rp + 4)) * 4;
+        if (p->lds_eval <= 80 * 1024) break;
     }
     if (p->mbe < 1 || p->nrbw > 8 || p->lds_step > 150 * 1024) {
         delete p;
