@@ -363,3 +363,48 @@ def test_odd_sizes_R24_B20(dev):
             continue
         assert frac_bad(got[key].numpy(), v, 2e-3, 2e-5) <= 0.05, key
     pop.close()
+
+
+def test_full_size_properties(dev):
+    """BASELINE configs[1] at full size (conf 4, R=128, BN, drpt 0.5, B=16, N_train=10,000, N_dev=5,600, bf16 taps;
+    E shortened to 2): size-independent properties instead of an oracle run —
+    (1) the fused two-group schedule and the back-to-back schedule are bit-identical,
+    (2) a candidate's trajectory does not depend on the rest of the population (lockstep independence),
+    (3) identical seeds -> identical results; different dropout seeds -> different trajectories, same regime,
+    (4) training works: loss falls, dev accuracy far above chance, counters are consistent."""
+    import os
+    from mfas_amd import FeatureTable, Hyper, Population
+    hp = Hyper(R=128, C=60, B=16, bn=True, drpt=0.5)
+    conf = np.array(CONFS["c4"])
+    tr = FeatureTable.synthetic(10000, 1, dev, torch.bfloat16, snr=0.15)
+    dv = FeatureTable.synthetic(5600, 2, dev, torch.bfloat16, snr=0.15)
+    nb = 625
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, 10000 / 16, 2 * nb)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    order = torch.stack([torch.randperm(10000, generator=g, device=dev) for _ in range(2)]).to(torch.int32)
+
+    def run(K, groups, seeds):
+        os.environ["MFAS_GROUPS"] = str(groups)
+        try:
+            pop = Population(hp, [conf] * K, dev, drop_seeds=seeds, chunk_cols=128)   # same chunking = same summation order
+        finally:
+            del os.environ["MFAS_GROUPS"]
+        pop.init([100 + s for s in seeds])
+        stats, status = pop.train(tr, dv, 2, etas, order=order)
+        pop.close()
+        assert not status.any()
+        return stats
+
+    seeds = list(range(8))
+    a = run(8, 2, seeds)
+    b = run(8, 1, seeds)
+    assert a.tobytes() == b.tobytes(), "fused vs back-to-back schedule differ"   # (1)
+    c = run(3, 1, [5, 2, 7])
+    for j, s_ in enumerate([5, 2, 7]):
+        assert c[j].tobytes() == a[s_].tobytes(), "population-dependent result"   # (2) + (3)
+    assert len({a[k]["dev_corrects"][1] for k in range(8)}) > 1         # different seeds really differ
+    for k in range(8):                                                  # (4)
+        assert a[k]["train_loss_sum"][1] < a[k]["train_loss_sum"][0] < 10000 * np.log(60) * 1.05
+        assert a[k]["dev_corrects"][1] > 0.5 * 5600
+        assert 0 <= a[k]["train_corrects"][0] <= 10000 and 0 <= a[k]["dev_corrects"][0] <= 5600
