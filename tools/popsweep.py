@@ -2,7 +2,7 @@ import subprocess, sys, json, os
 pops = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "8,16,32,64".split(","))]
 extra = sys.argv[2:] 
 for pop in pops:
-    out = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--pop", str(pop), "--no-cpu-baseline"] + extra, capture_output=True, text=True)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--steps", "1", "--warmup", "1", "--pop", str(pop), "--no-cpu-baseline"] + extra, capture_output=True, text=True)
     ok = False
     for ln in out.stdout.splitlines():
         if ln.startswith("{"):
