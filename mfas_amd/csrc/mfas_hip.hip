@@ -1532,7 +1532,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         while (target > 64 && tot_cols / target < 320.0) target >>= 1;           // ... but keep >= ~320 workgroups
         // R >= 128, measured on MI355X: 64-column chunks (finer, better-balanced workgroups) win once
         // the chain is hidden under the other group's sweep (K >= 24); below that fewer partial chunks matter more
-        if (g.nrb >= 8) target = std::min(target, K >= 24 ? 64 : 256);
+        if (g.nrb >= 8) target = std::min(target, K >= 24 ? 64 : 256);   // (K >= 24 at R >= 128 <=> fused schedule)
     }
     target = std::max(16, (target / 16) * 16);
     p->cands.resize(K);
@@ -1710,8 +1710,9 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(hipMemcpy(p->d_cands, p->cands.data(), sizeof(CandDev) * K, hipMemcpyHostToDevice));
     CREATE_CHK(hipMemcpy(p->d_descs, p->descs.data(), sizeof(SegDesc) * p->descs.size(), hipMemcpyHostToDevice));
     {   // candidate groups: two halves balanced by work (descriptor columns), contiguous ranges
-        // Two groups (chain of one hidden under the sweep of the other) pay off once a group's sweep outlasts the
-        // ~50 us chain, i.e. from ~12 candidates per group; smaller populations run chain and sweep back to back.
+        // Two groups (the chain of one runs under the sweep of the other).  Measured on MI355X: pays from ~24 candidates
+        // both at R=128 (a group's sweep then outlasts the ~50 us chain) and at R=16 (two half-size chain launches under
+        // the sweeps beat chain + sweep back to back: 124 vs 105 cand/s at 50 candidates).
         int ngroups = K >= 24 ? 2 : 1;
         if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
         int split = K;
