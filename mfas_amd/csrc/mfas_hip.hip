@@ -1526,7 +1526,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             for (int i = 0; i < n_cells[k]; ++i)
                 tot_cols += hp->s_sizes[confs[(k * 4 + i) * 3] & 3] + hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 3];
         int lds_max = 64;                                   // largest power of two with Bp*(2cc+20)*4 <= 72 KiB
-        while ((size_t)g.Bp * (4 * lds_max + 20) * 4 <= 72 * 1024 && lds_max < 1024) lds_max <<= 1;
+        while ((size_t)g.Bp * (8 * lds_max + 20) * 4 <= 72 * 1024 && lds_max < 1024) lds_max <<= 1;   // test the doubled size
         target = 64;
         while (target * g.nrb < 64 * 16 && target < lds_max) target <<= 1;      // >= 64 tiles per workgroup
         while (target > 64 && tot_cols / target < 320.0) target >>= 1;           // ... but keep >= ~320 workgroups
@@ -1661,7 +1661,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         for (const SegDesc& d : p->descs) {
             const int nrb = d.rows_p / 16;
             size_t fl = (size_t)g.Bp * (d.cc + 16) + (size_t)g.Bp * (d.cc + 4) + (size_t)g.Bp * (d.rows_p + 16);
-            if (nrb < STEP_NW) fl += (size_t)STEP_NW * nrb * g.MB * 256;
+            if (nrb < STEP_NW && d.kind <= KIND_V) fl += (size_t)STEP_NW * nrb * g.MB * 256;   // k-split reduction (forward only)
             ls = std::max(ls, fl * 4);
         }
         // chain: ping-pong activations + logits + misc (+ reduced feature sums when they fit next to the sweep's need)

@@ -408,3 +408,22 @@ def test_full_size_properties(dev):
         assert a[k]["train_loss_sum"][1] < a[k]["train_loss_sum"][0] < 10000 * np.log(60) * 1.05
         assert a[k]["dev_corrects"][1] > 0.5 * 5600
         assert 0 <= a[k]["train_corrects"][0] <= 10000 and 0 <= a[k]["dev_corrects"][0] <= 5600
+
+
+@pytest.mark.parametrize("B,R", [(48, 16), (33, 128)])
+def test_large_batch_paths(dev, B, R):
+    """batch > 32 runs the MB=4 (64 padded rows) instantiation; 33 leaves the last 31 padded rows inert."""
+    ohp = O.Hyper(R=R, B=B, bn=True, drpt=0.25, epochs=2)
+    conf = np.array(CONFS["l2"])
+    N = 2 * B + 7
+    ttr, tdv = O.synth_table(N, 81, snr=0.5), O.synth_table(50, 82, snr=0.5)
+    pop = mk_pop(ohp, [conf], dev, drop_seeds=[4])
+    pop.set_state_dict(0, O.init_params(conf, ohp, 8))
+    stats, status = pop.train(table(ttr, dev), table(tdv, dev), 2, etas_for(ohp, N))
+    hist = []
+    O.train_candidate(conf, ohp, O.init_params(conf, ohp, 8), ttr, tdv, seed=4, history=hist)
+    for e in range(2):
+        assert abs(stats["train_loss_sum"][0, e] / N - hist[e]["train_loss"]) < 2e-3
+        assert abs(stats["dev_corrects"][0, e] - hist[e]["dev_corrects"]) <= 1
+    assert not status.any()
+    pop.close()
