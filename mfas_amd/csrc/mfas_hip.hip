@@ -69,6 +69,14 @@ struct SegDesc {          // one workgroup of k_sweep / k_pack
     float init_bound;
 };
 
+#define TAP_MAX_ITEMS 8
+struct TapDesc {          // tap-major workgroup (R < 128): one feature chunk shared by up to 8 segments of that tap
+    int32_t kind, tap, k0, cc;      // modality (KIND_S / KIND_V), tap index, first column, columns
+    int32_t rows_p, width, nitems, _pad;
+    int32_t cand[TAP_MAX_ITEMS], cell[TAP_MAX_ITEMS], part_idx[TAP_MAX_ITEMS];
+    int64_t w_off[TAP_MAX_ITEMS];   // plane offset of each item's chunk: tiles [rb][kb][256]
+};
+
 struct CandDev {
     int32_t L;
     int32_t conf[MFAS_MAX_CELLS][3];
@@ -244,6 +252,8 @@ __device__ __forceinline__ void stage_f32(float* dst, int stride, const float* s
 // ------------------------------------------------------------------------------------------------
 struct SweepArgs {
     const SegDesc* desc;
+    const TapDesc* tdesc;   // tap-major work list (may be empty)
+    int32_t ntap, _padt;
     const CandDev* cands;
     float* plane;
     int64_t plane_stride;
@@ -408,6 +418,115 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, fl
         for (int w = 1; w < STEP_NW; ++w)
             s += *reinterpret_cast<const f32x4*>(wred + ((w * nrb * MB + slot) << 8) + ln * 4);
         *reinterpret_cast<f32x4*>(part + (slot << 8) + ln * 4) = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweep_tap_body — the same fused dW + Adam + next-step forward for SMALL R (1, 2 or 4 row blocks): a column chunk of
+// ONE feature tap is staged once and shared by up to 8/nrb segments (candidates x cells) that read this tap; every wave
+// owns one (segment, row block), streams its contiguous tiles and writes its forward partial directly — no cross-wave
+// reduction, and the feature staging (1/3 of the traffic at R=16) is amortised over the segments.
+// ------------------------------------------------------------------------------------------------
+template <int MB, bool NT>
+__device__ __forceinline__ void sweep_tap_body(const SweepArgs& a, const int bid, float* lds) {
+    const TapDesc& d = a.tdesc[bid];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int Bp = MB * 16;
+    const int cc = d.cc, rows_p = d.rows_p, nrb = rows_p >> 4, nkb = cc >> 4;
+    const int ST = cc + 16, SN = cc + 4;
+    float* xt = lds;
+    float* xn = xt + Bp * ST;
+    const bool upd = a.do_update != 0;
+    const bool fwd = a.do_forward != 0;
+    if (!upd && !fwd) return;
+    const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
+    if (upd) stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_t, a.base_t, a.nvalid_t, Bp, tid, STEP_THREADS);
+    if (fwd) stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_n, a.base_n, a.nvalid_n, Bp, tid, STEP_THREADS);
+    __syncthreads();
+    const int item = wave / nrb, rb = wave - item * nrb;
+    if (item >= d.nitems) return;
+    const CandDev& cd = a.cands[d.cand[item]];
+    float* sb = a.stepbuf + cd.step_off;
+    const int cell = d.cell[item];
+    float dyf[MB * 4];
+#pragma unroll
+    for (int j = 0; j < MB * 4; ++j) dyf[j] = 0.f;
+    if (upd) {
+        const float* dsrc = sb + a.g.sb_dy + (int64_t)cell * Bp * a.g.Rp;
+#pragma unroll
+        for (int j = 0; j < MB * 4; ++j) dyf[j] = dsrc[(4 * j + lg) * rows_p + rb * 16 + l15];
+    }
+    float gsc = 1.0f;
+    if (a.g.alphas && upd) gsc = sb[a.g.sb_gsc + cell * 2 + d.kind];
+    float* Wp = a.plane + d.w_off[item];
+    float* Mp = Wp + a.plane_stride;
+    float* Vp = Mp + a.plane_stride;
+    const AdamC ac = a.ac;
+    f32x4 yacc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kbb = 0; kbb < nkb; kbb += SWEEP_U) {
+        f32x4 w4[SWEEP_U], m4[SWEEP_U], v4[SWEEP_U];
+#pragma unroll
+        for (int u = 0; u < SWEEP_U; ++u) {
+            const int kb = kbb + u;
+            if (kb < nkb) {
+                const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+                w4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Wp + off))
+                           : *reinterpret_cast<const f32x4*>(Wp + off);
+                if (upd) {
+                    m4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mp + off))
+                               : *reinterpret_cast<const f32x4*>(Mp + off);
+                    v4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vp + off))
+                               : *reinterpret_cast<const f32x4*>(Vp + off);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SWEEP_U; ++u) {
+            const int kb = kbb + u;
+            if (kb < nkb) {
+                const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+                if (upd) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < MB * 4; ++j)
+                        acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float w = w4[u][q], m = m4[u][q], v = v4[u][q];
+                        adam1(w, m, v, acc[q] * gsc, ac);
+                        w4[u][q] = w;
+                        m4[u][q] = m;
+                        v4[u][q] = v;
+                    }
+                    if (NT) {
+                        __builtin_nontemporal_store(w4[u], reinterpret_cast<f32x4*>(Wp + off));
+                        __builtin_nontemporal_store(m4[u], reinterpret_cast<f32x4*>(Mp + off));
+                        __builtin_nontemporal_store(v4[u], reinterpret_cast<f32x4*>(Vp + off));
+                    } else {
+                        *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
+                        *reinterpret_cast<f32x4*>(Mp + off) = m4[u];
+                        *reinterpret_cast<f32x4*>(Vp + off) = v4[u];
+                    }
+                }
+                if (fwd) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * SN + kb * 16 + 4 * lg);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][q], yacc[mb]);
+                    }
+                }
+            }
+        }
+    }
+    if (fwd) {
+        float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[cell] + d.part_idx[item]) * nrb * MB) << 8);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            *reinterpret_cast<f32x4*>(part + ((rb * MB + mb) << 8) + lane * 4) = yacc[mb];
     }
 }
 
@@ -1042,8 +1161,10 @@ struct StepArgs {
 template <int MB, bool NT>
 __global__ void __launch_bounds__(STEP_THREADS, (MB == 1 ? 4 : 2)) k_step(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x < a.nchain) chain_body<MB, false>(a.ca, (int)blockIdx.x, lds);
-    else sweep_body<MB, NT>(a.sa, (int)blockIdx.x - a.nchain, lds);
+    const int bid = (int)blockIdx.x;
+    if (bid < a.nchain) chain_body<MB, false>(a.ca, bid, lds);
+    else if (bid < a.nchain + a.sa.ntap) sweep_tap_body<MB, NT>(a.sa, bid - a.nchain, lds);
+    else sweep_body<MB, NT>(a.sa, bid - a.nchain - a.sa.ntap, lds);
 }
 
 // Standalone chain launch (small populations: chain and sweep run back to back, so the chain's latency is on the
@@ -1433,7 +1554,8 @@ struct mfas_population {
     int64_t plane_stride = 0, wt_size = 0, step_total = 0;
     CandDev* d_cands = nullptr;
     SegDesc* d_descs = nullptr;
-    struct Group { int c0 = 0, nc = 0, ndesc = 0; SegDesc* d_descs = nullptr; double alg_state = 0, alg_feat = 0; };
+    struct Group { int c0 = 0, nc = 0, ndesc = 0, ntap = 0; SegDesc* d_descs = nullptr; TapDesc* d_taps = nullptr;
+                   double alg_state = 0, alg_feat = 0; };
     std::vector<Group> groups;           // 1 or 2 contiguous candidate ranges, each with its own sweep work list
     DevStats* d_stats = nullptr;
     int32_t* d_status = nullptr;
@@ -1730,15 +1852,55 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             mfas_population::Group gr;
             gr.c0 = gi == 0 ? 0 : split;
             gr.nc = gi == 0 ? split : K - split;
-            std::vector<SegDesc> sorted(p->descs.begin() + p->desc_start[gr.c0], p->descs.begin() + p->desc_start[gr.c0 + gr.nc]);
-            std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) { return x.cc * x.rows_p > y.cc * y.rows_p; });
-            gr.ndesc = (int)sorted.size();
-            for (const SegDesc& d : sorted) {
+            std::vector<SegDesc> all(p->descs.begin() + p->desc_start[gr.c0], p->descs.begin() + p->desc_start[gr.c0 + gr.nc]);
+            for (const SegDesc& d : all) {
                 gr.alg_state += 24.0 * d.rows * std::min(d.cc, d.cols - d.k0);
                 if (d.kind <= KIND_V) gr.alg_feat += (double)hp->B * d.cc;
             }
-            CREATE_CHK(hipMalloc(&gr.d_descs, sizeof(SegDesc) * sorted.size()));
+            // small R (1, 2 or 4 row blocks): feature segments are regrouped tap-major (sweep_tap_body)
+            std::vector<SegDesc> sorted;
+            std::vector<TapDesc> taps;
+            const bool tap_major = (g.nrb == 1 || g.nrb == 2 || g.nrb == 4) && !getenv("MFAS_NO_TAP_MAJOR");
+            if (tap_major) {
+                const int per_wg = STEP_NW / g.nrb;
+                std::vector<const SegDesc*> feat;
+                for (const SegDesc& d : all) { if (d.kind <= KIND_V) feat.push_back(&d); else sorted.push_back(d); }
+                std::stable_sort(feat.begin(), feat.end(), [](const SegDesc* x, const SegDesc* y) {
+                    if (x->kind != y->kind) return x->kind < y->kind;
+                    if (x->tap != y->tap) return x->tap < y->tap;
+                    if (x->cc != y->cc) return x->cc < y->cc;
+                    return x->k0 < y->k0;
+                });
+                for (size_t i0 = 0; i0 < feat.size();) {
+                    TapDesc t;
+                    memset(&t, 0, sizeof(t));
+                    const SegDesc* f0 = feat[i0];
+                    t.kind = f0->kind; t.tap = f0->tap; t.k0 = f0->k0; t.cc = f0->cc; t.rows_p = f0->rows_p; t.width = f0->width;
+                    while (i0 < feat.size() && t.nitems < per_wg && feat[i0]->kind == t.kind && feat[i0]->tap == t.tap &&
+                           feat[i0]->k0 == t.k0 && feat[i0]->cc == t.cc) {
+                        t.cand[t.nitems] = feat[i0]->cand; t.cell[t.nitems] = feat[i0]->cell;
+                        t.part_idx[t.nitems] = feat[i0]->part_idx; t.w_off[t.nitems] = feat[i0]->w_off;
+                        ++t.nitems; ++i0;
+                    }
+                    taps.push_back(t);
+                }
+                std::stable_sort(taps.begin(), taps.end(), [](const TapDesc& x, const TapDesc& y) { return x.nitems * x.cc > y.nitems * y.cc; });
+                if (taps.size() < 192 && !getenv("MFAS_FORCE_TAP_MAJOR")) {   // too few workgroups to fill 256 CUs: per-segment path
+                    taps.clear();
+                    sorted = all;
+                }
+            } else {
+                sorted = all;
+            }
+            std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) { return x.cc * x.rows_p > y.cc * y.rows_p; });
+            gr.ndesc = (int)sorted.size();
+            gr.ntap = (int)taps.size();
+            CREATE_CHK(hipMalloc(&gr.d_descs, sizeof(SegDesc) * std::max<size_t>(sorted.size(), 1)));
             CREATE_CHK(hipMemcpy(gr.d_descs, sorted.data(), sizeof(SegDesc) * sorted.size(), hipMemcpyHostToDevice));
+            if (!taps.empty()) {
+                CREATE_CHK(hipMalloc(&gr.d_taps, sizeof(TapDesc) * taps.size()));
+                CREATE_CHK(hipMemcpy(gr.d_taps, taps.data(), sizeof(TapDesc) * taps.size(), hipMemcpyHostToDevice));
+            }
             p->groups.push_back(gr);
         }
     }
@@ -1768,7 +1930,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->ev) hipEventDestroy(e);
     hipFree(p->plane); hipFree(p->wt); hipFree(p->stepbuf); hipFree(p->best);
-    for (auto& gr : p->groups) hipFree(gr.d_descs);
+    for (auto& gr : p->groups) { hipFree(gr.d_descs); hipFree(gr.d_taps); }
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
     hipFree(p->d_seeds); hipFree(p->d_corr); hipFree(p->d_posw);
     delete p;
@@ -1911,6 +2073,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         if (gs >= 0) {
             SweepArgs& s = st.sa;
             s.desc = p->groups[gs].d_descs;
+            s.tdesc = p->groups[gs].d_taps; s.ntap = p->groups[gs].ntap;
             s.do_update = upd; s.do_forward = fwd;
             s.pos_t = ep * N + ts * B; s.base_t = (int)(ts * B);
             s.nvalid_t = (int)std::min<int64_t>(B, N - ts * B);
@@ -1920,7 +2083,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             const int64_t gstep = ep * nb + ts;
             s.ac.ss = upd ? step_scalars[2 * gstep] : 0.f;
             s.ac.bc2s = upd ? step_scalars[2 * gstep + 1] : 1.f;
-            nsw = (unsigned)p->groups[gs].ndesc;
+            nsw = (unsigned)(p->groups[gs].ndesc + p->groups[gs].ntap);
         }
         if (gc >= 0) {
             ChainArgs& c = st.ca;
@@ -1933,6 +2096,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             nch = (unsigned)p->groups[gc].nc;
         }
         st.nchain = (int)nch;
+        if (gs < 0) { st.sa.ntap = 0; }
         const bool prof = p->profiling && gs >= 0 && upd && fwd && ((nlaunch++ % p->prof_every) == 0);
         if (prof) {
             if (p->ev.size() < ev_used + 2) {

@@ -297,6 +297,17 @@ def test_lockstep_independence_and_determinism(dev):
     finally:
         del os.environ["MFAS_GROUPS"]
     assert f == a                         # scheduling must not change a single bit
+    os.environ["MFAS_FORCE_TAP_MAJOR"] = "1"   # small-R tap-major sweep (one feature chunk shared by several segments)
+    try:
+        t1 = run([0, 1, 2, 3, 4], 0)
+        t2 = run([4, 2, 0], 0)
+    finally:
+        del os.environ["MFAS_FORCE_TAP_MAJOR"]
+    for i in (0, 2, 4):
+        assert t1[i] == t2[i], i          # grouping segments into workgroups does not change a candidate's arithmetic
+    for i in range(5):                    # vs the per-segment path: summation order differs, results agree closely
+        assert max(abs(x - y) for x, y in zip(a[i][0], t1[i][0])) <= 3
+        assert max(abs(x - y) for x, y in zip(a[i][1], t1[i][1])) < 0.5
     b = run([4, 2, 0], 0)
     c = run([0, 1, 2, 3, 4], 0)
     for i in (0, 2, 4):
@@ -427,3 +438,28 @@ def test_large_batch_paths(dev, B, R):
         assert abs(stats["dev_corrects"][0, e] - hist[e]["dev_corrects"]) <= 1
     assert not status.any()
     pop.close()
+
+
+def test_tap_major_sweep_vs_oracle(dev):
+    """Forced tap-major sweep (R=16 and R=32, mixed depths sharing taps) against the oracle trajectory."""
+    import os
+    for R in (16, 32):
+        ohp = O.Hyper(R=R, B=20, bn=True, drpt=0.3, epochs=2)
+        confs = [np.array(CONFS[c]) for c in ("c4", "c0", "l1", "l2", "l3", "c4")]
+        ttr, tdv = O.synth_table(130, 91, snr=0.5), O.synth_table(70, 92, snr=0.5)
+        os.environ["MFAS_FORCE_TAP_MAJOR"] = "1"
+        try:
+            pop = mk_pop(ohp, confs, dev, drop_seeds=list(range(20, 26)))
+        finally:
+            del os.environ["MFAS_FORCE_TAP_MAJOR"]
+        for k, c in enumerate(confs):
+            pop.set_state_dict(k, O.init_params(c, ohp, 60 + k))
+        stats, status = pop.train(table(ttr, dev), table(tdv, dev), 2, etas_for(ohp, 130))
+        for k, c in enumerate(confs):
+            hist = []
+            O.train_candidate(c, ohp, O.init_params(c, ohp, 60 + k), ttr, tdv, seed=20 + k, history=hist)
+            for e in range(2):
+                assert abs(stats["train_loss_sum"][k, e] / 130 - hist[e]["train_loss"]) < 2e-3, (R, k, e)
+                assert abs(stats["dev_corrects"][k, e] - hist[e]["dev_corrects"]) <= 1, (R, k, e)
+        assert not status.any()
+        pop.close()
