@@ -56,10 +56,9 @@ static int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------------
 struct SegDesc {          // one workgroup of k_sweep / k_pack
     int32_t cand, kind, cell, tap;
-    int32_t k0, cc;       // first column inside the segment and column count of this workgroup's k-range
-    int32_t rb, _padrb;   // 16-row block handled by this workgroup
+    int32_t k0, cc;       // first column inside the segment, chunk columns (multiple of 16)
     int32_t rows_p, width;  // padded rows; FEAT: table row width (elements)
-    int64_t w_off;        // float offset (within a plane) of this (k-split, row block) run: tiles [kb][256]
+    int64_t w_off;        // float offset (within a plane) of this chunk: tiles [rb][kb][256]
     int64_t wt_off;       // OUT/HEAD: float offset in the transposed arena, else -1
     int32_t part_idx;     // FEAT: chunk index within the cell's partial list
     int32_t rows, cols;   // true rows (R or C) / true columns of the whole segment
@@ -136,23 +135,6 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
-__host__ __device__ static inline uint32_t lowbias32_h(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x7FEB352DU;
-    x ^= x >> 15;
-    x *= 0x846CA68BU;
-    x ^= x >> 16;
-    return x;
-}
-// oracle/np_oracle.py:hash_u01
-__host__ __device__ static inline float hash_u01(uint32_t h0, uint32_t idx) {
-    return (float)(lowbias32_h(idx ^ h0) >> 8) * (1.0f / 16777216.0f);
-}
-static inline uint32_t hash_h0(uint32_t seed) { return lowbias32_h(seed * 0x9E3779B9U + 0x7F4A7C15U); }
-static inline uint32_t param_seed(uint32_t seed, uint32_t slot) {
-    return (uint32_t)(((uint64_t)seed * 1000003ULL + (uint64_t)slot * 7919ULL + 17ULL) & 0x7FFFFFFFULL);
-}
-
 __device__ __forceinline__ float act_fwd(float y, int nl) {
     if (nl == 0) return fmaxf(y, 0.0f);
     if (nl == 1) return 1.0f / (1.0f + expf(-y));
@@ -1715,7 +1697,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
                     SegDesc d;
                     memset(&d, 0, sizeof(d));
                     d.cand = k; d.kind = j; d.cell = i; d.tap = j < 2 ? c.conf[i][j] : 0;
-                    d.k0 = ch * cc; d.cc = cc; d.rb = -1; d.rows_p = g.Rp; d.width = j < 2 ? widths[j] : g.Rp;
+                    d.k0 = ch * cc; d.cc = cc; d.rows_p = g.Rp; d.width = j < 2 ? widths[j] : g.Rp;
                     d.w_off = plane_off + (int64_t)ch * g.Rp * cc;
                     d.wt_off = j == 2 ? wt_off : -1;
                     d.part_idx = j < 2 ? (j == 0 ? ch : c.nch_s[i] + ch) : 0;
@@ -1740,7 +1722,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             SegDesc d;
             memset(&d, 0, sizeof(d));
             d.cand = k; d.kind = KIND_HEAD; d.cell = L - 1; d.tap = 0;
-            d.k0 = 0; d.cc = g.Rp; d.rb = -1; d.rows_p = g.Cp; d.width = g.Rp;
+            d.k0 = 0; d.cc = g.Rp; d.rows_p = g.Cp; d.width = g.Rp;
             d.w_off = plane_off; d.wt_off = wt_off; d.part_idx = 0;
             d.rows = hp->C; d.cols = hp->R;
             d.src_off = c.f_Wc; d.src_ld = hp->R; d.src_col0 = 0;
