@@ -136,12 +136,12 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ float act_fwd(float y, int nl) {
-    if (nl == 0) return fmaxf(y, 0.0f);
+    if (nl == 0) return y <= 0.0f ? 0.0f : y;   // torch.relu: NaN propagates (fmaxf would swallow it)
     if (nl == 1) return 1.0f / (1.0f + expf(-y));
     return y > 0.0f ? y : 0.01f * y;
 }
 __device__ __forceinline__ float act_bwd(float a, float da, int nl) {
-    if (nl == 0) return a > 0.0f ? da : 0.0f;
+    if (nl == 0) return a <= 0.0f ? 0.0f : da;  // threshold_backward(grad, result, 0)
     if (nl == 1) return da * (1.0f - a) * a;
     return a > 0.0f ? da : 0.01f * da;   // leaky: sign(a) == sign(y)
 }

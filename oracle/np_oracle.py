@@ -352,7 +352,7 @@ def backward(params, hp: Hyper, cache, dlogits, train_bn_stats=True):
             d_a = d_z
         nl = c["nl"]
         if nl == 0:
-            d_y = np.where(c["a"] > 0, d_a, F32(0)).astype(F32)
+            d_y = np.where(c["a"] <= 0, F32(0), d_a).astype(F32)     # threshold_backward: NaN activations pass the grad
         elif nl == 1:
             d_y = (d_a * (F32(1.0) - c["a"]) * c["a"]).astype(F32)
         else:

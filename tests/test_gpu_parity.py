@@ -463,3 +463,28 @@ def test_tap_major_sweep_vs_oracle(dev):
                 assert abs(stats["dev_corrects"][k, e] - hist[e]["dev_corrects"]) <= 1, (R, k, e)
         assert not status.any()
         pop.close()
+
+
+def test_nan_candidate_is_flagged_and_isolated(dev):
+    """A candidate that diverges (NaN weights) raises its status flag; its neighbours' results are unchanged."""
+    ohp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=2)
+    confs = [np.array(CONFS["l2"]), np.array(CONFS["l1"]), np.array(CONFS["l3"])]
+    ttr, tdv = O.synth_table(64, 21, snr=0.3), O.synth_table(48, 22, snr=0.3)
+
+    def run(poison):
+        pop = mk_pop(ohp, confs, dev)
+        for k, c in enumerate(confs):
+            p = O.init_params(c, ohp, 5 + k)
+            if poison and k == 1:
+                p["fusion_layers.0.0.weight"][3, 7] = np.nan
+            pop.set_state_dict(k, p)
+        stats, status = pop.train(table(ttr, dev), table(tdv, dev), 2, etas_for(ohp, 64))
+        pop.close()
+        return stats, status
+
+    clean, st0 = run(False)
+    bad, st1 = run(True)
+    assert st0.tolist() == [0, 0, 0] and st1.tolist() == [0, 1, 0]
+    for k in (0, 2):
+        assert clean[k].tobytes() == bad[k].tobytes()
+    assert not np.isfinite(bad[1]["train_loss_sum"]).all()
