@@ -126,6 +126,12 @@ int mfas_population_sweep_profile(const mfas_population* pop, int64_t* launches,
                                   double* bytes_per_launch);
 int mfas_population_set_profiling(mfas_population* pop, int32_t on);
 
+/* Replaces GlobalPooling2D.forward (models/auxiliary/aux_models.py:54-64; applied at ntu_searchable.py:224-225): mean over
+ * the `inner` trailing elements of each of the rows = B*C contiguous rows of a backbone tap (B, C, ...) -> out[rows].
+ * x / out are device pointers of dtype MFAS_DT_* ; f32 accumulation.  The step that builds an mfas_table from raw taps. */
+int mfas_global_pool(const void* x, int32_t dtype, int64_t rows, int64_t inner, void* out, int32_t out_dtype,
+                     void* hip_stream);
+
 /* loss_mode 1: per-class positive weights of WeightedCrossEntropyWithLogits (HOST float[C]; default all 1). */
 int mfas_population_set_pos_weight(mfas_population* pop, const float* pos_weight);
 

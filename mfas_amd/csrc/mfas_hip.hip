@@ -1516,6 +1516,56 @@ __global__ void __launch_bounds__(256) k_vec(const PackArgs a, int cand_fixed) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_pool — GlobalPooling2D (models/auxiliary/aux_models.py:54-64): mean over all trailing dims of a (B, C, ...) tap.
+// One wave per (b, c) row of `inner` contiguous elements, 16 B per lane per load, f32 accumulation, wave shuffle
+// reduction; pure HBM-bound reduction (the "step before the path" that builds the feature table).
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct PoolVec;
+template <> struct PoolVec<float> { static constexpr int N = 4; };
+template <> struct PoolVec<uint16_t> { static constexpr int N = 8; };
+
+__device__ __forceinline__ float pool_cvt(uint16_t v, int dtype) {
+    return dtype == MFAS_DT_BF16 ? __uint_as_float((uint32_t)v << 16) : __half2float(__ushort_as_half(v));
+}
+
+__global__ void __launch_bounds__(256) k_pool(const void* x, int dtype, int64_t rows, int64_t inner, void* out, int out_dtype) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float acc = 0.f;
+    if (dtype == MFAS_DT_F32) {
+        const float* p = reinterpret_cast<const float*>(x) + row * inner;
+        const int64_t nv = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? inner / 4 : 0;
+        for (int64_t i = lane; i < nv; i += 64) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+            acc += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (int64_t i = nv * 4 + lane; i < inner; i += 64) acc += p[i];
+    } else {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(x) + row * inner;
+        const int64_t nv = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? inner / 8 : 0;
+        for (int64_t i = lane; i < nv; i += 64) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc += pool_cvt((uint16_t)(w[j] & 0xFFFFU), dtype) + pool_cvt((uint16_t)(w[j] >> 16), dtype);
+        }
+        for (int64_t i = nv * 8 + lane; i < inner; i += 64) acc += pool_cvt(p[i], dtype);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        const float m = acc / (float)inner;
+        if (out_dtype == MFAS_DT_F32) reinterpret_cast<float*>(out)[row] = m;
+        else if (out_dtype == MFAS_DT_BF16) {
+            uint32_t u = __float_as_uint(m);
+            u += 0x7FFFU + ((u >> 16) & 1U);          // round to nearest even
+            reinterpret_cast<uint16_t*>(out)[row] = (uint16_t)(u >> 16);
+        } else reinterpret_cast<__half*>(out)[row] = __float2half(m);
+    }
+}
+
 // ================================================================================================
 // Host side: C ABI
 // ================================================================================================
@@ -2209,6 +2259,18 @@ extern "C" int mfas_population_forward(mfas_population* p, int32_t k, const mfas
         HIPCHK(hipStreamSynchronize(p->stream));
         *corrects = (int64_t)h;
     }
+    return MFAS_OK;
+}
+
+extern "C" int mfas_global_pool(const void* x, int32_t dtype, int64_t rows, int64_t inner, void* out, int32_t out_dtype,
+                                void* hip_stream) {
+    if (!x || !out || rows <= 0 || inner <= 0 || dtype < 0 || dtype > 2 || out_dtype < 0 || out_dtype > 2)
+        return fail(MFAS_EINVAL, "bad argument");
+    const int64_t nblk = (rows + 3) / 4;
+    if (nblk > 0x7FFFFFFF) return fail(MFAS_EINVAL, "too many rows");
+    hipLaunchKernelGGL(k_pool, dim3((unsigned)nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), x, (int)dtype,
+                       rows, inner, out, (int)out_dtype);
+    HIPCHK(hipGetLastError());
     return MFAS_OK;
 }
 

@@ -212,3 +212,33 @@ def test_population_sharding_two_ranks_matches_single(dev, tmp_path):
     single = run(1)[0]
     two = run(2)
     assert two[0] == two[1] == single and len(single) == 7
+
+
+def test_global_pooling_kernel(dev):
+    """GlobalPooling2D on the GPU: NTU tap shapes, all dtypes, odd inner sizes; plus its bandwidth."""
+    import time
+    from mfas_amd.pooling import build_feature_table, global_pool
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    for shape in [(3, 128, 4, 4), (2, 512, 8, 32, 32), (5, 7, 13), (4, 256, 2, 2), (2, 1024), (3, 9, 1001)]:
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            x = torch.randn(shape, generator=g, device=dev).to(dt)
+            got = global_pool(x, torch.float32)
+            want = x.float().reshape(shape[0], shape[1], -1).mean(2) if len(shape) > 2 else x.float()
+            torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+    x = torch.randn(4, 64, 8, 16, 16, generator=g, device=dev)
+    assert global_pool(x, torch.bfloat16).dtype == torch.bfloat16
+    torch.testing.assert_close(global_pool(x, torch.bfloat16).float(), x.reshape(4, 64, -1).mean(2), rtol=1e-2, atol=1e-3)
+    raw = {"s0": torch.randn(6, 128, 4, 4, device=dev), "v0": torch.randn(6, 512, 2, 8, 8, device=dev)}
+    t = build_feature_table(raw, torch.zeros(6, dtype=torch.int32, device=dev))
+    assert t.taps["v0"].shape == (6, 512) and t.dtype == torch.bfloat16
+    big = torch.randn(16, 512, 8, 32, 32, device=dev)          # v0-shaped: 16 samples x 16.8 MB
+    global_pool(big)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        global_pool(big)
+    torch.cuda.synchronize()
+    gbs = big.numel() * 4 * 10 / (time.perf_counter() - t0) / 1e9
+    print(f"global_pool: {gbs:.0f} GB/s on a 268 MB f32 tap")
+    assert gbs > 1000
