@@ -50,6 +50,8 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--random_search", action="store_true", default=False)
     p.add_argument("--engine_init", default="torch", choices=["torch", "device"])
+    p.add_argument("--controller_threads", type=int, default=4,
+                   help="torch CPU threads for the 81k-parameter surrogate (more threads only add overhead)")
     return p.parse_args(argv)
 
 
@@ -63,6 +65,7 @@ def main(argv=None):
     device = torch.device("cuda", local)
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=device)
+    torch.set_num_threads(max(1, args.controller_threads))
     torch.manual_seed(args.seed)          # every rank runs the same (seeded) controller
     np.random.seed(args.seed)
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.feature_dtype]

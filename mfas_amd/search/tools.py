@@ -28,7 +28,10 @@ def train_surrogate(surrogate, surrogate_dataloader, surrogate_optimizer, surrog
 
 
 def sample_k_configurations(configurations, accuracies_, k, temperature):
-    """p ∝ acc, tempered p^(1/T), k draws without replacement from the global numpy stream (tools.py:47-58)."""
+    """p ∝ acc, tempered p^(1/T), k draws without replacement from the global numpy stream (tools.py:47-58).
+    Departure: k is clamped to the number of configurations (the reference raises ValueError when num_samples exceeds
+    the 32 single-layer configurations of the first level, e.g. BASELINE config 4's --num_samples 50)."""
+    k = min(int(k), len(configurations))
     acc = np.array(accuracies_)
     p = acc / acc.sum()
     p = pow(p, 1.0 / temperature)
