@@ -1225,21 +1225,54 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
             }
             for (int c0 = 0; c0 < cols; c0 += EVAL_CE) {
                 const int nc = min(EVAL_CE, cols - c0);
-                __syncthreads();
-                stage_table(xs, SS, tp, a.tab.dtype, tw, c0, nc, nullptr, 0, (int)brow, nvalid, ME, tid, 256);
-                __syncthreads();
-                for (int kbl = 0; kbl < (nc >> 4); ++kbl) {
-                    const int kb = (c0 >> 4) + kbl;
+                if constexpr (NRBW <= 2) {
+                    // this chunk's weight tiles are requested BEFORE the feature staging so that their L2 latency
+                    // overlaps the staging barriers (8 k-blocks x NRBW row blocks = up to 64 VGPRs)
+                    f32x4 wt[EVAL_CE / 16][NRBW];
 #pragma unroll
-                    for (int j = 0; j < NRBW; ++j) {
-                        const int rb = wave + 4 * j;
-                        if (rb < nrb) {
-                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][sv], Rp, cc, rb, kb) + lane * 4);
+                    for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl)
 #pragma unroll
-                            for (int mb = 0; mb < MBE; ++mb) {
-                                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+                        for (int j = 0; j < NRBW; ++j) {
+                            const int rb = wave + 4 * j;
+                            if (kbl < (nc >> 4) && rb < nrb)
+                                wt[kbl][j] = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][sv], Rp, cc, rb, (c0 >> 4) + kbl) + lane * 4);
+                        }
+                    __syncthreads();
+                    stage_table(xs, SS, tp, a.tab.dtype, tw, c0, nc, nullptr, 0, (int)brow, nvalid, ME, tid, 256);
+                    __syncthreads();
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], w4[q], acc[j][mb]);
+                    for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl)
+                        if (kbl < (nc >> 4)) {
+#pragma unroll
+                            for (int j = 0; j < NRBW; ++j) {
+                                const int rb = wave + 4 * j;
+                                if (rb < nrb) {
+#pragma unroll
+                                    for (int mb = 0; mb < MBE; ++mb) {
+                                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], wt[kbl][j][q], acc[j][mb]);
+                                    }
+                                }
+                            }
+                        }
+                } else {
+                    __syncthreads();
+                    stage_table(xs, SS, tp, a.tab.dtype, tw, c0, nc, nullptr, 0, (int)brow, nvalid, ME, tid, 256);
+                    __syncthreads();
+                    for (int kbl = 0; kbl < (nc >> 4); ++kbl) {
+                        const int kb = (c0 >> 4) + kbl;
+#pragma unroll
+                        for (int j = 0; j < NRBW; ++j) {
+                            const int rb = wave + 4 * j;
+                            if (rb < nrb) {
+                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][sv], Rp, cc, rb, kb) + lane * 4);
+#pragma unroll
+                                for (int mb = 0; mb < MBE; ++mb) {
+                                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], w4[q], acc[j][mb]);
+                                }
                             }
                         }
                     }
