@@ -21,6 +21,7 @@ extern "C" {
 #define MFAS_ENOMEM -3
 
 #define MFAS_MAX_CELLS 4 /* max_fusions (main_searchable_ntu.py:39) */
+#define MFAS_MAX_TAPS 8  /* tap slots per modality (NTU uses 4+4, AV-MNIST 5+3, MM-IMDB 2+4) */
 
 #define MFAS_DT_F32 0
 #define MFAS_DT_BF16 1
@@ -37,22 +38,25 @@ typedef struct mfas_hyper {
     int32_t multitask;  /* args.multitask: argmax over central+visual+skeleton logits */
     double drpt;        /* args.drpt (<=1e-10: no Dropout module) */
     double wd, beta1, beta2, adam_eps, bn_eps, bn_momentum;
-    int32_t s_sizes[4]; /* skeleton tap widths (ntu_searchable.py:291) */
-    int32_t v_sizes[4]; /* visual tap widths   (ntu_searchable.py:292) */
+    int32_t s_sizes[MFAS_MAX_TAPS]; /* first-modality tap widths (skeleton: ntu_searchable.py:291; audio:
+                                     * avmnist_searchable.py:290-292); 0 = unused slot.  Any width >= 1: tables store
+                                     * each row padded with zeros to a multiple of 16 elements. */
+    int32_t v_sizes[MFAS_MAX_TAPS]; /* second-modality tap widths (visual: ntu_searchable.py:292) */
     /* Head loss / dev metric.  0: CrossEntropyLoss + top-1 accuracy (NTU, ntu_searchable.py:31).
      * 1: multi-label WeightedCrossEntropyWithLogits (models/central/mm_imdb.py:655-673) + F1 'samples' of
      *    sigmoid(logits) > f1_threshold (models/search/train_searchable/mmimdb.py:86,105). */
     int32_t loss_mode;
-    int32_t _pad;
+    int32_t allow_plain_cell; /* 1: [Linear, nl] cells (no BN, no Dropout) are legal (avmnist_searchable.py:276-285); the
+                               * NTU searchable leaves that case undefined (ntu_searchable.py:274-284) */
     double f1_threshold; /* th_fscore, mmimdb.py:16 (0.3) */
 } mfas_hyper;
 
 /* Pooled feature table = what Visual/Skeleton.forward + GlobalPooling2D hand to the fusion net
  * (models/central/ntu.py:35-50,129-183; ntu_searchable.py:211-225) for N samples, plus labels
- * (datasets/ntu.py:254).  Row-major (N, width) arrays. */
+ * (datasets/ntu.py:254). */
 typedef struct mfas_table {
-    const void* s[4];
-    const void* v[4];
+    const void* s[MFAS_MAX_TAPS]; /* (N, ceil16(width)) row-major, zero padded */
+    const void* v[MFAS_MAX_TAPS];
     const float* vlogit; /* (N, C) unimodal logits for multitask, or NULL */
     const float* slogit;
     const int32_t* label; /* (N) in [0, C); loss_mode 0 */

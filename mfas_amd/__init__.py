@@ -7,7 +7,7 @@ from .engine import (FeatureLoader, FeatureTable, Hyper, Population, best_dev_ac
                      flat_layout)
 from .ntu_searchable import (Searchable_Skeleton_Image_Net, get_central_states,  # noqa: F401
                              get_possible_layer_configurations, set_central_states, train_sampled_models)
-from . import mmimdb_searchable  # noqa: F401
+from . import avmnist_searchable, mmimdb_searchable  # noqa: F401
 from .scheduler import FixedScheduler, LRCosineAnnealingScheduler  # noqa: F401
 from .train_ntu import test_ntu_track_acc, train_ntu_track_acc  # noqa: F401
 

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MFAS_LIB") or os.path.join(_HERE, "csrc", "libmfas_hip.so")   # MFAS_LIB: debug builds
 
 MFAS_DT = {"float32": 0, "bfloat16": 1, "float16": 2}
+MAX_TAPS = 8        # MFAS_MAX_TAPS
 
 
 class mfas_hyper(C.Structure):
@@ -17,12 +18,12 @@ class mfas_hyper(C.Structure):
                 ("alphas", C.c_int32), ("multitask", C.c_int32), ("drpt", C.c_double),
                 ("wd", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
                 ("adam_eps", C.c_double), ("bn_eps", C.c_double), ("bn_momentum", C.c_double),
-                ("s_sizes", C.c_int32 * 4), ("v_sizes", C.c_int32 * 4), ("loss_mode", C.c_int32),
-                ("_pad", C.c_int32), ("f1_threshold", C.c_double)]
+                ("s_sizes", C.c_int32 * MAX_TAPS), ("v_sizes", C.c_int32 * MAX_TAPS), ("loss_mode", C.c_int32),
+                ("allow_plain_cell", C.c_int32), ("f1_threshold", C.c_double)]
 
 
 class mfas_table(C.Structure):
-    _fields_ = [("s", C.c_void_p * 4), ("v", C.c_void_p * 4), ("vlogit", C.c_void_p),
+    _fields_ = [("s", C.c_void_p * MAX_TAPS), ("v", C.c_void_p * MAX_TAPS), ("vlogit", C.c_void_p),
                 ("slogit", C.c_void_p), ("label", C.c_void_p), ("multilabel", C.c_void_p), ("N", C.c_int64),
                 ("dtype", C.c_int32), ("_pad", C.c_int32)]
 

@@ -115,7 +115,7 @@ struct Geo {             // geometry shared by all candidates of a population
     int64_t sb_part, sb_dy, sb_xo, sb_dlog, sb_sav, sb_yf, sb_gsc, sb_size;
     int32_t vec_cell_stride;   // 5*Rp + 16
     int32_t vec_head;          // offset of head bias inside the vector block
-    int32_t sw[4], vw[4];      // tap widths (elements per table row)
+    int32_t sw[MFAS_MAX_TAPS], vw[MFAS_MAX_TAPS];   // table row strides of the taps (width padded to 16)
     int32_t loss_mode;         // 0 softmax CE + accuracy, 1 weighted BCE + F1-samples
     float f1_th;
 };
@@ -1669,13 +1669,13 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         const int bp = ((hp->B + 15) / 16 == 3 ? 4 : (hp->B + 15) / 16) * 16, lpr = std::min(16, 512 / bp);
         if (((hp->C + 15) & ~15) > 8 * lpr) return fail(MFAS_EINVAL, "num_outputs too large for this batch size (C_padded <= 8 * min(16, 512/B_padded))");
     }
-    if (!(hp->drpt > 1e-10) && !hp->bn)   // ntu_searchable.py:274-284: `op` never assigned
+    if (!(hp->drpt > 1e-10) && !hp->bn && !hp->allow_plain_cell)   // ntu_searchable.py:274-284: `op` never assigned
         return fail(MFAS_EINVAL, "illegal cell variant: drpt < 1e-10 without batchnorm (reference: UnboundLocalError)");
     if (hp->drpt >= 1.0) return fail(MFAS_EINVAL, "drpt must be < 1");
     if (hp->loss_mode == 1 && hp->multitask) return fail(MFAS_EINVAL, "multitask applies to the single-label head only");
-    for (int j = 0; j < 4; ++j)
-        if (hp->s_sizes[j] < 16 || hp->s_sizes[j] % 16 || hp->v_sizes[j] < 16 || hp->v_sizes[j] % 16)
-            return fail(MFAS_EINVAL, "tap widths must be positive multiples of 16");
+    for (int j = 0; j < MFAS_MAX_TAPS; ++j)
+        if (hp->s_sizes[j] < 0 || hp->v_sizes[j] < 0 || hp->s_sizes[j] > (1 << 20) || hp->v_sizes[j] > (1 << 20))
+            return fail(MFAS_EINVAL, "tap widths must be in [0, 2^20]");
     mfas_population* p = new (std::nothrow) mfas_population();
     if (!p) return fail(MFAS_ENOMEM, "host alloc");
     p->hp = *hp;
@@ -1698,7 +1698,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     g.bn_eps = (float)hp->bn_eps; g.bn_mom = (float)hp->bn_momentum;
     g.vec_cell_stride = 5 * g.Rp + 16;
     g.vec_head = MFAS_MAX_CELLS * g.vec_cell_stride;
-    for (int j = 0; j < 4; ++j) { g.sw[j] = hp->s_sizes[j]; g.vw[j] = hp->v_sizes[j]; }
+    for (int j = 0; j < MFAS_MAX_TAPS; ++j) { g.sw[j] = ceil16(hp->s_sizes[j]); g.vw[j] = ceil16(hp->v_sizes[j]); }
     g.loss_mode = hp->loss_mode == 1 ? 1 : 0;
     g.f1_th = (float)hp->f1_threshold;
     const int vec_size = (g.vec_head + g.Cp + 63) & ~63;
@@ -1711,7 +1711,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         double tot_cols = 0;
         for (int k = 0; k < K; ++k)
             for (int i = 0; i < n_cells[k]; ++i)
-                tot_cols += hp->s_sizes[confs[(k * 4 + i) * 3] & 3] + hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 3];
+                tot_cols += ceil16(hp->s_sizes[confs[(k * 4 + i) * 3] & 7]) + ceil16(hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 7]);
         int lds_max = 64;                                   // largest power of two with Bp*(2cc+20)*4 <= 72 KiB
         while ((size_t)g.Bp * (8 * lds_max + 20) * 4 <= 72 * 1024 && lds_max < 1024) lds_max <<= 1;   // test the doubled size
         target = 64;
@@ -1752,8 +1752,9 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
                 c.conf[i][j] = confs[(k * 4 + i) * 3 + j];
                 c.seg_off[i][j] = -1;
             }
-            if (c.conf[i][0] < 0 || c.conf[i][0] > 3 || c.conf[i][1] < 0 || c.conf[i][1] > 3 || c.conf[i][2] < 0 || c.conf[i][2] > 2) {
-                delete p; return fail(MFAS_EINVAL, "configuration entry out of range");
+            if (c.conf[i][0] < 0 || c.conf[i][0] >= MFAS_MAX_TAPS || c.conf[i][1] < 0 || c.conf[i][1] >= MFAS_MAX_TAPS ||
+                c.conf[i][2] < 0 || c.conf[i][2] > 2 || hp->s_sizes[c.conf[i][0]] < 1 || hp->v_sizes[c.conf[i][1]] < 1) {
+                delete p; return fail(MFAS_EINVAL, "configuration entry out of range (tap index / unused tap slot / non-linearity)");
             }
             const int sw = hp->s_sizes[c.conf[i][0]], vw = hp->v_sizes[c.conf[i][1]];
             const int Kin = sw + vw + (i > 0 ? hp->R : 0);
@@ -1763,7 +1764,8 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             c.f_bn[i] = f; if (hp->bn) f += 4 * (int64_t)hp->R;
             c.part_cell_off[i] = pslot;
             const float bound = (float)(1.0 / sqrt((double)Kin));
-            const int widths[3] = {sw, vw, g.Rp};
+            const int widths[3] = {ceil16(sw), ceil16(vw), g.Rp};     // stored (padded) columns = table row stride
+            const int true_w[3] = {sw, vw, hp->R};                     // reference columns
             const int col0[3] = {0, sw, sw + vw};
             for (int j = 0; j < 3; ++j) {
                 if (j == 2 && i == 0) continue;
@@ -1784,7 +1786,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
                     d.w_off = plane_off + (int64_t)ch * g.Rp * cc;
                     d.wt_off = j == 2 ? wt_off : -1;
                     d.part_idx = j < 2 ? (j == 0 ? ch : c.nch_s[i] + ch) : 0;
-                    d.rows = hp->R; d.cols = j < 2 ? widths[j] : hp->R;
+                    d.rows = hp->R; d.cols = true_w[j];
                     d.src_off = c.f_W[i]; d.src_ld = Kin; d.src_col0 = col0[j];
                     d.init_seed = 2 * i; d.init_bound = bound;
                     p->descs.push_back(d);
@@ -1792,8 +1794,8 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
                 if (j < 2) pslot += nch;
                 plane_off += (int64_t)g.Rp * cols_p;
                 if (j == 2) wt_off += (int64_t)g.Rp * g.Rp;
-                alg_bytes += 24.0 * hp->R * (j < 2 ? widths[j] : hp->R);
-                if (j < 2) alg_feat += (double)hp->B * widths[j];   // x elements (dtype size applied at train time)
+                alg_bytes += 24.0 * hp->R * true_w[j];
+                if (j < 2) alg_feat += (double)hp->B * true_w[j];   // x elements (dtype size applied at train time)
             }
         }
         c.f_Wc = f; f += (int64_t)hp->C * hp->R;
@@ -1919,7 +1921,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             gr.nc = gi == 0 ? split : K - split;
             std::vector<SegDesc> all(p->descs.begin() + p->desc_start[gr.c0], p->descs.begin() + p->desc_start[gr.c0 + gr.nc]);
             for (const SegDesc& d : all) {
-                gr.alg_state += 24.0 * d.rows * std::min(d.cc, d.cols - d.k0);
+                gr.alg_state += 24.0 * d.rows * std::max(0, std::min(d.cc, d.cols - d.k0));
                 if (d.kind <= KIND_V) gr.alg_feat += (double)hp->B * d.cc;
             }
             // small R (1, 2 or 4 row blocks): feature segments are regrouped tap-major (sweep_tap_body)

@@ -18,7 +18,7 @@ from .scheduler import adam_step_scalars
 
 S_SIZES = (128, 256, 1024, 512)    # /root/reference/models/search/ntu_searchable.py:291
 V_SIZES = (512, 1024, 2048, 2048)  # ntu_searchable.py:292
-TAPS = ("s0", "s1", "s2", "s3", "v0", "v1", "v2", "v3")
+TAPS = tuple(f"s{j}" for j in range(_lib.MAX_TAPS)) + tuple(f"v{j}" for j in range(_lib.MAX_TAPS))
 
 
 @dataclass
@@ -41,6 +41,7 @@ class Hyper:
     v_sizes: Sequence[int] = V_SIZES
     loss_mode: int = 0          # 0 CE + top-1 (NTU); 1 weighted BCE-with-logits + F1-samples (MM-IMDB)
     f1_threshold: float = 0.3   # th_fscore, train_searchable/mmimdb.py:16
+    allow_plain_cell: bool = False   # [Linear, nl] cells are legal (AV-MNIST, avmnist_searchable.py:276-285)
 
     @classmethod
     def from_args(cls, args) -> "Hyper":
@@ -59,10 +60,13 @@ class Hyper:
         h.drpt = float(self.drpt)
         h.wd, h.beta1, h.beta2 = self.wd, self.beta1, self.beta2
         h.adam_eps, h.bn_eps, h.bn_momentum = self.adam_eps, self.bn_eps, self.bn_momentum
-        for j in range(4):
-            h.s_sizes[j] = int(self.s_sizes[j])
-            h.v_sizes[j] = int(self.v_sizes[j])
+        if len(self.s_sizes) > _lib.MAX_TAPS or len(self.v_sizes) > _lib.MAX_TAPS:
+            raise ValueError(f"at most {_lib.MAX_TAPS} taps per modality")
+        for j in range(_lib.MAX_TAPS):
+            h.s_sizes[j] = int(self.s_sizes[j]) if j < len(self.s_sizes) else 0
+            h.v_sizes[j] = int(self.v_sizes[j]) if j < len(self.v_sizes) else 0
         h.loss_mode = int(self.loss_mode)
+        h.allow_plain_cell = int(self.allow_plain_cell)
         h.f1_threshold = float(self.f1_threshold)
         return h
 
@@ -117,10 +121,13 @@ class FeatureTable:
         if self.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise ValueError(f"unsupported tap dtype {self.dtype}")
         self.N = int(label.shape[0])
-        self.taps = {k: v.contiguous() for k, v in taps.items()}
-        for k, v in self.taps.items():
+        self.widths = {k: int(v.shape[1]) for k, v in taps.items()}     # true tap widths
+        self.taps = {}
+        for k, v in taps.items():
             if v.shape[0] != self.N or v.dim() != 2 or v.device != dev:
                 raise ValueError(f"tap {k}: expected (N, width) on {dev}")
+            pad = (-v.shape[1]) % 16       # the engine reads rows padded with zeros to a multiple of 16 elements
+            self.taps[k] = (torch.nn.functional.pad(v, (0, pad)) if pad else v).contiguous()
         self.label = label.to(torch.int32).contiguous()
         self.vlogit = None if vlogit is None else vlogit.to(torch.float32).contiguous()
         self.slogit = None if slogit is None else slogit.to(torch.float32).contiguous()
@@ -144,7 +151,7 @@ class FeatureTable:
         import os
         os.makedirs(directory, exist_ok=True)
         for k, v in self.taps.items():
-            a = v.cpu()
+            a = v[:, :self.widths[k]].cpu()
             if a.dtype == torch.bfloat16:
                 np.save(os.path.join(directory, f"{split}_{k}.bf16.npy"), a.view(torch.int16).numpy().view(np.uint16))
             else:
@@ -197,7 +204,7 @@ class FeatureTable:
     def to_c(self) -> _lib.mfas_table:
         t = _lib.mfas_table()
         some = next(iter(self.taps.values())).data_ptr()
-        for j in range(4):      # taps a population never selects may be absent: any valid pointer will do
+        for j in range(_lib.MAX_TAPS):   # taps a population never selects may be absent: any valid pointer will do
             t.s[j] = self.taps[f"s{j}"].data_ptr() if f"s{j}" in self.taps else some
             t.v[j] = self.taps[f"v{j}"].data_ptr() if f"v{j}" in self.taps else some
         t.vlogit = None if self.vlogit is None else self.vlogit.data_ptr()

@@ -67,6 +67,7 @@ class Hyper:
     loss_mode: int = 0
     f1_threshold: float = 0.3
     pos_weight: Optional[Sequence[float]] = None
+    allow_plain_cell: bool = False   # AV-MNIST: [Linear, nl] without BN / Dropout (avmnist_searchable.py:276-285)
 
     @property
     def use_dropout(self) -> bool:
@@ -74,7 +75,7 @@ class Hyper:
 
     def check(self):
         # ntu_searchable.py:274-284: with drpt<1e-10 and no batchnorm `op` is never assigned.
-        if not self.use_dropout and not self.bn:
+        if not self.use_dropout and not self.bn and not self.allow_plain_cell:
             raise ValueError("illegal cell variant: drpt<1e-10 without batchnorm "
                              "(reference raises UnboundLocalError, ntu_searchable.py:274-284)")
 

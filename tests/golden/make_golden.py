@@ -551,7 +551,89 @@ def g11():
     save("g11_mmimdb.npz", **out)
 
 
+# ------------------------------------------------------------------ G12 AV-MNIST searchable (next#4)
+def g12():
+    """The reference's AV-MNIST variant (models/search/avmnist_searchable.py:23-108,184-297 +
+    train_searchable/avmnist.py) through stub backbones serving 5 audio + 3 image taps of widths c..16c / c..4c
+    (channels = 3 -> widths that are NOT multiples of 16) — incl. the plain [Linear, nl] cell (drpt = 0)."""
+    import types
+    import models.auxiliary as aux_pkg
+    sys.modules.setdefault("models.aux", aux_pkg)
+    sys.modules.setdefault("models.aux.scheduler", sc)
+    import models.central.avmnist as cav
+
+    class FeatImg(nn.Module):
+        def __init__(self, args, ch):
+            super().__init__()
+
+        def forward(self, x):
+            return (x["vlogit"], x["v0"], x["v1"], x["v2"])
+
+    class FeatAud(nn.Module):
+        def __init__(self, args, ch):
+            super().__init__()
+
+        def forward(self, x):
+            return (x["slogit"], x["s0"], x["s1"], x["s2"], x["s3"], x["s4"])
+
+    cav.GP_LeNet, cav.GP_LeNet_Deeper = FeatImg, FeatAud
+    import models.search.avmnist_searchable as avm
+    out = {}
+    SS, VS = (3, 6, 12, 24, 48), (3, 6, 12)
+    out["layer_confs"] = np.array(avm.get_possible_layer_configurations(0))
+
+    class AVLoader:
+        def __init__(self, t, B):
+            self.t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in t.items()}
+            self.B = B
+            self.dataset = range(len(t["label"]))
+
+        def __iter__(self):
+            N = len(self.dataset)
+            z = torch.zeros(1)
+            for i in range(0, N, self.B):
+                sl = slice(i, min(i + self.B, N))
+                img = D({k: self.t[k][sl] for k in ("v0", "v1", "v2")})
+                img["vlogit"] = z
+                aud = D({k: self.t[k][sl] for k in ("s0", "s1", "s2", "s3", "s4")})
+                aud["slogit"] = z
+                yield {"image": img, "audio": aud, "label": self.t["label"][sl]}
+
+    ttr = O.synth_table(192, 71, snr=1.0, C=10, s_sizes=SS, v_sizes=VS)
+    tdv = O.synth_table(96, 72, snr=1.0, C=10, s_sizes=SS, v_sizes=VS)
+    confs = [[[4, 2, 0]], [[3, 1, 1], [4, 2, 2]], [[0, 0, 0], [2, 1, 1], [4, 2, 0]]]
+    for tag, drpt in (("plain", 0.0),):
+        args = mkargs(inner_representation_size=16, batchnorm=False, drpt=drpt, epochs=3, batchsize=16, num_outputs=10,
+                      channels=3, audio_cp="ske", rgb_cp="rgb")
+        hp = O.Hyper(R=16, C=10, B=16, bn=False, drpt=drpt, epochs=3, s_sizes=SS, v_sizes=VS, allow_plain_cell=True)
+
+        class Cap:
+            def __init__(self):
+                self.n = 0
+
+            def __call__(self, a, conf):
+                m = avm.Searchable_Audio_Image_Net(a, conf)
+                p = O.init_params(conf, hp, 30 + self.n)
+                sd = m.state_dict()
+                for k, v in p.items():
+                    if k in sd:
+                        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+                        sd[k].copy_(torch.from_numpy(v))
+                self.n += 1
+                return m
+
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            accs = avm.train_sampled_models([np.array(c) for c in confs], Cap(), {"train": AVLoader(ttr, 16), "dev": AVLoader(tdv, 16)},
+                                            args, "cpu")
+        out[tag + "/accs"] = np.array([float(a) for a in accs])
+        out[tag + "/dev_acc_per_epoch"] = np.array([float(m.group(1)) for m in re.finditer(r"dev Acc: ([0-9.]+)", buf.getvalue())])
+    for i, c in enumerate(confs):
+        out[f"conf{i}"] = np.array(c)
+    save("g12_avmnist.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

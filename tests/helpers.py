@@ -24,7 +24,8 @@ def engine_hyper(ohp: "O.Hyper"):
     return Hyper(R=ohp.R, C=ohp.C, B=ohp.B, bn=ohp.bn, drpt=ohp.drpt, alphas=ohp.alphas,
                  multitask=ohp.multitask, wd=ohp.wd, beta1=ohp.beta1, beta2=ohp.beta2,
                  adam_eps=ohp.adam_eps, bn_eps=ohp.bn_eps, bn_momentum=ohp.bn_momentum,
-                 s_sizes=tuple(ohp.s_sizes), v_sizes=tuple(ohp.v_sizes))
+                 s_sizes=tuple(ohp.s_sizes), v_sizes=tuple(ohp.v_sizes), loss_mode=ohp.loss_mode,
+                 f1_threshold=ohp.f1_threshold, allow_plain_cell=ohp.allow_plain_cell)
 
 
 def etas_for(ohp, n_train, epochs=None):
