@@ -111,7 +111,8 @@ int mfas_population_init(mfas_population* pop, const uint32_t* seeds /* K, host 
  * {lr_t/(1-beta1^t), sqrt(1-beta2^t)} (scheduler.py:25-46 + torch Adam bias corrections).
  * max_steps >= 0 stops after that many train steps of the first epoch (debug/known-answer tests;
  * dev evaluation is skipped).  stats: HOST [K][epochs].  status: HOST [K], 1 = non-finite loss seen.
- * snapshot_best != 0 keeps the best-dev-epoch parameters and restores them at the end (:82-86). */
+ * snapshot_best != 0 keeps the best-dev-epoch parameters and restores them at the end (:82-86).
+ * Every call starts from zeroed Adam moments and step count (a freshly constructed optimizer). */
 int mfas_population_train(mfas_population* pop, const mfas_table* train, const mfas_table* dev,
                           const int32_t* order, const float* step_scalars, int32_t epochs,
                           int64_t max_steps, int32_t snapshot_best, mfas_epoch_stats* stats,

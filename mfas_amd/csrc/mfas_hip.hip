@@ -2108,6 +2108,8 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     }
     HIPCHK(hipMemsetAsync(p->d_stats, 0, sizeof(DevStats) * K * epochs, p->stream));
     HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int32_t) * K, p->stream));
+    // every call is a freshly built torch.optim.Adam (ntu_searchable.py:65; main_found_ntu.py:108,128): zero exp_avg / exp_avg_sq
+    HIPCHK(hipMemsetAsync(p->plane + p->plane_stride, 0, sizeof(float) * 2 * (size_t)p->plane_stride, p->stream));
     if (snapshot_best && !p->best) HIPCHK(hipMalloc(&p->best, sizeof(float) * (size_t)p->plane_stride));
     std::vector<double> best_acc(K, 0.0);
     std::vector<DevStats> hstats((size_t)K * epochs);

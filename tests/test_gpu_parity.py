@@ -488,3 +488,24 @@ def test_nan_candidate_is_flagged_and_isolated(dev):
     for k in (0, 2):
         assert clean[k].tobytes() == bad[k].tobytes()
     assert not np.isfinite(bad[1]["train_loss_sum"]).all()
+
+
+def test_second_train_call_is_a_fresh_optimizer(dev):
+    """Two consecutive train() calls on one population == the oracle trained twice with a new Adam each time
+    (main_found_ntu.py builds a new optimizer + scheduler per phase, :108-137)."""
+    ohp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=1)
+    conf = np.array(CONFS["l2"])
+    ttr, tdv = O.synth_table(64, 21, snr=0.3), O.synth_table(48, 22, snr=0.3)
+    pop = mk_pop(ohp, [conf], dev)
+    pop.set_state_dict(0, O.init_params(conf, ohp, 5))
+    ta, tb = table(ttr, dev), table(tdv, dev)
+    s1, _ = pop.train(ta, tb, 1, etas_for(ohp, 64))
+    s2, _ = pop.train(ta, tb, 1, etas_for(ohp, 64))
+    params = O.init_params(conf, ohp, 5)
+    h1, h2 = [], []
+    O.train_candidate(conf, ohp, params, ttr, tdv, history=h1)
+    O.train_candidate(conf, ohp, params, ttr, tdv, history=h2)      # continues from the trained weights, new Adam
+    assert abs(s1["train_loss_sum"][0, 0] / 64 - h1[0]["train_loss"]) < 1e-3
+    assert abs(s2["train_loss_sum"][0, 0] / 64 - h2[0]["train_loss"]) < 1e-3
+    assert s2["dev_corrects"][0, 0] == h2[0]["dev_corrects"]
+    pop.close()
