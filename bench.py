@@ -198,6 +198,14 @@ def main():
                 traffic = json.load(open(tp))["per_launch"]["total_bytes"]
             except Exception:
                 traffic = None
+        stream = None       # live ceiling of THIS box for the sweep's access pattern (no compute), same units as `achieved`
+        if world == 1:
+            import ctypes
+            from mfas_amd import _lib
+            gb = ctypes.c_double(0)
+            with torch.cuda.device(device):
+                if _lib.lib().mfas_stream_probe(400 << 20, 10, ctypes.byref(gb)) == 0:
+                    stream = gb.value
         line = {
             "metric": "candidate-archs trained/sec (NTU inner loop)", "value": total / dt, "unit": "candidates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -211,7 +219,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "launches": n_launch, "avg_launch_us": (ms / n_launch * 1e3) if n_launch else None,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "stream_ceiling": stream, "frac_of_stream": (achieved / stream) if (achieved and stream) else None},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(train, dev, a)

@@ -131,6 +131,10 @@ int mfas_population_sweep_profile(const mfas_population* pop, int64_t* launches,
                                   double* bytes_per_launch);
 int mfas_population_set_profiling(mfas_population* pop, int32_t on);
 
+/* (new) Streaming ceiling of this device for the sweep's access pattern: three planes of `bytes_per_plane` are
+ * read-modify-written in 1 KiB tiles with nontemporal 16 B/lane accesses and no compute; returns GB/s (read + write). */
+int mfas_stream_probe(int64_t bytes_per_plane, int32_t iters, double* gb_per_s);
+
 /* Replaces GlobalPooling2D.forward (models/auxiliary/aux_models.py:54-64; applied at ntu_searchable.py:224-225): mean over
  * the `inner` trailing elements of each of the rows = B*C contiguous rows of a backbone tap (B, C, ...) -> out[rows].
  * x / out are device pointers of dtype MFAS_DT_* ; f32 accumulation.  The step that builds an mfas_table from raw taps. */

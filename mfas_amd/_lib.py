@@ -63,6 +63,7 @@ def lib():
     L.mfas_population_sweep_profile.argtypes = [P, P, P, P]
     L.mfas_population_set_profiling.argtypes = [P, C.c_int32]
     L.mfas_population_set_pos_weight.argtypes = [P, P]
+    L.mfas_stream_probe.argtypes = [C.c_int64, C.c_int32, P]
     L.mfas_global_pool.argtypes = [P, C.c_int32, C.c_int64, C.c_int64, P, C.c_int32, P]
     _lib = L
     return L
@@ -71,7 +72,7 @@ def lib():
 EXPORTS = ["mfas_last_error", "mfas_version", "mfas_population_create", "mfas_population_destroy",
            "mfas_population_param_count", "mfas_population_set_params", "mfas_population_get_params",
            "mfas_population_init", "mfas_population_train", "mfas_population_forward",
-           "mfas_population_sweep_profile", "mfas_population_set_profiling", "mfas_population_set_pos_weight", "mfas_global_pool"]
+           "mfas_population_sweep_profile", "mfas_population_set_profiling", "mfas_population_set_pos_weight", "mfas_global_pool", "mfas_stream_probe"]
 
 
 def check(rc):

@@ -1599,6 +1599,35 @@ __global__ void __launch_bounds__(256) k_pool(const void* x, int dtype, int64_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_stream_probe — what this box's memory system gives the sweep's access pattern with NO compute: every wave
+// read-modify-writes runs of 1 KiB tiles of three planes (16 B/lane, nontemporal), like W / m / v.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_stream_probe(float* P, size_t plane, size_t ntiles) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int RUN = 8, U = 4;
+    for (size_t r0 = wave * RUN; r0 < ntiles; r0 += nwaves * RUN)
+        for (int t0 = 0; t0 < RUN && r0 + t0 < ntiles; t0 += U) {
+            f32x4 w[U], m[U], v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t off = (r0 + t0 + u) * 256 + lane * 4;
+                w[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + off));
+                m[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + plane + off));
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + 2 * plane + off));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t off = (r0 + t0 + u) * 256 + lane * 4;
+                __builtin_nontemporal_store(w[u] * 0.999f + m[u] * 0.001f, reinterpret_cast<f32x4*>(P + off));
+                __builtin_nontemporal_store(m[u] * 0.9f + v[u], reinterpret_cast<f32x4*>(P + plane + off));
+                __builtin_nontemporal_store(v[u] * 0.999f + w[u], reinterpret_cast<f32x4*>(P + 2 * plane + off));
+            }
+        }
+}
+
 // ================================================================================================
 // Host side: C ABI
 // ================================================================================================
@@ -2296,6 +2325,29 @@ extern "C" int mfas_population_forward(mfas_population* p, int32_t k, const mfas
         HIPCHK(hipStreamSynchronize(p->stream));
         *corrects = (int64_t)h;
     }
+    return MFAS_OK;
+}
+
+extern "C" int mfas_stream_probe(int64_t bytes_per_plane, int32_t iters, double* gb_per_s) {
+    if (bytes_per_plane < (1 << 20) || iters < 1 || !gb_per_s) return fail(MFAS_EINVAL, "bad argument");
+    const size_t plane = (size_t)bytes_per_plane / 1024 * 256;   // floats, whole tiles
+    float* P = nullptr;
+    HIPCHK(hipMalloc(&P, plane * 4 * 3));
+    hipError_t e = hipMemset(P, 0, plane * 4 * 3);
+    hipEvent_t a, b;
+    if (e == hipSuccess) e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    if (e != hipSuccess) { hipFree(P); return fail(MFAS_EHIP, hipGetErrorString(e)); }
+    hipLaunchKernelGGL(k_stream_probe, dim3(2048), dim3(256), 0, 0, P, plane, plane / 256);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_stream_probe, dim3(2048), dim3(256), 0, 0, P, plane, plane / 256);
+    hipEventRecord(b, 0);
+    e = hipEventSynchronize(b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a); hipEventDestroy(b); hipFree(P);
+    if (e != hipSuccess) return fail(MFAS_EHIP, hipGetErrorString(e));
+    *gb_per_s = (double)plane * 4 * 3 * 2 * iters / 1e9 / (ms * 1e-3);
     return MFAS_OK;
 }
 
