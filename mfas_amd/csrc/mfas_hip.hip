@@ -227,6 +227,86 @@ __device__ __forceinline__ void stage_f32(float* dst, int stride, const float* s
     }
 }
 
+#define SWEEP_U 2   // tiles of W/m/v in flight per wave (x3 planes); 4 spills at the 128-VGPR budget, no gain
+
+// ------------------------------------------------------------------------------------------------
+// tile_run — the fused per-tile work shared by both sweep decompositions, for ONE row block `rb` over the k-blocks
+// kb0, kb0+kbs, ... < nkb of a chunk: request SWEEP_U tiles of W/m/v, then per tile
+//   dW^T = x_t^T dy (4*MB f32 MFMAs; D image == the tile image)  ->  Adam(+L2) on 4 elements/lane in registers  ->
+//   store W, m, v (+ transposed copy T for OUT/HEAD)  ->  y_{t+1} += x_{t+1} W_new^T (4*MB f32 MFMAs) into yacc.
+// ------------------------------------------------------------------------------------------------
+template <int MB, bool NT>
+__device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const int rb, const int nkb, const int kb0,
+                                         const int kbs, const float* xt, const int ST, const float* xn, const int SN,
+                                         const float (&dyf)[MB * 4], const float gsc, const AdamC& ac, const bool upd,
+                                         const bool fwd, f32x4 (&yacc)[MB], float* T, const int tstride_rb,
+                                         const int lane) {
+    const int l15 = lane & 15, lg = lane >> 4;
+    for (int kbb = kb0; kbb < nkb; kbb += SWEEP_U * kbs) {
+        f32x4 w4[SWEEP_U], m4[SWEEP_U], v4[SWEEP_U];
+#pragma unroll
+        for (int u = 0; u < SWEEP_U; ++u) {
+            const int kb = kbb + u * kbs;
+            if (kb < nkb) {
+                const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+                // state larger than the Infinity Cache is streamed once per step: nontemporal (+5 % HBM rate)
+                w4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Wp + off))
+                           : *reinterpret_cast<const f32x4*>(Wp + off);
+                if (upd) {
+                    m4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mp + off))
+                               : *reinterpret_cast<const f32x4*>(Mp + off);
+                    v4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vp + off))
+                               : *reinterpret_cast<const f32x4*>(Vp + off);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SWEEP_U; ++u) {
+            const int kb = kbb + u * kbs;
+            if (kb < nkb) {
+                const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+                if (upd) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < MB * 4; ++j)
+                        acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float w = w4[u][q], m = m4[u][q], v = v4[u][q];
+                        adam1(w, m, v, acc[q] * gsc, ac);
+                        w4[u][q] = w;
+                        m4[u][q] = m;
+                        v4[u][q] = v;
+                    }
+                    if (NT) {
+                        __builtin_nontemporal_store(w4[u], reinterpret_cast<f32x4*>(Wp + off));
+                        __builtin_nontemporal_store(m4[u], reinterpret_cast<f32x4*>(Mp + off));
+                        __builtin_nontemporal_store(v4[u], reinterpret_cast<f32x4*>(Vp + off));
+                    } else {
+                        *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
+                        *reinterpret_cast<f32x4*>(Mp + off) = m4[u];
+                        *reinterpret_cast<f32x4*>(Vp + off) = v4[u];
+                    }
+                    if (T) {   // keep the transposed copy used by the backward chain in step (OUT / HEAD only)
+                        float* Tt = T + ((int64_t)kb * tstride_rb + rb) * 256;
+                        const int base = (((l15 >> 2) * 16 + 4 * lg) << 2) + (l15 & 3);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Tt[base + 4 * q] = w4[u][q];
+                    }
+                }
+                if (fwd) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * SN + kb * 16 + 4 * lg);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][q], yacc[mb]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_sweep — fused dW + Adam + next-step forward.  One workgroup = ALL row blocks of one weight segment
 // over a chunk of `cc` columns: x_t / x_{t+1} / dy are staged ONCE in LDS, then every wave streams whole
@@ -252,8 +332,6 @@ struct SweepArgs {
 
 #define STEP_NW 8
 #define STEP_THREADS (STEP_NW * 64)
-
-#define SWEEP_U 2   // tiles of W/m/v in flight per wave (x3 planes); 4 spills at the 128-VGPR budget, no gain
 
 template <int MB, bool NT>
 __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, float* lds) {
@@ -316,70 +394,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, fl
         f32x4 yacc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int kbb = kb0; kbb < nkb; kbb += SWEEP_U * kbs) {
-            // request the W/m/v tiles of SWEEP_U k-blocks before any is consumed
-            f32x4 w4[SWEEP_U], m4[SWEEP_U], v4[SWEEP_U];
-#pragma unroll
-            for (int u = 0; u < SWEEP_U; ++u) {
-                const int kb = kbb + u * kbs;
-                if (kb < nkb) {
-                    const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
-                    // state larger than the Infinity Cache is streamed once per step: nontemporal (+5 % HBM rate)
-                    w4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Wp + off))
-                               : *reinterpret_cast<const f32x4*>(Wp + off);
-                    if (upd) {
-                        m4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mp + off))
-                                   : *reinterpret_cast<const f32x4*>(Mp + off);
-                        v4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vp + off))
-                                   : *reinterpret_cast<const f32x4*>(Vp + off);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < SWEEP_U; ++u) {
-                const int kb = kbb + u * kbs;
-                if (kb < nkb) {
-                    const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
-                    if (upd) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int j = 0; j < MB * 4; ++j)
-                            acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float w = w4[u][q], m = m4[u][q], v = v4[u][q];
-                            adam1(w, m, v, acc[q] * gsc, ac);
-                            w4[u][q] = w;
-                            m4[u][q] = m;
-                            v4[u][q] = v;
-                        }
-                        if (NT) {
-                            __builtin_nontemporal_store(w4[u], reinterpret_cast<f32x4*>(Wp + off));
-                            __builtin_nontemporal_store(m4[u], reinterpret_cast<f32x4*>(Mp + off));
-                            __builtin_nontemporal_store(v4[u], reinterpret_cast<f32x4*>(Vp + off));
-                        } else {
-                            *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
-                            *reinterpret_cast<f32x4*>(Mp + off) = m4[u];
-                            *reinterpret_cast<f32x4*>(Vp + off) = v4[u];
-                        }
-                        if (d.wt_off >= 0) {   // keep the transposed copy used by the backward chain in step
-                            float* T = a.wt + d.wt_off + ((int64_t)((d.k0 >> 4) + kb) * nrb + rb) * 256;
-                            const int base = (((l15 >> 2) * 16 + 4 * lg) << 2) + (l15 & 3);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) T[base + 4 * q] = w4[u][q];
-                        }
-                    }
-                    if (fwd) {
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * SN + kb * 16 + 4 * lg);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][q], yacc[mb]);
-                        }
-                    }
-                }
-            }
-        }
+        tile_run<MB, NT>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
+                         d.wt_off >= 0 ? a.wt + d.wt_off + (int64_t)(d.k0 >> 4) * nrb * 256 : nullptr, nrb, lane);
         if (fwd) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -448,62 +464,7 @@ __device__ __forceinline__ void sweep_tap_body(const SweepArgs& a, const int bid
     f32x4 yacc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kbb = 0; kbb < nkb; kbb += SWEEP_U) {
-        f32x4 w4[SWEEP_U], m4[SWEEP_U], v4[SWEEP_U];
-#pragma unroll
-        for (int u = 0; u < SWEEP_U; ++u) {
-            const int kb = kbb + u;
-            if (kb < nkb) {
-                const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
-                w4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Wp + off))
-                           : *reinterpret_cast<const f32x4*>(Wp + off);
-                if (upd) {
-                    m4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mp + off))
-                               : *reinterpret_cast<const f32x4*>(Mp + off);
-                    v4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vp + off))
-                               : *reinterpret_cast<const f32x4*>(Vp + off);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SWEEP_U; ++u) {
-            const int kb = kbb + u;
-            if (kb < nkb) {
-                const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
-                if (upd) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < MB * 4; ++j)
-                        acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float w = w4[u][q], m = m4[u][q], v = v4[u][q];
-                        adam1(w, m, v, acc[q] * gsc, ac);
-                        w4[u][q] = w;
-                        m4[u][q] = m;
-                        v4[u][q] = v;
-                    }
-                    if (NT) {
-                        __builtin_nontemporal_store(w4[u], reinterpret_cast<f32x4*>(Wp + off));
-                        __builtin_nontemporal_store(m4[u], reinterpret_cast<f32x4*>(Mp + off));
-                        __builtin_nontemporal_store(v4[u], reinterpret_cast<f32x4*>(Vp + off));
-                    } else {
-                        *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
-                        *reinterpret_cast<f32x4*>(Mp + off) = m4[u];
-                        *reinterpret_cast<f32x4*>(Vp + off) = v4[u];
-                    }
-                }
-                if (fwd) {
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * SN + kb * 16 + 4 * lg);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][q], yacc[mb]);
-                    }
-                }
-            }
-        }
-    }
+    tile_run<MB, NT>(Wp, Mp, Vp, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc, nullptr, nrb, lane);
     if (fwd) {
         float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[cell] + d.part_idx[item]) * nrb * MB) << 8);
 #pragma unroll
