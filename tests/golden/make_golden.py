@@ -633,7 +633,33 @@ def g12():
     save("g12_avmnist.npz", **out)
 
 
+# ------------------------------------------------------------------ G13 full-size deterministic trajectory
+def g13():
+    """BASELINE configs[1] at FULL size through the unchanged reference: conf 4, R=128, --batchnorm, B=16,
+    N_train=10,000, N_dev=5,600, bf16-rounded taps (synth_table(N, seed, snr=0.15, quant='bf16')), deterministic mode
+    (drpt=0, unshuffled), 3 epochs, params = init_params(conf, hp, 77).
+    The run is repeated with 1, 2, 4 and 8 BLAS threads: the summation order inside ATen's GEMMs changes, Adam's
+    sign-like early steps amplify the round-off, and the reference's trajectory differs from ITSELF (per-step loss by
+    1e-4 after one step, 1e-2 after ten).  The spread of these runs is the reference's own reproducibility envelope."""
+    out = {}
+    ttr = dict(O.synth_table(10000, 1, snr=0.15, quant="bf16"), vlogit=np.zeros((10000, 60), np.float32), slogit=np.zeros((10000, 60), np.float32))
+    tdv = dict(O.synth_table(5600, 2, snr=0.15, quant="bf16"), vlogit=np.zeros((5600, 60), np.float32), slogit=np.zeros((5600, 60), np.float32))
+    conf = np.array(CONFS["c4"])
+    args = mkargs(inner_representation_size=128, batchnorm=True, drpt=0.0, epochs=3, batchsize=16)
+    hists, bests = [], []
+    for nt in (1, 2, 4, 8):
+        torch.set_num_threads(nt)
+        accs, cap, hist = run_tsm([conf], args, {"train": ListLoader(ttr, 16), "dev": ListLoader(tdv, 16)}, 77)
+        hists.append(hist)
+        bests.append(accs[0])
+        print("g13 threads", nt, accs[0], hist[:, 2], flush=True)
+    out["threads"] = np.array([1, 2, 4, 8])
+    out["best_acc"] = np.array(bests)
+    out["hist"] = np.array(hists)          # [run][2*epoch + phase] = (phase, loss, acc)
+    save("g13_fullsize.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()
