@@ -1,7 +1,7 @@
 """Where does one train_sampled_models-equivalent call spend its time? (create / init / train / close)"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mfas_amd as M
 from oracle import np_oracle as O
 
