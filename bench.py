@@ -215,7 +215,7 @@ def main():
                                    f"N_train={a.n_train}, N_dev={a.n_dev}, {a.dtype} precomputed taps, f32 state/compute",
                        "candidates_per_gpu_per_step": a.pop, "parallelism": f"population-sharded x{world}",
                        "mean_best_dev_acc": float(np.mean(accs))},
-            "roofline": {"bound": "hbm", "kernel": "k_step<1,true> (chain blocks + sweep blocks: dW, Adam, next-step forward)",
+            "roofline": {"bound": "hbm", "kernel": "k_step (chain blocks of one group + sweep blocks of the other: dW, Adam, next-step forward)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "launches": n_launch, "avg_launch_us": (ms / n_launch * 1e3) if n_launch else None,

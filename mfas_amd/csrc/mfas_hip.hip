@@ -227,7 +227,12 @@ __device__ __forceinline__ void stage_f32(float* dst, int stride, const float* s
     }
 }
 
-#define SWEEP_U 2   // tiles of W/m/v in flight per wave (x3 planes); 4 spills at the 128-VGPR budget, no gain
+// U = tiles of W/m/v in flight per wave (x3 planes).  A workgroup has 2 waves per SIMD, so two workgroups share a CU only
+// inside a 128-VGPR budget (WPE = 4 waves per SIMD).  MB == 1 always runs that way with U = 2 (U = 4 spills, no gain).
+// MB == 2 has two builds: WPE = 2 (up to 256 VGPRs, one workgroup per CU, U = 2: nothing spills, best when the co-scheduled
+// chain's latency bounds the launch) and WPE = 4 (U = 1, the chain code spills a little, two workgroups per CU: +10..19 %
+// when the sweep bounds the launch).  Deeper batches (U = 4, 6 at WPE = 2) measured 8-12 % slower.
+template <int MB, int WPE> struct SweepU { static constexpr int v = (MB == 2 && WPE == 4) ? 1 : 2; };
 
 // ------------------------------------------------------------------------------------------------
 // tile_run — the fused per-tile work shared by both sweep decompositions, for ONE row block `rb` over the k-blocks
@@ -235,7 +240,7 @@ __device__ __forceinline__ void stage_f32(float* dst, int stride, const float* s
 //   dW^T = x_t^T dy (4*MB f32 MFMAs; D image == the tile image)  ->  Adam(+L2) on 4 elements/lane in registers  ->
 //   store W, m, v (+ transposed copy T for OUT/HEAD)  ->  y_{t+1} += x_{t+1} W_new^T (4*MB f32 MFMAs) into yacc.
 // ------------------------------------------------------------------------------------------------
-template <int MB, bool NT>
+template <int MB, bool NT, int SWEEP_U>
 __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const int rb, const int nkb, const int kb0,
                                          const int kbs, const float* xt, const int ST, const float* xn, const int SN,
                                          const float (&dyf)[MB * 4], const float gsc, const AdamC& ac, const bool upd,
@@ -333,7 +338,7 @@ struct SweepArgs {
 #define STEP_NW 8
 #define STEP_THREADS (STEP_NW * 64)
 
-template <int MB, bool NT>
+template <int MB, bool NT, int U>
 __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, float* lds) {
     const SegDesc d = a.desc[bid];
     const CandDev& cd = a.cands[d.cand];
@@ -394,7 +399,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, fl
         f32x4 yacc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        tile_run<MB, NT>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
+        tile_run<MB, NT, U>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
                          d.wt_off >= 0 ? a.wt + d.wt_off + (int64_t)(d.k0 >> 4) * nrb * 256 : nullptr, nrb, lane);
         if (fwd) {
 #pragma unroll
@@ -425,7 +430,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, fl
 // owns one (segment, row block), streams its contiguous tiles and writes its forward partial directly — no cross-wave
 // reduction, and the feature staging (1/3 of the traffic at R=16) is amortised over the segments.
 // ------------------------------------------------------------------------------------------------
-template <int MB, bool NT>
+template <int MB, bool NT, int U>
 __device__ __forceinline__ void sweep_tap_body(const SweepArgs& a, const int bid, float* lds) {
     const TapDesc& d = a.tdesc[bid];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -464,7 +469,7 @@ __device__ __forceinline__ void sweep_tap_body(const SweepArgs& a, const int bid
     f32x4 yacc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tile_run<MB, NT>(Wp, Mp, Vp, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc, nullptr, nrb, lane);
+    tile_run<MB, NT, U>(Wp, Mp, Vp, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc, nullptr, nrb, lane);
     if (fwd) {
         float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[cell] + d.part_idx[item]) * nrb * MB) << 8);
 #pragma unroll
@@ -1101,13 +1106,13 @@ struct StepArgs {
     int32_t nchain, _pad;
 };
 
-template <int MB, bool NT>
-__global__ void __launch_bounds__(STEP_THREADS, (MB == 1 ? 4 : 2)) k_step(const StepArgs a) {
+template <int MB, bool NT, int WPE>
+__global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bid = (int)blockIdx.x;
     if (bid < a.nchain) chain_body<MB, false>(a.ca, bid, lds);
-    else if (bid < a.nchain + a.sa.ntap) sweep_tap_body<MB, NT>(a.sa, bid - a.nchain, lds);
-    else sweep_body<MB, NT>(a.sa, bid - a.nchain - a.sa.ntap, lds);
+    else if (bid < a.nchain + a.sa.ntap) sweep_tap_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain, lds);
+    else sweep_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain - a.sa.ntap, lds);
 }
 
 // Standalone chain launch (small populations: chain and sweep run back to back, so the chain's latency is on the
@@ -1626,6 +1631,7 @@ struct mfas_population {
     // profiling of the dominant kernel
     bool profiling = false;
     int prof_every = 16;            // HIP events bracket every prof_every-th sweep launch (event records are not free)
+    double occ_bytes = 0;           // MB == 2: group state bytes/launch above which the sweep (not the chain) bounds a fused launch
     std::vector<hipEvent_t> ev;     // pairs
     int64_t prof_launches = 0;
     double prof_ms = 0.0, bytes_per_launch = 0.0, prof_bytes = 0.0;
@@ -1964,12 +1970,18 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(hipMemsetAsync(p->plane, 0, sizeof(float) * 3 * (size_t)p->plane_stride, p->stream));
     CREATE_CHK(hipMemsetAsync(p->wt, 0, sizeof(float) * (size_t)std::max<int64_t>(p->wt_size, 64), p->stream));
     CREATE_CHK(hipMemsetAsync(p->stepbuf, 0, sizeof(float) * (size_t)p->step_total, p->stream));
-    CREATE_CHK(set_lds((k_step<1, false>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<2, false>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<4, false>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<1, true>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<2, true>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<4, true>), p->lds_step));
+    // measured crossover (MI355X, B=20): R=16 between 165 and 330 MB of group state per launch, R=128 between 300 and 600 MB
+    // (the spilling chain of the occupancy build takes ~40 / ~125 us there)
+    p->occ_bytes = g.nrb >= 8 ? 450e6 : 250e6;
+    if (const char* e = getenv("MFAS_OCC_BYTES")) p->occ_bytes = atof(e);
+    CREATE_CHK(set_lds((k_step<1, false, 4>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<2, false, 2>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<2, false, 4>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<4, false, 2>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<1, true, 4>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<2, true, 2>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<2, true, 4>), p->lds_step));
+    CREATE_CHK(set_lds((k_step<4, true, 2>), p->lds_step));
     CREATE_CHK(set_lds(k_chain<1>, p->lds_chain));
     CREATE_CHK(set_lds(k_chain<2>, p->lds_chain));
     CREATE_CHK(set_lds(k_chain<4>, p->lds_chain));
@@ -2171,9 +2183,18 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             else hipLaunchKernelGGL(k_chain<4>, dim3(nch), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca);
             return;
         }
-#define STEP_LAUNCH(M, T) hipLaunchKernelGGL((k_step<M, T>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
-        if (p->nontemporal) { if (g.MB == 1) STEP_LAUNCH(1, true); else if (g.MB == 2) STEP_LAUNCH(2, true); else STEP_LAUNCH(4, true); }
-        else { if (g.MB == 1) STEP_LAUNCH(1, false); else if (g.MB == 2) STEP_LAUNCH(2, false); else STEP_LAUNCH(4, false); }
+#define STEP_LAUNCH(M, T, W) hipLaunchKernelGGL((k_step<M, T, W>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
+        // MB == 2: the two-workgroups-per-CU build unless a co-scheduled chain would bound the launch (see SweepU)
+        const bool occ = nch == 0 || p->groups[gs].alg_state > p->occ_bytes;
+        if (p->nontemporal) {
+            if (g.MB == 1) STEP_LAUNCH(1, true, 4);
+            else if (g.MB == 2) { if (occ) STEP_LAUNCH(2, true, 4); else STEP_LAUNCH(2, true, 2); }
+            else STEP_LAUNCH(4, true, 2);
+        } else {
+            if (g.MB == 1) STEP_LAUNCH(1, false, 4);
+            else if (g.MB == 2) { if (occ) STEP_LAUNCH(2, false, 4); else STEP_LAUNCH(2, false, 2); }
+            else STEP_LAUNCH(4, false, 2);
+        }
 #undef STEP_LAUNCH
         if (prof) {
             hipEventRecord(p->ev[ev_used + 1], p->stream);
