@@ -193,6 +193,20 @@ def init_params(conf, hp: Hyper, seed: int, perturb_bn: bool = False) -> Dict[st
     return p
 
 
+def perturb_params(p: Dict[str, np.ndarray], trial: int, rel: float = 1e-7) -> Dict[str, np.ndarray]:
+    """Round-off-sized multiplicative noise on the weight matrices (trial 0 = unchanged).  Used to sample the
+    reproducibility envelope of a long trajectory: the reference, this oracle and the engine are each run from the SAME
+    perturbed starts (golden G14, tests/test_fullsize.py)."""
+    if trial == 0:
+        return p
+    rng = np.random.default_rng(1000 + trial)
+    q = dict(p)
+    for k in sorted(p):
+        if p[k].dtype == F32 and p[k].ndim == 2:
+            q[k] = (p[k] * (1.0 + rel * rng.standard_normal(p[k].shape))).astype(F32)
+    return q
+
+
 def trainable_keys(conf, hp: Hyper) -> List[str]:
     """central_params() membership/order (ntu_searchable.py:249-256).  alphas are in the optimizer
     even when unused; then their grad is None and Adam skips them."""

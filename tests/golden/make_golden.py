@@ -659,7 +659,42 @@ def g13():
     save("g13_fullsize.npz", **out)
 
 
+# ------------------------------------------------------------------ G14 full-size reproducibility envelope
+def g14():
+    """Same full-size deterministic recipe as G13 (3 epochs, 4 BLAS threads), started from NT=16 round-off-sized
+    perturbations of the initial weight matrices (O.perturb_params(init_params(conf, hp, 77), trial), trial 0 = exact).
+    The oracle and the engine are run from the same starts in tests/test_fullsize.py: the three ensembles must agree in
+    distribution (means within the standard error), which is the strongest statement chaos allows at this size."""
+    ttr = dict(O.synth_table(10000, 1, snr=0.15, quant="bf16"), vlogit=np.zeros((10000, 60), np.float32), slogit=np.zeros((10000, 60), np.float32))
+    tdv = dict(O.synth_table(5600, 2, snr=0.15, quant="bf16"), vlogit=np.zeros((5600, 60), np.float32), slogit=np.zeros((5600, 60), np.float32))
+    conf = np.array(CONFS["c4"])
+    args = mkargs(inner_representation_size=128, batchnorm=True, drpt=0.0, epochs=3, batchsize=16)
+    torch.set_num_threads(4)
+    NT = 16
+    hists, bests = [], []
+    for trial in range(NT):
+        class CapP(Capture):
+            def __call__(self, a, c):
+                m = ntu.Searchable_Skeleton_Image_Net(a, c)
+                pp = O.perturb_params(O.init_params(c, hyper_of(a), 77), trial)
+                sd = m.state_dict()
+                for k, v in pp.items():
+                    sd[k].copy_(torch.from_numpy(v))
+                self.models.append(m)
+                return m
+        cap = CapP(77)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            accs = ntu.train_sampled_models([conf], cap, {"train": ListLoader(ttr, 16), "dev": ListLoader(tdv, 16)}, args, "cpu")
+        h = parse_hist(buf.getvalue())
+        hists.append(h)
+        bests.append(float(accs[0]))
+        print("g14 trial", trial, bests[-1], h[:, 1:].ravel(), flush=True)
+    # hist[trial][2*epoch + phase] = (phase, loss, acc)
+    save("g14_fullsize_envelope.npz", hist=np.array(hists), best_acc=np.array(bests), rel=np.array([1e-7]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()
