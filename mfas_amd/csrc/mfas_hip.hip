@@ -611,6 +611,96 @@ __device__ __forceinline__ void bce_rows(float* lg_l, int SC, float* red, int Bp
     }
 }
 
+// Softmax cross-entropy on the LDS logits (train_searchable/ntu.py:53-61), LPR lanes per batch row: classes c = sub,
+// sub+LPR, ... (<= 8 classes per lane, exp kept).  Leaves dlogits = (softmax - onehot)/nvalid in place, the row's loss in
+// red[b] and its top-1 hit in red[Bp + b] (multitask: argmax of central + visual + skeleton logits).
+template <int MB, int NC>
+__device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, float* lg_l, const int SC, float* red_l, const int* lab_l,
+                                                const int nvalid, const float nf, const int tid) {
+    constexpr int Bp = MB * 16;
+    constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
+    const Geo& g = a.g;
+    const int C = g.C, Cp = g.Cp;
+    const int b = tid / LPR, sub = tid % LPR;
+    float* row = lg_l + b * SC;
+    const bool ok = b < nvalid;
+    const int lab = lab_l[b];
+    // NC classes per lane (host guarantees Cp <= 8 * LPR; the caller picks NC = 4 when Cp <= 4 * LPR: the skipped
+    // iterations only ever added 0 / compared against -3e38, so the result is bit-identical)
+    float xv[NC], ev[NC];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = sub + j * LPR;
+        xv[j] = c < C ? row[c] : -3.0e38f;
+        mx = fmaxf(mx, xv[j]);
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = sub + j * LPR;
+        ev[j] = c < C ? expf(xv[j] - mx) : 0.f;
+        se += ev[j];
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) se += __shfl_xor(se, o);
+    // argmax, first max on ties (torch.max(dim=1)); multitask: central + visual + skeleton logits
+    float bv = -3.0e38f;
+    int bi = 0x7FFFFFFF;
+    const float* vl = nullptr;
+    const float* sl = nullptr;
+    if (g.multitask && ok) {
+        const int64_t grow = a.order ? (int64_t)a.order[a.pos_t + b] : (int64_t)(a.base_t + b);
+        vl = a.tab.vlogit + grow * C;
+        sl = a.tab.slogit + grow * C;
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = sub + j * LPR;
+        if (c < C) {
+            float t = xv[j];
+            if (vl) t = (t + vl[c]) + sl[c];
+            if (t > bv) { bv = t; bi = c; }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+        const float pv = __shfl_xor(bv, o);
+        const int pi = __shfl_xor(bi, o);
+        if (pv > bv || (pv == bv && pi < bi)) { bv = pv; bi = pi; }
+    }
+    const float lse = mx + logf(se);
+    if (sub == 0) {
+        red_l[b] = ok ? -(row[lab] - lse) : 0.f;
+        red_l[Bp + b] = (ok && bi == lab) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = sub + j * LPR;
+        if (c < Cp) {
+            float dl = 0.f;
+            if (ok && c < C) {
+                dl = ev[j] / se;
+                if (c == lab) dl -= 1.0f;
+                dl = dl / nf;
+            }
+            row[c] = dl;
+        }
+    }
+
+}
+
+template <int MB>
+__device__ __forceinline__ void softmax_rows(const ChainArgs& a, float* lg_l, const int SC, float* red_l, const int* lab_l,
+                                             const int nvalid, const float nf, const int tid) {
+    constexpr int Bp = MB * 16;
+    constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
+    if (a.g.Cp <= 4 * LPR) softmax_rows_nc<MB, 4>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+    else softmax_rows_nc<MB, 8>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+}
+
 #ifdef MFAS_CHAIN_TIMING
 #define CT_STAMP(slot) do { if (threadIdx.x == 0 && bid == 0 && a.gstep == 3) a.status[64 + (slot)] = (int32_t)(__builtin_readcyclecounter() - ct0); } while (0)
 #else
@@ -645,14 +735,21 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
     float* Vv = Mv + a.plane_stride;
     float* sb = a.stepbuf + cd.step_off;
     float* sav = sb + g.sb_sav;              // [3][L][nrb][MB][256]: act, xhat, (yS - yV)
+    // per-candidate scalars the serial loops need, read ONCE: the LDS barriers are compiler memory barriers, and a field
+    // of `cd` used after one is a fresh scalar load (a few hundred cycles on the critical path of every cell)
+    const int64_t cvec_off = cd.vec_off;
+    int nlbits = 0;
+#pragma unroll
+    for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
+    const int cgidx = cd.gidx;
     // reduced feature sums [1 or 2][L][nrb][MB][256]: LDS when it fits the shared budget, else scratch
     float* yf_l = a.yf_in_lds ? reinterpret_cast<float*>(lab_l + Bp) : sb + g.sb_yf;
     // vector parameters (+ their Adam state): the standalone chain stages the candidate's whole vector block into LDS
     // once, so that no dependent global load sits inside the serial cell loops; updates are written to global only
     const int nvec = MFAS_MAX_CELLS * g.vec_cell_stride + Cp;
-    const float* vecW = W + cd.vec_off;
-    const float* vecM = Mv + cd.vec_off;
-    const float* vecV = Vv + cd.vec_off;
+    const float* vecW = W + cvec_off;
+    const float* vecM = Mv + cvec_off;
+    const float* vecV = Vv + cvec_off;
     if (PF && a.vec_in_lds) {
         float* vl = reinterpret_cast<float*>(lab_l + Bp) + (a.yf_in_lds ? (g.alphas ? 2 : 1) * sav_plane : 0);
         for (int e = tid; e < nvec; e += CHAIN_THREADS) {
@@ -728,8 +825,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
         }
         const float* xprev = xo_l + ((i + 1) & 1) * Bp * SX;
         float* xcur = xo_l + (i & 1) * Bp * SX;
-        const int nl = cd.conf[i][2];
-        const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
+        const int nl = (nlbits >> (2 * i)) & 3;
+        const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
         const int vbl = i * g.vec_cell_stride;
         float sgS = 1.0f, sgV = 1.0f;
         if (g.alphas) {
@@ -869,83 +966,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
     CT_STAMP(6);
     if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
-    } else if (tid < LPR * Bp) {   // LPR lanes per row: classes c = sub, sub+LPR, ... (<= 8 classes per lane, exp kept)
-        const int b = tid / LPR, sub = tid % LPR;
-        float* row = lg_l + b * SC;
-        const bool ok = b < nvalid;
-        const int lab = lab_l[b];
-        constexpr int NC = 8;                    // classes per lane (host guarantees Cp <= NC * LPR)
-        float xv[NC], ev[NC];
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            const int c = sub + j * LPR;
-            xv[j] = c < C ? row[c] : -3.0e38f;
-            mx = fmaxf(mx, xv[j]);
-        }
-#pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float se = 0.f;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            const int c = sub + j * LPR;
-            ev[j] = c < C ? expf(xv[j] - mx) : 0.f;
-            se += ev[j];
-        }
-#pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) se += __shfl_xor(se, o);
-        // argmax, first max on ties (torch.max(dim=1)); multitask: central + visual + skeleton logits
-        float bv = -3.0e38f;
-        int bi = 0x7FFFFFFF;
-        const float* vl = nullptr;
-        const float* sl = nullptr;
-        if (g.multitask && ok) {
-            const int64_t grow = a.order ? (int64_t)a.order[a.pos_t + b] : (int64_t)(a.base_t + b);
-            vl = a.tab.vlogit + grow * C;
-            sl = a.tab.slogit + grow * C;
-        }
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            const int c = sub + j * LPR;
-            if (c < C) {
-                float t = xv[j];
-                if (vl) t = (t + vl[c]) + sl[c];
-                if (t > bv) { bv = t; bi = c; }
-            }
-        }
-#pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) {
-            const float pv = __shfl_xor(bv, o);
-            const int pi = __shfl_xor(bi, o);
-            if (pv > bv || (pv == bv && pi < bi)) { bv = pv; bi = pi; }
-        }
-        const float lse = mx + logf(se);
-        if (sub == 0) {
-            red_l[b] = ok ? -(row[lab] - lse) : 0.f;
-            red_l[Bp + b] = (ok && bi == lab) ? 1.f : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            const int c = sub + j * LPR;
-            if (c < Cp) {
-                float dl = 0.f;
-                if (ok && c < C) {
-                    dl = ev[j] / se;
-                    if (c == lab) dl -= 1.0f;
-                    dl = dl / nf;
-                }
-                row[c] = dl;
-            }
-        }
+    } else if (tid < LPR * Bp) {
+        softmax_rows<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
     }
     lds_barrier();
-    if (tid == 0) {
+    if (tid == CHAIN_THREADS - 64) {   // last wave: keeps the read-modify-write of the statistics off wave 0
         float ls = 0.f, cs = 0.f;
         for (int b = 0; b < Bp; ++b) { ls += red_l[b]; cs += red_l[Bp + b]; }
-        DevStats& st = a.stats[(int64_t)cd.gidx * a.E + a.epoch];
+        DevStats& st = a.stats[(int64_t)cgidx * a.E + a.epoch];
         st.train_loss += (double)ls;
         st.train_corr += (long long)cs;
-        if (!(fabsf(ls) <= 3.0e38f)) a.status[cd.gidx] = 1;
+        if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
     }
     CT_STAMP(7);
     // dlogits -> global (dy operand of the HEAD segment); head-bias Adam
@@ -955,11 +986,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             const int b = e / Cp, c = e - b * Cp;
             dlg[e] = lg_l[b * SC + c];
         }
-        if (tid < C) {
+        const int hc = tid - (CHAIN_THREADS - 256);   // head-bias columns on the upper four waves
+        if (hc >= 0 && hc < C) {
             float gsum = 0.f;
-            for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + tid];
-            const int64_t o = cd.vec_off + g.vec_head + tid;
-            float w = vecW[g.vec_head + tid], m = vecM[g.vec_head + tid], v = vecV[g.vec_head + tid];
+            for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + hc];
+            const int64_t o = cvec_off + g.vec_head + hc;
+            float w = vecW[g.vec_head + hc], m = vecM[g.vec_head + hc], v = vecV[g.vec_head + hc];
             adam1(w, m, v, gsum, ac);
             W[o] = w; Mv[o] = m; Vv[o] = v;
         }
@@ -975,8 +1007,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
         CT_STAMP(8 + (L - 1 - i));
         if (pf && i >= 1 && wave < nrb)   // next backward product (cell i-1) uses the transposed prev-out block of cell i
             issue_tiles(wb, a.wt + cd.outT_off[i] + (int64_t)wave * nrb * 256, nrb, lane);
-        const int nl = cd.conf[i][2];
-        const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
+        const int nl = (nlbits >> (2 * i)) & 3;
+        const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
         const int vbl = i * g.vec_cell_stride;
         const bool from_head = (i == L - 1);
         const float* src = from_head ? lg_l : dy_l + ((i + 1) & 1) * Bp * SX;
@@ -1096,6 +1128,451 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// chain_lean — the same train-step chain for ONE row block (R <= 16) and <= 4 class blocks (C <= 64): the reference's
+// search defaults (inner_representation_size 16, main_searchable_ntu.py:26-45).  A 16-wide cell is a string of ~15
+// dependent little steps, and in the general chain_body every one of them pays a workgroup barrier, fresh scalar loads of
+// the candidate record, address arithmetic for up to 32 row blocks and a global round trip for its weight tile.  Here:
+//   * everything a step needs from global memory (labels, vector block, EVERY product's weight tile, the sweep's partial
+//     sums) is requested at kernel entry — one memory latency for the whole chain;
+//   * wave 0 owns the single row block and runs all L cells forward (and later backward) back to back with no barrier:
+//     the activations of all cells stay in LDS (xo_l / dy_l [L][Bp][20]) together with the saved activations;
+//   * the other seven waves do the bulk work around it: partial-sum reduction, head / softmax, coalesced copies of
+//     out_i, dy_i and dlogits to the step buffers the sweep reads, statistics, head-bias Adam.
+// Arithmetic (operation order included) is that of chain_body.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 pick4(const f32x4 (&t)[MFAS_MAX_CELLS], int i) {
+    switch (i) { case 0: return t[0]; case 1: return t[1]; case 2: return t[2]; default: return t[3]; }
+}
+
+template <int MB>
+__device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, float* lds) {
+#ifdef MFAS_CHAIN_TIMING
+    const unsigned long long ct0 = __builtin_readcyclecounter();
+#endif
+    const CandDev& cd = a.cands[bid];
+    const Geo& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int Bp = MB * 16;
+    constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
+    constexpr int Rp = 16, SX = Rp + 4;
+    const int Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L, SC = Cp + 4;
+    constexpr int sav_plane = MFAS_MAX_CELLS * MB * 256;
+    const int nvec = MFAS_MAX_CELLS * g.vec_cell_stride + Cp;
+    float* xo_l = lds;                                          // [L][Bp][SX] out_i of every cell
+    float* dy_l = xo_l + MFAS_MAX_CELLS * Bp * SX;              // [L][Bp][SX] dy_i of every cell
+    float* lg_l = dy_l + MFAS_MAX_CELLS * Bp * SX;              // [Bp][SC] logits -> dlogits
+    float* rstd_l = lg_l + Bp * SC;                             // [L][Rp]
+    float* red_l = rstd_l + MFAS_MAX_CELLS * Rp;                // [2*Bp + 16]
+    int* lab_l = reinterpret_cast<int*>(red_l + 2 * Bp + 16);   // [Bp]
+    float* yf_l = reinterpret_cast<float*>(lab_l + Bp);         // [1 or 2][L][MB][256] reduced feature sums
+    float* vec_l = yf_l + (g.alphas ? 2 : 1) * sav_plane;       // [3][nvec] vector block + Adam state
+    float* sav_a = vec_l + 3 * nvec;                            // [L][MB][256] activations
+    float* sav_x = sav_a + sav_plane;                           // xhat (batchnorm only)
+    float* sav_d = sav_a + (g.bn ? 2 : 1) * sav_plane;          // yS - yV (alphas only)
+
+    float* W = a.plane;
+    float* Mv = a.plane + a.plane_stride;
+    float* Vv = Mv + a.plane_stride;
+    float* sb = a.stepbuf + cd.step_off;
+    const int64_t cvec_off = cd.vec_off;
+    const int cgidx = cd.gidx;
+    int nlbits = 0;
+#pragma unroll
+    for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
+    const int nvalid = a.nvalid;
+    const float nf = (float)nvalid;
+    const AdamC ac = a.ac;
+    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(a.gstep + 1));
+
+    // ------------------------------------------------------------------ entry: every global read of the chain is
+    // requested here, in the order the results are needed (the memory counter retires in order): the sweep's partial
+    // sums first, then the vector block, the weight tiles of all products and last the labels (a dependent pair of loads
+    // that nothing needs before the loss, fetched by wave 1 so that wave 0 never waits for them)
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int per_cell = MB * 64;   // float4 partial-sum items per cell; L * per_cell <= 512: one item per thread
+    constexpr int PB = 16;
+    const bool has_item = tid < L * per_cell;
+    const int pi = has_item ? tid / per_cell : 0, pit = tid - pi * per_cell;
+    const int ns = cd.nch_s[pi], nch = has_item ? ns + cd.nch_v[pi] : 0;
+    const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[pi] * MB) << 8) + pit * 4;
+    f32x4 p8[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u)
+        if (u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)u * MB) << 8));
+    float vw = 0.f, vm = 0.f, vv = 0.f;   // nvec = 4 * 96 + Cp <= 448: one element of the vector block per thread
+    if (tid < nvec) { vw = W[cvec_off + tid]; vm = Mv[cvec_off + tid]; vv = Vv[cvec_off + tid]; }
+    f32x4 tP[MFAS_MAX_CELLS], tT[MFAS_MAX_CELLS], tHT[4], tH = z4;   // prev-out tile of cell i, its transpose, head^T, head
+#pragma unroll
+    for (int i = 0; i < MFAS_MAX_CELLS; ++i) { tP[i] = z4; tT[i] = z4; tHT[i] = z4; }
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 1; i < MFAS_MAX_CELLS; ++i)
+            if (i < L) {
+                tP[i] = *reinterpret_cast<const f32x4*>(W + cd.seg_off[i][2] + lane * 4);
+                tT[i] = *reinterpret_cast<const f32x4*>(a.wt + cd.outT_off[i] + lane * 4);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < ncb) tHT[u] = *reinterpret_cast<const f32x4*>(a.wt + cd.headT_off + ((int64_t)u << 8) + lane * 4);
+    }
+    if (wave < ncb) tH = *reinterpret_cast<const f32x4*>(W + cd.head_off + ((int64_t)wave << 8) + lane * 4);
+    int lab = 0;
+    if (wave == 1 && lane < nvalid) {
+        const int64_t row = a.order ? (int64_t)a.order[a.pos_t + lane] : (int64_t)(a.base_t + lane);
+        lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
+    }
+    // dropout keep bits of this lane's elements (wave 0 owns the row block): bit (i*MB + mb)*4 + q — computed while the
+    // loads above are in flight, used by the forward AND the backward pass
+    const int r = l15;
+    const bool colok = r < R;
+    uint32_t keep = 0xFFFFFFFFu;
+    if (wave == 0 && g.use_drop) {
+#pragma unroll
+        for (int i = 0; i < MFAS_MAX_CELLS; ++i)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (!drop_keep(h0, i, (uint32_t)((mb * 16 + 4 * lg + q) * R + r), g.drop_thr)) keep &= ~(1u << ((i * MB + mb) * 4 + q));
+    }
+    // phase 0: reduce the sweep's column-chunk partial sums (fixed order) into LDS; stage the vector block
+    if (has_item) {
+        f32x4 accS = z4, accV = z4;
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+            if (u < nch) {
+                if (u < ns) accS += p8[u]; else accV += p8[u];
+            }
+        for (int ch0 = PB; ch0 < nch; ch0 += PB) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+                if (ch0 + u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)(ch0 + u) * MB) << 8));
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+                if (ch0 + u < nch) {
+                    if (ch0 + u < ns) accS += p8[u]; else accV += p8[u];
+                }
+        }
+        if (g.alphas) {
+            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS;
+            *reinterpret_cast<f32x4*>(yf_l + sav_plane + tid * 4) = accV;
+        } else {
+            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS + accV;
+        }
+    }
+    if (tid < nvec) { vec_l[tid] = vw; vec_l[nvec + tid] = vm; vec_l[2 * nvec + tid] = vv; }
+    const float* vecW = vec_l;
+    const float* vecM = vec_l + nvec;
+    const float* vecV = vec_l + 2 * nvec;
+    lds_barrier();
+    CT_STAMP(0);
+
+    // ------------------------------------------------------------------ forward: wave 0, all cells, no barrier
+    if (wave == 0) {
+        for (int i = 0; i < L; ++i) {
+            CT_STAMP(1 + i);
+            const int nl = (nlbits >> (2 * i)) & 3;
+            const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
+            const int vbl = i * g.vec_cell_stride;
+            const float bias = vecW[vbl + VEC_B * Rp + r];
+            float gam = 1.f, bet = 0.f;
+            if (g.bn) { gam = vecW[vbl + VEC_G * Rp + r]; bet = vecW[vbl + VEC_BE * Rp + r]; }
+            float sgS = 1.0f, sgV = 1.0f;
+            if (g.alphas) {
+                const float sg = 1.0f / (1.0f + expf(-vecW[vbl + 5 * Rp]));
+                sgS = sg;
+                sgV = 1.0f - sg;
+                if (lane == 0) {
+                    sb[g.sb_gsc + i * 2] = sgS;
+                    sb[g.sb_gsc + i * 2 + 1] = sgV;
+                }
+            }
+            f32x4 acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int o = ((i * MB + mb) << 8) + lane * 4;
+                acc[mb] = *reinterpret_cast<const f32x4*>(yf_l + o);
+                if (g.alphas) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yf_l + sav_plane + o);
+                    *reinterpret_cast<f32x4*>(sav_d + o) = acc[mb] - yv;
+                    acc[mb] = acc[mb] * sgS + yv * sgV;
+                }
+            }
+            if (i > 0) {
+                const f32x4 w = pick4(tP, i);
+                const float* xprev = xo_l + (i - 1) * Bp * SX;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xprev + (mb * 16 + l15) * SX + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w[q], acc[mb]);
+                }
+            }
+            float av[MB][4];
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    const float v = act_fwd(acc[mb][q] + bias, nl);
+                    av[mb][q] = v;
+                    if (b < nvalid) s += v;
+                }
+            float zv[MB][4];
+            if (g.bn) {
+                const float mu = colsum(s) / nf;
+                float s2 = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        const float dlt = av[mb][q] - mu;
+                        if (b < nvalid) s2 += dlt * dlt;
+                    }
+                const float var = colsum(s2) / nf;
+                const float rstd = 1.0f / sqrtf(var + g.bn_eps);
+                f32x4 xh4[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float xh = (av[mb][q] - mu) * rstd;
+                        xh4[mb][q] = xh;
+                        zv[mb][q] = xh * gam + bet;
+                    }
+                if (lg == 0) {
+                    rstd_l[i * Rp + r] = rstd;
+                    if (colok) {   // running stats: momentum 0.1, unbiased variance
+                        float rm = vecW[vbl + VEC_RM * Rp + r], rv = vecW[vbl + VEC_RV * Rp + r];
+                        const float unb = var * (nf / (nf - 1.0f));
+                        rm += g.bn_mom * (mu - rm);
+                        rv += g.bn_mom * (unb - rv);
+                        W[vb + VEC_RM * Rp + r] = rm;
+                        W[vb + VEC_RV * Rp + r] = rv;
+                    }
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    *reinterpret_cast<f32x4*>(sav_x + ((i * MB + mb) << 8) + lane * 4) = xh4[mb];
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zv[mb][q] = av[mb][q];
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = av[mb][q];
+                *reinterpret_cast<f32x4*>(sav_a + ((i * MB + mb) << 8) + lane * 4) = a4;
+            }
+            float* xcur = xo_l + i * Bp * SX;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float o = zv[mb][q];
+                    if (g.use_drop) o = ((keep >> ((i * MB + mb) * 4 + q)) & 1u) ? o * g.drop_scale : 0.0f;
+                    if (!(colok && b < nvalid)) o = 0.0f;
+                    xcur[b * SX + r] = o;
+                }
+        }
+    }
+    if (wave == 1 && lane < Bp) lab_l[lane] = lab;   // visible to the loss after the head's barrier
+    lds_barrier();
+    CT_STAMP(5);
+
+    // ------------------------------------------------------------------ out_i -> step buffer (x operand of the sweep's
+    // OUT / HEAD segments), coalesced, by everyone; head on waves < ncb
+    {
+        float* xo_g = sb + g.sb_xo;   // [L][Bp][Rp]
+        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) xo_g[e] = xo_l[(e >> 4) * SX + (e & 15)];
+        const float* xl = xo_l + (L - 1) * Bp * SX;
+        if (wave < ncb) {
+            const int c = wave * 16 + l15;
+            const float bias = vecW[g.vec_head + c];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x4 acc = z4;
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xl + (mb * 16 + l15) * SX + 4 * lg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], tH[q], acc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lg_l[(mb * 16 + 4 * lg + q) * SC + c] = acc[q] + bias;
+            }
+        }
+    }
+    lds_barrier();
+    CT_STAMP(6);
+    if (g.loss_mode == 1) {
+        if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
+    } else if (tid < LPR * Bp) {
+        softmax_rows<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+    }
+    lds_barrier();
+    CT_STAMP(7);
+    if (tid == CHAIN_THREADS - 64) {
+        float ls = 0.f, cs = 0.f;
+        for (int b = 0; b < Bp; ++b) { ls += red_l[b]; cs += red_l[Bp + b]; }
+        DevStats& st = a.stats[(int64_t)cgidx * a.E + a.epoch];
+        st.train_loss += (double)ls;
+        st.train_corr += (long long)cs;
+        if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
+    }
+    if (wave != 0) {   // dlogits -> step buffer (dy operand of the HEAD segment); head-bias Adam
+        float* dlg = sb + g.sb_dlog;
+        for (int e = tid - 64; e < Bp * Cp; e += CHAIN_THREADS - 64) {
+            const int b = e / Cp, c = e - b * Cp;
+            dlg[e] = lg_l[b * SC + c];
+        }
+        const int hc = tid - (CHAIN_THREADS - 256);
+        if (hc >= 0 && hc < C) {
+            float gsum = 0.f;
+            for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + hc];
+            const int64_t o = cvec_off + g.vec_head + hc;
+            float w = vecW[g.vec_head + hc], m = vecM[g.vec_head + hc], v = vecV[g.vec_head + hc];
+            adam1(w, m, v, gsum, ac);
+            W[o] = w; Mv[o] = m; Vv[o] = v;
+        }
+    } else {
+        // -------------------------------------------------------------- backward: wave 0, all cells, no barrier
+        for (int i = L - 1; i >= 0; --i) {
+            CT_STAMP(8 + (L - 1 - i));
+            const int nl = (nlbits >> (2 * i)) & 3;
+            const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
+            const int vbl = i * g.vec_cell_stride;
+            const bool from_head = (i == L - 1);
+            float gr = 0.f;
+            if (g.bn) gr = vecW[vbl + VEC_G * Rp + r] * rstd_l[i * Rp + r];
+            const int64_t ob = vb + VEC_B * Rp + r, og = vb + VEC_G * Rp + r, obe = vb + VEC_BE * Rp + r;
+            float pw[3] = {0.f, 0.f, 0.f}, pm[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f};
+            if (lg == 0 && colok) {
+                const int lb = vbl + VEC_B * Rp + r, lgm = vbl + VEC_G * Rp + r, lbe = vbl + VEC_BE * Rp + r;
+                pw[0] = vecW[lb]; pm[0] = vecM[lb]; pv[0] = vecV[lb];
+                if (g.bn) {
+                    pw[1] = vecW[lgm]; pm[1] = vecM[lgm]; pv[1] = vecV[lgm];
+                    pw[2] = vecW[lbe]; pm[2] = vecM[lbe]; pv[2] = vecV[lbe];
+                }
+            }
+            f32x4 a4[MB], xh4[MB], df4[MB], acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int o = ((i * MB + mb) << 8) + lane * 4;
+                a4[mb] = *reinterpret_cast<const f32x4*>(sav_a + o);
+                xh4[mb] = z4;
+                df4[mb] = z4;
+                if (g.bn) xh4[mb] = *reinterpret_cast<const f32x4*>(sav_x + o);
+                if (g.alphas) df4[mb] = *reinterpret_cast<const f32x4*>(sav_d + o);
+                acc[mb] = z4;
+            }
+            if (from_head) {   // d_out = dlogits . Wc: even / odd class blocks in two chains (as mma_tiles)
+                f32x4 acc2[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc2[mb] = z4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < ncb) {
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(lg_l + (mb * 16 + l15) * SC + u * 16 + 4 * lg);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (u & 1) acc2[mb] = MFMA16(x4[q], tHT[u][q], acc2[mb]);
+                                else acc[mb] = MFMA16(x4[q], tHT[u][q], acc[mb]);
+                            }
+                        }
+                    }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] += acc2[mb];
+            } else {
+                const f32x4 w = pick4(tT, i + 1);
+                const float* src = dy_l + (i + 1) * Bp * SX;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(src + (mb * 16 + l15) * SX + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w[q], acc[mb]);
+                }
+            }
+            float dz[MB][4];
+            float sdz = 0.f, sdzx = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float d = acc[mb][q];
+                    if (g.use_drop) d = ((keep >> ((i * MB + mb) * 4 + q)) & 1u) ? d * g.drop_scale : 0.0f;
+                    if (!(b < nvalid)) d = 0.f;
+                    dz[mb][q] = d;
+                    sdz += d;
+                    if (g.bn) sdzx += d * xh4[mb][q];
+                }
+            float dgam = 0.f, dbet = 0.f;
+            if (g.bn) {
+                dbet = colsum(sdz);
+                dgam = colsum(sdzx);
+                const float k1 = dbet / nf, k2 = dgam / nf;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        const float da = gr * (dz[mb][q] - k1 - xh4[mb][q] * k2);
+                        dz[mb][q] = b < nvalid ? da : 0.f;
+                    }
+            }
+            float sdy = 0.f, dalpha = 0.f;
+            float* dcur = dy_l + i * Bp * SX;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float dy = act_bwd(a4[mb][q], dz[mb][q], nl);
+                    if (!colok) dy = 0.f;
+                    sdy += dy;
+                    dalpha += dy * df4[mb][q];
+                    dcur[b * SX + r] = dy;
+                }
+            const float db = colsum(sdy);
+            if (lg == 0 && colok) {   // Adam on the column's vector parameters (one owner lane per column)
+                adam1(pw[0], pm[0], pv[0], db, ac);
+                W[ob] = pw[0]; Mv[ob] = pm[0]; Vv[ob] = pv[0];
+                if (g.bn) {
+                    adam1(pw[1], pm[1], pv[1], dgam, ac);
+                    W[og] = pw[1]; Mv[og] = pm[1]; Vv[og] = pv[1];
+                    adam1(pw[2], pm[2], pv[2], dbet, ac);
+                    W[obe] = pw[2]; Mv[obe] = pm[2]; Vv[obe] = pv[2];
+                }
+            }
+            if (g.alphas) {   // d(alpha_i) = sigma'(alpha) * sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]
+                for (int o = 32; o > 0; o >>= 1) dalpha += __shfl_xor(dalpha, o);
+                if (lane == 0) {
+                    const float tot = dalpha;
+                    const int64_t o = vb + 5 * Rp;
+                    float w = vecW[vbl + 5 * Rp], m = vecM[vbl + 5 * Rp], v = vecV[vbl + 5 * Rp];
+                    const float sg = 1.0f / (1.0f + expf(-w));
+                    adam1(w, m, v, tot * sg * (1.0f - sg), ac);
+                    W[o] = w; Mv[o] = m; Vv[o] = v;
+                }
+            }
+        }
+    }
+    lds_barrier();
+    CT_STAMP(12);
+    {   // dy_i -> step buffer (dy operand of the sweep), coalesced
+        float* dy_g = sb + g.sb_dy;   // [L][Bp][Rp]
+        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) dy_g[e] = dy_l[(e >> 4) * SX + (e & 15)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_step — ONE launch per half-step: blocks [0, nchain) run the chain of one candidate group while the other
 // blocks run the sweep of the OTHER group (candidates are independent).  The latency-bound chain hides under
 // the HBM-bound sweep; kernel boundaries carry every dependency (chain(t) -> sweep(t) -> chain(t+1) of a group).
@@ -1106,21 +1583,25 @@ struct StepArgs {
     int32_t nchain, _pad;
 };
 
-template <int MB, bool NT, int WPE>
+template <int MB, bool NT, int WPE, bool LEAN>
 __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bid = (int)blockIdx.x;
-    if (bid < a.nchain) chain_body<MB, false>(a.ca, bid, lds);
+    if (bid < a.nchain) {
+        if constexpr (LEAN) chain_lean<MB>(a.ca, bid, lds);
+        else chain_body<MB, false>(a.ca, bid, lds);
+    }
     else if (bid < a.nchain + a.sa.ntap) sweep_tap_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain, lds);
     else sweep_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain - a.sa.ntap, lds);
 }
 
 // Standalone chain launch (small populations: chain and sweep run back to back, so the chain's latency is on the
 // critical path): full register budget, next-product weight tiles prefetched into registers.
-template <int MB>
+template <int MB, bool LEAN>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_chain(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    chain_body<MB, true>(a, (int)blockIdx.x, lds);
+    if constexpr (LEAN) chain_lean<MB>(a, (int)blockIdx.x, lds);
+    else chain_body<MB, true>(a, (int)blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1626,6 +2107,7 @@ struct mfas_population {
     bool vec_in_lds = false;
     int mbe = 4, nrbw = 1;
     bool yf_in_lds = false;
+    bool lean_chain = false;        // chain_lean (R <= 16, C <= 64, B <= 32) in standalone and fused launches
     bool nontemporal = false;
     int stats_cap = 0;
     // profiling of the dominant kernel
@@ -1857,6 +2339,12 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         const size_t vec = (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp) * 4;
         p->vec_in_lds = base + (p->yf_in_lds ? yf : 0) + vec <= 150 * 1024;
         p->lds_chain = base + (p->yf_in_lds ? yf : 0) + (p->vec_in_lds ? vec : 0);
+        // chain_lean's LDS: out_i / dy_i of all cells, logits, misc, reduced sums, vector block, saved activations
+        const size_t plane = (size_t)MFAS_MAX_CELLS * g.MB * 256;
+        const size_t lean = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
+                             + (g.alphas ? 2 : 1) * plane + vec / 4 + (1 + (g.bn ? 1 : 0) + (g.alphas ? 1 : 0)) * plane) * 4;
+        p->lean_chain = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && std::max(ls, lean) <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
+        if (p->lean_chain) { p->lds_chain = lean; p->lds_step = std::max(p->lds_step, lean); }
     }
     p->nrbw = (g.nrb + 3) / 4;
     if (p->nrbw == 3) p->nrbw = 4;
@@ -1974,17 +2462,15 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     // (the spilling chain of the occupancy build takes ~40 / ~125 us there)
     p->occ_bytes = g.nrb >= 8 ? 450e6 : 250e6;
     if (const char* e = getenv("MFAS_OCC_BYTES")) p->occ_bytes = atof(e);
-    CREATE_CHK(set_lds((k_step<1, false, 4>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<2, false, 2>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<2, false, 4>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<4, false, 2>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<1, true, 4>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<2, true, 2>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<2, true, 4>), p->lds_step));
-    CREATE_CHK(set_lds((k_step<4, true, 2>), p->lds_step));
-    CREATE_CHK(set_lds(k_chain<1>, p->lds_chain));
-    CREATE_CHK(set_lds(k_chain<2>, p->lds_chain));
-    CREATE_CHK(set_lds(k_chain<4>, p->lds_chain));
+#define SET_STEP(M, W, F) CREATE_CHK(set_lds((k_step<M, false, W, F>), p->lds_step)); CREATE_CHK(set_lds((k_step<M, true, W, F>), p->lds_step))
+    SET_STEP(1, 4, false); SET_STEP(2, 2, false); SET_STEP(2, 4, false); SET_STEP(4, 2, false);
+    SET_STEP(1, 4, true); SET_STEP(2, 2, true); SET_STEP(2, 4, true);
+#undef SET_STEP
+    CREATE_CHK(set_lds((k_chain<1, false>), p->lds_chain));
+    CREATE_CHK(set_lds((k_chain<2, false>), p->lds_chain));
+    CREATE_CHK(set_lds((k_chain<4, false>), p->lds_chain));
+    CREATE_CHK(set_lds((k_chain<1, true>), p->lds_chain));
+    CREATE_CHK(set_lds((k_chain<2, true>), p->lds_chain));
     // W/m/v beyond what the 256 MiB Infinity Cache can keep between steps are streamed nontemporally
     p->nontemporal = (double)p->plane_stride * 12.0 > 200.0 * 1024 * 1024;
     if (const char* e = getenv("MFAS_NT")) p->nontemporal = atoi(e) != 0;
@@ -2178,23 +2664,23 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             hipEventRecord(p->ev[ev_used], p->stream);
         }
         if (nsw == 0) {   // chain only: the latency-tuned standalone kernel
-            if (g.MB == 1) hipLaunchKernelGGL(k_chain<1>, dim3(nch), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca);
-            else if (g.MB == 2) hipLaunchKernelGGL(k_chain<2>, dim3(nch), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca);
-            else hipLaunchKernelGGL(k_chain<4>, dim3(nch), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca);
+#define CHAIN_LAUNCH(M, F) hipLaunchKernelGGL((k_chain<M, F>), dim3(nch), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca)
+            if (p->lean_chain) { if (g.MB == 1) CHAIN_LAUNCH(1, true); else CHAIN_LAUNCH(2, true); }
+            else if (g.MB == 1) CHAIN_LAUNCH(1, false);
+            else if (g.MB == 2) CHAIN_LAUNCH(2, false);
+            else CHAIN_LAUNCH(4, false);
+#undef CHAIN_LAUNCH
             return;
         }
-#define STEP_LAUNCH(M, T, W) hipLaunchKernelGGL((k_step<M, T, W>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
+#define STEP_LAUNCH(M, T, W, F) hipLaunchKernelGGL((k_step<M, T, W, F>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
+#define STEP_PICK(M, W) do { if (p->nontemporal) { if (p->lean_chain) STEP_LAUNCH(M, true, W, true); else STEP_LAUNCH(M, true, W, false); } \
+                             else { if (p->lean_chain) STEP_LAUNCH(M, false, W, true); else STEP_LAUNCH(M, false, W, false); } } while (0)
         // MB == 2: the two-workgroups-per-CU build unless a co-scheduled chain would bound the launch (see SweepU)
         const bool occ = nch == 0 || p->groups[gs].alg_state > p->occ_bytes;
-        if (p->nontemporal) {
-            if (g.MB == 1) STEP_LAUNCH(1, true, 4);
-            else if (g.MB == 2) { if (occ) STEP_LAUNCH(2, true, 4); else STEP_LAUNCH(2, true, 2); }
-            else STEP_LAUNCH(4, true, 2);
-        } else {
-            if (g.MB == 1) STEP_LAUNCH(1, false, 4);
-            else if (g.MB == 2) { if (occ) STEP_LAUNCH(2, false, 4); else STEP_LAUNCH(2, false, 2); }
-            else STEP_LAUNCH(4, false, 2);
-        }
+        if (g.MB == 1) STEP_PICK(1, 4);
+        else if (g.MB == 2) { if (occ || p->lean_chain) STEP_PICK(2, 4); else STEP_PICK(2, 2); }   // chain_lean never spills
+        else { if (p->nontemporal) STEP_LAUNCH(4, true, 2, false); else STEP_LAUNCH(4, false, 2, false); }
+#undef STEP_PICK
 #undef STEP_LAUNCH
         if (prof) {
             hipEventRecord(p->ev[ev_used + 1], p->stream);
