@@ -8,7 +8,7 @@ import pytest
 
 torch = pytest.importorskip("torch")
 from oracle import np_oracle as O
-from tests.helpers import engine_hyper, etas_for, oracle_steps
+from tests.helpers import engine_hyper, etas_for, oracle_steps, rel_err
 from tests.test_gpu_parity import check_state, mk_pop, table
 
 pytestmark = pytest.mark.gpu
@@ -52,4 +52,15 @@ def test_random_population_steps(case):
     for k, c in enumerate(confs):
         params, st, losses = oracle_steps(c, hp, O.init_params(c, hp, 900 + 10 * case + k, perturb_bn=True), t, steps, seed=seeds[k])
         check_state(pop, k, params, st, steps, tag=f"case{case}/cand{k}/R{hp.R}/B{hp.B}/C{hp.C}/bn{hp.bn}/d{hp.drpt}/a{hp.alphas}/m{hp.multitask}")
+    # eval-mode forward (k_eval) of the trained state on a ragged row range, against the oracle fed the ENGINE's parameters
+    tab = table(t, dev)
+    for k, c in enumerate(confs):
+        P = {key: v.numpy() for key, v in pop.get_state_dict(k).items()}
+        row0, nrows = int(rng.integers(0, 3)), int(N - 3)
+        logits, corr = pop.forward(k, tab, row0=row0, nrows=nrows, count=True)
+        feats = {key: v[row0:row0 + nrows] for key, v in t.items() if key != "label"}
+        want, _ = O.forward(P, c, hp, feats, False)
+        assert rel_err(logits.cpu().numpy(), want) < 2e-4, (case, k)
+        pred = (want + feats["vlogit"] + feats["slogit"]).argmax(1) if hp.multitask else want.argmax(1)
+        assert abs(corr - int((pred == t["label"][row0:row0 + nrows]).sum())) <= 1, (case, k)
     pop.close()
