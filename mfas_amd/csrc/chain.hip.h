@@ -1,0 +1,1096 @@
+// chain.hip.h — the serial train-step chain of one candidate: general (chain_body) and latency-lean small-R (chain_lean) forms
+// (part of the single translation unit mfas_hip.hip; see the header comment there and DESIGN.md)
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// k_chain — one 8-wave workgroup per candidate: forward chain, CE loss, backward chain (train step).
+// Latency-bound by construction (serial in the cells), so: every wave owns one 16-column block, weight
+// tiles of a product are requested in one batch before the MFMAs, saved activations live in LDS.
+// ------------------------------------------------------------------------------------------------
+struct ChainArgs {
+    const CandDev* cands;
+    float* plane;
+    int64_t plane_stride;
+    const float* wt;
+    float* stepbuf;
+    mfas_table tab;
+    const int32_t* order;
+    int64_t pos_t;
+    int32_t base_t, nvalid;
+    int32_t gstep, epoch, E;
+    int32_t yf_in_lds, vec_in_lds;
+    AdamC ac;
+    Geo g;
+    DevStats* stats;
+    int32_t* status;
+    const float* pos_w;   // loss_mode 1: per-class positive weights
+};
+
+#define CHAIN_NW STEP_NW
+#define CHAIN_THREADS STEP_THREADS
+
+__device__ __forceinline__ bool drop_keep(uint32_t h0, int cell, uint32_t idx, uint32_t thr) {
+    // oracle/np_oracle.py:dropout_keep
+    const uint32_t key = idx + (uint32_t)cell * 0x7F4A7C15U;
+    return (lowbias32(key ^ h0) >> 8) >= thr;
+}
+
+// acc[mb] += X[b][0..16*nk) . tile(k)   (X in LDS row-major with stride sx; tiles: 256 floats each, stride tstride)
+template <int MB>
+__device__ __forceinline__ void lds_x_times_tiles(f32x4 (&acc)[MB], const float* X, int sx, const float* tiles,
+                                                  int64_t tstride, int nk, int lane) {
+    // same arithmetic as mma_tiles: even / odd k-blocks in two independent chains, summed at the end
+    const int l15 = lane & 15, lg = lane >> 4;
+    f32x4 acc2[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc2[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < nk; k0 += 8) {
+        f32x4 w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nk) w8[u] = *reinterpret_cast<const f32x4*>(tiles + (int64_t)(k0 + u) * tstride + lane * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nk) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(X + (mb * 16 + l15) * sx + (k0 + u) * 16 + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (u & 1) acc2[mb] = MFMA16(x4[q], w8[u][q], acc2[mb]);
+                        else acc[mb] = MFMA16(x4[q], w8[u][q], acc[mb]);
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] += acc2[mb];
+}
+
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic (lgkmcnt) but NOT for its
+// outstanding global stores, which __syncthreads() would (s_waitcnt vmcnt(0) = a full store round trip per cell).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Software pipelining of the chain: the weight tiles of a product do not depend on the activations, so a wave
+// requests the NEXT product's tiles (<= 8 tiles = 32 VGPRs) before it starts the current one.
+__device__ __forceinline__ void issue_tiles(f32x4 (&w8)[8], const float* tiles, int nk, int lane) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nk) w8[u] = *reinterpret_cast<const f32x4*>(tiles + (int64_t)u * 256 + lane * 4);
+}
+
+// acc[mb] += X[b][0..16*nk) . w8[k]; even / odd k-blocks accumulate in two independent MFMA chains
+template <int MB>
+__device__ __forceinline__ void mma_tiles(f32x4 (&acc)[MB], const float* X, int sx, const f32x4 (&w8)[8], int nk, int lane) {
+    const int l15 = lane & 15, lg = lane >> 4;
+    f32x4 acc2[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc2[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nk) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(X + (mb * 16 + l15) * sx + u * 16 + 4 * lg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (u & 1) acc2[mb] = MFMA16(x4[q], w8[u][q], acc2[mb]);
+                    else acc[mb] = MFMA16(x4[q], w8[u][q], acc[mb]);
+                }
+            }
+        }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] += acc2[mb];
+}
+
+// WeightedCrossEntropyWithLogits (models/central/mm_imdb.py:655-673) on the LDS logits, 4 lanes per row:
+// L = mean_{b,c}[ w_c z (-log s) + (1 - z)(-log(1 - s)) ], s = sigmoid(x);  dlogit = (-w_c z (1 - s) + (1 - z) s) / (B*C).
+// red[b] receives the row's share of the BATCH-MEAN loss times nvalid (so that sum_b red[b] = loss * batch size,
+// train_searchable/mmimdb.py:96), red[Bp + b] = 0.
+__device__ __forceinline__ void bce_rows(float* lg_l, int SC, float* red, int Bp, const int* rowidx,
+                                         const float* multilabel, const float* pos_w, int C, int Cp, int nvalid, int tid) {
+    const int b = tid >> 2, sub = tid & 3;
+    float* row = lg_l + b * SC;
+    const bool ok = b < nvalid;
+    const float* z = ok ? multilabel + (int64_t)rowidx[b] * C : nullptr;
+    float ls = 0.f;
+    const float inv = 1.0f / ((float)nvalid * (float)C);
+    for (int c = sub; c < Cp; c += 4) {
+        float dl = 0.f;
+        if (ok && c < C) {
+            const float sg = 1.0f / (1.0f + expf(-row[c]));
+            const float zz = z[c], w = pos_w[c];
+            ls += w * zz * -logf(sg) + (1.0f - zz) * -logf(1.0f - sg);
+            dl = (-w * zz * (1.0f - sg) + (1.0f - zz) * sg) * inv;
+        }
+        row[c] = dl;
+    }
+    ls += __shfl_xor(ls, 1);
+    ls += __shfl_xor(ls, 2);
+    if (sub == 0) {
+        red[b] = ls / (float)C;      // sum_b red[b] / nvalid = batch-mean loss
+        red[Bp + b] = 0.f;
+    }
+}
+
+// Softmax cross-entropy on the LDS logits (train_searchable/ntu.py:53-61), LPR lanes per batch row: classes c = sub,
+// sub+LPR, ... (<= 8 classes per lane, exp kept).  Leaves dlogits = (softmax - onehot)/nvalid in place, the row's loss in
+// red[b] and its top-1 hit in red[Bp + b] (multitask: argmax of central + visual + skeleton logits).
+template <int MB, int NC>
+__device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, float* lg_l, const int SC, float* red_l, const int* lab_l,
+                                                const int nvalid, const float nf, const int tid) {
+    constexpr int Bp = MB * 16;
+    constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
+    const Geo& g = a.g;
+    const int C = g.C, Cp = g.Cp;
+    const int b = tid / LPR, sub = tid % LPR;
+    float* row = lg_l + b * SC;
+    const bool ok = b < nvalid;
+    const int lab = lab_l[b];
+    // NC classes per lane (host guarantees Cp <= 8 * LPR; the caller picks NC = 4 when Cp <= 4 * LPR: the skipped
+    // iterations only ever added 0 / compared against -3e38, so the result is bit-identical)
+    float xv[NC], ev[NC];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = sub + j * LPR;
+        xv[j] = c < C ? row[c] : -3.0e38f;
+        mx = fmaxf(mx, xv[j]);
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = sub + j * LPR;
+        ev[j] = c < C ? expf(xv[j] - mx) : 0.f;
+        se += ev[j];
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) se += __shfl_xor(se, o);
+    // argmax, first max on ties (torch.max(dim=1)); multitask: central + visual + skeleton logits
+    float bv = -3.0e38f;
+    int bi = 0x7FFFFFFF;
+    const float* vl = nullptr;
+    const float* sl = nullptr;
+    if (g.multitask && ok) {
+        const int64_t grow = a.order ? (int64_t)a.order[a.pos_t + b] : (int64_t)(a.base_t + b);
+        vl = a.tab.vlogit + grow * C;
+        sl = a.tab.slogit + grow * C;
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = sub + j * LPR;
+        if (c < C) {
+            float t = xv[j];
+            if (vl) t = (t + vl[c]) + sl[c];
+            if (t > bv) { bv = t; bi = c; }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+        const float pv = __shfl_xor(bv, o);
+        const int pi = __shfl_xor(bi, o);
+        if (pv > bv || (pv == bv && pi < bi)) { bv = pv; bi = pi; }
+    }
+    const float lse = mx + logf(se);
+    if (sub == 0) {
+        red_l[b] = ok ? -(row[lab] - lse) : 0.f;
+        red_l[Bp + b] = (ok && bi == lab) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = sub + j * LPR;
+        if (c < Cp) {
+            float dl = 0.f;
+            if (ok && c < C) {
+                dl = ev[j] / se;
+                if (c == lab) dl -= 1.0f;
+                dl = dl / nf;
+            }
+            row[c] = dl;
+        }
+    }
+
+}
+
+template <int MB>
+__device__ __forceinline__ void softmax_rows(const ChainArgs& a, float* lg_l, const int SC, float* red_l, const int* lab_l,
+                                             const int nvalid, const float nf, const int tid) {
+    constexpr int Bp = MB * 16;
+    constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
+    if (a.g.Cp <= 4 * LPR) softmax_rows_nc<MB, 4>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+    else softmax_rows_nc<MB, 8>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+}
+
+#ifdef MFAS_CHAIN_TIMING
+#define CT_STAMP(slot) do { if (threadIdx.x == 0 && bid == 0 && a.gstep == 3) a.status[64 + (slot)] = (int32_t)(__builtin_readcyclecounter() - ct0); } while (0)
+#else
+#define CT_STAMP(slot) do { } while (0)
+#endif
+
+template <int MB, bool PF>
+__device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, float* lds) {
+#ifdef MFAS_CHAIN_TIMING
+    const unsigned long long ct0 = __builtin_readcyclecounter();
+#endif
+    const CandDev& cd = a.cands[bid];
+    const Geo& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int Bp = MB * 16;
+    constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;   // softmax lanes per batch row
+    const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
+    const int SX = Rp + 4, SC = Cp + 4;
+    // LDS kept close to the sweep's so both bodies can share one launch: ping-pong activation buffers (out_i
+    // going forward, reused for dy_i coming back), logits, reduced feature sums; saved activations go to L2 scratch.
+    float* xo_l = lds;                       // [2][Bp][SX]  ping-pong out_i (A operand of the next cell)
+    float* dy_l = xo_l;                      // backward reuses the same two buffers for dy_i
+    float* lg_l = xo_l + 2 * Bp * SX;        // [Bp][SC]  logits -> dlogits
+    float* rstd_l = lg_l + Bp * SC;          // [L][Rp]
+    float* red_l = rstd_l + MFAS_MAX_CELLS * Rp;   // [2*Bp] loss / correct per row (+ alpha partials)
+    int* lab_l = reinterpret_cast<int*>(red_l + 2 * Bp + 16);   // [Bp]
+    const int64_t sav_plane = (int64_t)MFAS_MAX_CELLS * nrb * MB * 256;
+
+    float* W = a.plane;
+    float* Mv = a.plane + a.plane_stride;
+    float* Vv = Mv + a.plane_stride;
+    float* sb = a.stepbuf + cd.step_off;
+    float* sav = sb + g.sb_sav;              // [3][L][nrb][MB][256]: act, xhat, (yS - yV)
+    // per-candidate scalars the serial loops need, read ONCE: the LDS barriers are compiler memory barriers, and a field
+    // of `cd` used after one is a fresh scalar load (a few hundred cycles on the critical path of every cell)
+    const int64_t cvec_off = cd.vec_off;
+    int nlbits = 0;
+#pragma unroll
+    for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
+    const int cgidx = cd.gidx;
+    // reduced feature sums [1 or 2][L][nrb][MB][256]: LDS when it fits the shared budget, else scratch
+    float* yf_l = a.yf_in_lds ? reinterpret_cast<float*>(lab_l + Bp) : sb + g.sb_yf;
+    // vector parameters (+ their Adam state): the standalone chain stages the candidate's whole vector block into LDS
+    // once, so that no dependent global load sits inside the serial cell loops; updates are written to global only
+    const int nvec = MFAS_MAX_CELLS * g.vec_cell_stride + Cp;
+    const float* vecW = W + cvec_off;
+    const float* vecM = Mv + cvec_off;
+    const float* vecV = Vv + cvec_off;
+    if (PF && a.vec_in_lds) {
+        float* vl = reinterpret_cast<float*>(lab_l + Bp) + (a.yf_in_lds ? (g.alphas ? 2 : 1) * sav_plane : 0);
+        for (int e = tid; e < nvec; e += CHAIN_THREADS) {
+            vl[e] = vecW[e];
+            vl[nvec + e] = vecM[e];
+            vl[2 * nvec + e] = vecV[e];
+        }
+        vecW = vl; vecM = vl + nvec; vecV = vl + 2 * nvec;   // visible after the phase-0 barrier below
+    }
+    const int nvalid = a.nvalid;
+    const float nf = (float)nvalid;
+    const AdamC ac = a.ac;
+    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(a.gstep + 1));
+
+    if (tid < Bp) {
+        int lab = 0;
+        if (tid < nvalid) {
+            const int64_t row = a.order ? (int64_t)a.order[a.pos_t + tid] : (int64_t)(a.base_t + tid);
+            lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
+        }
+        lab_l[tid] = lab;
+    }
+
+    // ------------------------------------------------------------------ phase 0: all 512 threads reduce the
+    // sweep's column-chunk partial sums of EVERY cell (fixed order) into LDS, loads batched 8 deep
+    {
+        const int per_cell = nrb * MB * 64;   // float4 items per cell
+        for (int e = tid; e < L * per_cell; e += CHAIN_THREADS) {
+            const int i = e / per_cell, it = e - i * per_cell;
+            const int ns = cd.nch_s[i], nch = ns + cd.nch_v[i];
+            const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8) + it * 4;
+            f32x4 accS = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
+            constexpr int PB = PF ? 16 : 8;   // partial-sum loads in flight per thread
+            for (int ch0 = 0; ch0 < nch; ch0 += PB) {
+                f32x4 p8[PB];
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+                    if (ch0 + u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)(ch0 + u) * nrb * MB) << 8));
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+                    if (ch0 + u < nch) {
+                        if (ch0 + u < ns) accS += p8[u]; else accV += p8[u];
+                    }
+            }
+            if (g.alphas) {
+                *reinterpret_cast<f32x4*>(yf_l + (int64_t)i * per_cell * 4 + it * 4) = accS;
+                *reinterpret_cast<f32x4*>(yf_l + sav_plane + (int64_t)i * per_cell * 4 + it * 4) = accV;
+            } else {
+                *reinterpret_cast<f32x4*>(yf_l + (int64_t)i * per_cell * 4 + it * 4) = accS + accV;
+            }
+        }
+    }
+    __syncthreads();
+
+    // one row block per wave and <= 8 k-blocks per product: register-prefetched tiles (wa = current, wb = next)
+    const bool pf = PF && nrb <= CHAIN_NW && ncb <= CHAIN_NW;
+    f32x4 wa[8], wb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { wa[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; wb[u] = wa[u]; }
+    // products in order: P_1..P_{L-1} (prev-out block of cell i), head, then backward: head^T, outT_{L-1}..outT_1
+    if (pf) {
+        if (L > 1) { if (wave < nrb) issue_tiles(wa, W + cd.seg_off[1][2] + (int64_t)wave * nrb * 256, nrb, lane); }
+        else if (wave < ncb) issue_tiles(wa, W + cd.head_off + (int64_t)wave * nrb * 256, nrb, lane);
+    }
+
+    CT_STAMP(0);
+    // ------------------------------------------------------------------ forward chain
+    for (int i = 0; i < L; ++i) {
+        CT_STAMP(1 + i);
+        if (pf && i >= 1) {   // wa holds P_i; request the NEXT product's tiles now: P_{i+1}, or the head after the last cell
+            if (i + 1 < L) { if (wave < nrb) issue_tiles(wb, W + cd.seg_off[i + 1][2] + (int64_t)wave * nrb * 256, nrb, lane); }
+            else if (wave < ncb) issue_tiles(wb, W + cd.head_off + (int64_t)wave * nrb * 256, nrb, lane);
+        }
+        const float* xprev = xo_l + ((i + 1) & 1) * Bp * SX;
+        float* xcur = xo_l + (i & 1) * Bp * SX;
+        const int nl = (nlbits >> (2 * i)) & 3;
+        const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
+        const int vbl = i * g.vec_cell_stride;
+        float sgS = 1.0f, sgV = 1.0f;
+        if (g.alphas) {
+            const float sg = 1.0f / (1.0f + expf(-vecW[vbl + 5 * Rp]));
+            sgS = sg;
+            sgV = 1.0f - sg;
+            if (tid == 0) {
+                sb[g.sb_gsc + i * 2] = sgS;
+                sb[g.sb_gsc + i * 2 + 1] = sgV;
+            }
+        }
+        for (int rb = wave; rb < nrb; rb += CHAIN_NW) {
+            const int r = rb * 16 + l15;
+            const bool colok = r < R;
+            // independent loads first: vector parameters of this column
+            const float bias = vecW[vbl + VEC_B * Rp + r];
+            float gam = 1.f, bet = 0.f;
+            if (g.bn) { gam = vecW[vbl + VEC_G * Rp + r]; bet = vecW[vbl + VEC_BE * Rp + r]; }
+            f32x4 acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int64_t o = ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4;
+                acc[mb] = *reinterpret_cast<const f32x4*>(yf_l + o);
+                if (g.alphas) {   // keep raw S-V difference for d(alpha); scale the two modality sums
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yf_l + sav_plane + o);
+                    *reinterpret_cast<f32x4*>(sav + 2 * sav_plane + o) = acc[mb] - yv;
+                    acc[mb] = acc[mb] * sgS + yv * sgV;
+                }
+            }
+            if (i > 0) {
+                if (pf) mma_tiles<MB>(acc, xprev, SX, wa, nrb, lane);
+                else lds_x_times_tiles<MB>(acc, xprev, SX, W + cd.seg_off[i][2] + (int64_t)rb * nrb * 256, 256, nrb, lane);
+            }
+            float av[MB][4];
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    const float v = act_fwd(acc[mb][q] + bias, nl);
+                    av[mb][q] = v;
+                    if (b < nvalid) s += v;
+                }
+            float zv[MB][4];
+            if (g.bn) {
+                const float mu = colsum(s) / nf;
+                float s2 = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        const float dlt = av[mb][q] - mu;
+                        if (b < nvalid) s2 += dlt * dlt;
+                    }
+                const float var = colsum(s2) / nf;
+                const float rstd = 1.0f / sqrtf(var + g.bn_eps);
+                f32x4 xh4[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float xh = (av[mb][q] - mu) * rstd;
+                        xh4[mb][q] = xh;
+                        zv[mb][q] = xh * gam + bet;
+                    }
+                if (lg == 0) {
+                    rstd_l[i * Rp + r] = rstd;
+                    if (colok) {   // running stats: momentum 0.1, unbiased variance
+                        float rm = vecW[vbl + VEC_RM * Rp + r], rv = vecW[vbl + VEC_RV * Rp + r];
+                        const float unb = var * (nf / (nf - 1.0f));
+                        rm += g.bn_mom * (mu - rm);
+                        rv += g.bn_mom * (unb - rv);
+                        W[vb + VEC_RM * Rp + r] = rm;
+                        W[vb + VEC_RV * Rp + r] = rv;
+                    }
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    *reinterpret_cast<f32x4*>(sav + sav_plane + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4) = xh4[mb];
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zv[mb][q] = av[mb][q];
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = av[mb][q];
+                *reinterpret_cast<f32x4*>(sav + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4) = a4;
+            }
+            float* xo_g = sb + g.sb_xo + (int64_t)i * Bp * Rp;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float o = zv[mb][q];
+                    if (g.use_drop)
+                        o = drop_keep(h0, i, (uint32_t)(b * R + r), g.drop_thr) ? o * g.drop_scale : 0.0f;
+                    if (!(colok && b < nvalid)) o = 0.0f;
+                    xcur[b * SX + r] = o;
+                    xo_g[b * Rp + r] = o;
+                }
+        }
+        if (pf && i >= 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wa[u] = wb[u];
+        }
+        lds_barrier();
+    }
+
+    CT_STAMP(5);
+    // ------------------------------------------------------------------ head + CE loss
+    {
+        const float* xl = xo_l + ((L - 1) & 1) * Bp * SX;
+        if (pf && wave < nrb)   // first backward product: d_out = dlogits . Wc  (transposed head tiles of this row block)
+            issue_tiles(wb, a.wt + cd.headT_off + (int64_t)wave * ncb * 256, ncb, lane);
+        for (int cb = wave; cb < ncb; cb += CHAIN_NW) {
+            f32x4 acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int c = cb * 16 + l15;
+            const float bias = vecW[g.vec_head + c];
+            if (pf) mma_tiles<MB>(acc, xl, SX, wa, nrb, lane);
+            else lds_x_times_tiles<MB>(acc, xl, SX, W + cd.head_off + (int64_t)cb * nrb * 256, 256, nrb, lane);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lg_l[(mb * 16 + 4 * lg + q) * SC + c] = acc[mb][q] + bias;
+        }
+    }
+    lds_barrier();
+    CT_STAMP(6);
+    if (g.loss_mode == 1) {
+        if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
+    } else if (tid < LPR * Bp) {
+        softmax_rows<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+    }
+    lds_barrier();
+    if (tid == CHAIN_THREADS - 64) {   // last wave: keeps the read-modify-write of the statistics off wave 0
+        float ls = 0.f, cs = 0.f;
+        for (int b = 0; b < Bp; ++b) { ls += red_l[b]; cs += red_l[Bp + b]; }
+        DevStats& st = a.stats[(int64_t)cgidx * a.E + a.epoch];
+        st.train_loss += (double)ls;
+        st.train_corr += (long long)cs;
+        if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
+    }
+    CT_STAMP(7);
+    // dlogits -> global (dy operand of the HEAD segment); head-bias Adam
+    {
+        float* dlg = sb + g.sb_dlog;
+        for (int e = tid; e < Bp * Cp; e += CHAIN_THREADS) {
+            const int b = e / Cp, c = e - b * Cp;
+            dlg[e] = lg_l[b * SC + c];
+        }
+        const int hc = tid - (CHAIN_THREADS - 256);   // head-bias columns on the upper four waves
+        if (hc >= 0 && hc < C) {
+            float gsum = 0.f;
+            for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + hc];
+            const int64_t o = cvec_off + g.vec_head + hc;
+            float w = vecW[g.vec_head + hc], m = vecM[g.vec_head + hc], v = vecV[g.vec_head + hc];
+            adam1(w, m, v, gsum, ac);
+            W[o] = w; Mv[o] = m; Vv[o] = v;
+        }
+    }
+
+    if (pf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wa[u] = wb[u];
+    }
+
+    // ------------------------------------------------------------------ backward chain
+    for (int i = L - 1; i >= 0; --i) {
+        CT_STAMP(8 + (L - 1 - i));
+        if (pf && i >= 1 && wave < nrb)   // next backward product (cell i-1) uses the transposed prev-out block of cell i
+            issue_tiles(wb, a.wt + cd.outT_off[i] + (int64_t)wave * nrb * 256, nrb, lane);
+        const int nl = (nlbits >> (2 * i)) & 3;
+        const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
+        const int vbl = i * g.vec_cell_stride;
+        const bool from_head = (i == L - 1);
+        const float* src = from_head ? lg_l : dy_l + ((i + 1) & 1) * Bp * SX;
+        const int sstride = from_head ? SC : SX;
+        const int nkk = from_head ? ncb : nrb;
+        const float* T = a.wt + (from_head ? cd.headT_off : cd.outT_off[i + 1]);
+        float* dcur = dy_l + (i & 1) * Bp * SX;
+        float dalpha = 0.f;
+        for (int rb = wave; rb < nrb; rb += CHAIN_NW) {
+            const int r = rb * 16 + l15;
+            const bool colok = r < R;
+            // independent loads first
+            float gr = 0.f;
+            if (g.bn) gr = vecW[vbl + VEC_G * Rp + r] * rstd_l[i * Rp + r];
+            int64_t ob = vb + VEC_B * Rp + r, og = vb + VEC_G * Rp + r, obe = vb + VEC_BE * Rp + r;
+            float pw[3] = {0.f, 0.f, 0.f}, pm[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f};
+            if (lg == 0 && colok) {
+                const int lb = vbl + VEC_B * Rp + r, lgm = vbl + VEC_G * Rp + r, lbe = vbl + VEC_BE * Rp + r;
+                pw[0] = vecW[lb]; pm[0] = vecM[lb]; pv[0] = vecV[lb];
+                if (g.bn) {
+                    pw[1] = vecW[lgm]; pm[1] = vecM[lgm]; pv[1] = vecV[lgm];
+                    pw[2] = vecW[lbe]; pm[2] = vecM[lbe]; pv[2] = vecV[lbe];
+                }
+            }
+            f32x4 a4[MB], xh4[MB], df4[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                a4[mb] = *reinterpret_cast<const f32x4*>(sav + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4);
+                xh4[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                df4[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (g.bn)
+                    xh4[mb] = *reinterpret_cast<const f32x4*>(sav + sav_plane + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4);
+                if (g.alphas)
+                    df4[mb] = *reinterpret_cast<const f32x4*>(sav + 2 * sav_plane + ((((int64_t)i * nrb + rb) * MB + mb) << 8) + lane * 4);
+            }
+            f32x4 acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (pf) mma_tiles<MB>(acc, src, sstride, wa, nkk, lane);
+            else lds_x_times_tiles<MB>(acc, src, sstride, T + (int64_t)rb * nkk * 256, 256, nkk, lane);
+            float dz[MB][4];
+            float sdz = 0.f, sdzx = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float d = acc[mb][q];
+                    if (g.use_drop)
+                        d = drop_keep(h0, i, (uint32_t)(b * R + r), g.drop_thr) ? d * g.drop_scale : 0.0f;
+                    if (!(b < nvalid)) d = 0.f;
+                    dz[mb][q] = d;
+                    sdz += d;
+                    if (g.bn) sdzx += d * xh4[mb][q];
+                }
+            float dgam = 0.f, dbet = 0.f;
+            if (g.bn) {
+                dbet = colsum(sdz);
+                dgam = colsum(sdzx);
+                const float k1 = dbet / nf, k2 = dgam / nf;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        const float da = gr * (dz[mb][q] - k1 - xh4[mb][q] * k2);
+                        dz[mb][q] = b < nvalid ? da : 0.f;
+                    }
+            }
+            float sdy = 0.f;
+            float* dy_g = sb + g.sb_dy + (int64_t)i * Bp * Rp;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float dy = act_bwd(a4[mb][q], dz[mb][q], nl);
+                    if (!colok) dy = 0.f;
+                    sdy += dy;
+                    dalpha += dy * df4[mb][q];
+                    dcur[b * SX + r] = dy;
+                    dy_g[b * Rp + r] = dy;
+                }
+            const float db = colsum(sdy);
+            if (lg == 0 && colok) {   // Adam on the column's vector parameters (one owner lane per column)
+                adam1(pw[0], pm[0], pv[0], db, ac);
+                W[ob] = pw[0]; Mv[ob] = pm[0]; Vv[ob] = pv[0];
+                if (g.bn) {
+                    adam1(pw[1], pm[1], pv[1], dgam, ac);
+                    W[og] = pw[1]; Mv[og] = pm[1]; Vv[og] = pv[1];
+                    adam1(pw[2], pm[2], pv[2], dbet, ac);
+                    W[obe] = pw[2]; Mv[obe] = pm[2]; Vv[obe] = pv[2];
+                }
+            }
+        }
+        if (pf && i >= 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wa[u] = wb[u];
+        }
+        if (g.alphas) {   // d(alpha_i) = sigma'(alpha) * sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]
+            for (int o = 32; o > 0; o >>= 1) dalpha += __shfl_xor(dalpha, o);
+            if (lane == 0) red_l[2 * Bp + wave] = dalpha;
+        }
+        lds_barrier();
+        if (g.alphas && tid == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < CHAIN_NW; ++w) tot += red_l[2 * Bp + w];
+            const int64_t o = vb + 5 * Rp;
+            float w = vecW[vbl + 5 * Rp], m = vecM[vbl + 5 * Rp], v = vecV[vbl + 5 * Rp];
+            const float sg = 1.0f / (1.0f + expf(-w));
+            adam1(w, m, v, tot * sg * (1.0f - sg), ac);
+            W[o] = w; Mv[o] = m; Vv[o] = v;
+        }
+        if (g.alphas) lds_barrier();
+    }
+    CT_STAMP(12);
+}
+
+// ------------------------------------------------------------------------------------------------
+// chain_lean — the same train-step chain for ONE row block (R <= 16) and <= 4 class blocks (C <= 64): the reference's
+// search defaults (inner_representation_size 16, main_searchable_ntu.py:26-45).  A 16-wide cell is a string of ~15
+// dependent little steps, and in the general chain_body every one of them pays a workgroup barrier, fresh scalar loads of
+// the candidate record, address arithmetic for up to 32 row blocks and a global round trip for its weight tile.  Here:
+//   * everything a step needs from global memory (labels, vector block, EVERY product's weight tile, the sweep's partial
+//     sums) is requested at kernel entry — one memory latency for the whole chain;
+//   * wave 0 owns the single row block and runs all L cells forward (and later backward) back to back with no barrier:
+//     the activations of all cells stay in LDS (xo_l / dy_l [L][Bp][20]) together with the saved activations;
+//   * the other seven waves do the bulk work around it: partial-sum reduction, head / softmax, coalesced copies of
+//     out_i, dy_i and dlogits to the step buffers the sweep reads, statistics, head-bias Adam.
+// Arithmetic (operation order included) is that of chain_body.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 pick4(const f32x4 (&t)[MFAS_MAX_CELLS], int i) {
+    switch (i) { case 0: return t[0]; case 1: return t[1]; case 2: return t[2]; default: return t[3]; }
+}
+
+template <int MB>
+__device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, float* lds) {
+#ifdef MFAS_CHAIN_TIMING
+    const unsigned long long ct0 = __builtin_readcyclecounter();
+#endif
+    const CandDev& cd = a.cands[bid];
+    const Geo& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int Bp = MB * 16;
+    constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
+    constexpr int Rp = 16, SX = Rp + 4;
+    const int Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L, SC = Cp + 4;
+    constexpr int sav_plane = MFAS_MAX_CELLS * MB * 256;
+    const int nvec = MFAS_MAX_CELLS * g.vec_cell_stride + Cp;
+    float* xo_l = lds;                                          // [L][Bp][SX] out_i of every cell
+    float* dy_l = xo_l + MFAS_MAX_CELLS * Bp * SX;              // [L][Bp][SX] dy_i of every cell
+    float* lg_l = dy_l + MFAS_MAX_CELLS * Bp * SX;              // [Bp][SC] logits -> dlogits
+    float* rstd_l = lg_l + Bp * SC;                             // [L][Rp]
+    float* red_l = rstd_l + MFAS_MAX_CELLS * Rp;                // [2*Bp + 16]
+    int* lab_l = reinterpret_cast<int*>(red_l + 2 * Bp + 16);   // [Bp]
+    float* yf_l = reinterpret_cast<float*>(lab_l + Bp);         // [1 or 2][L][MB][256] reduced feature sums
+    float* vec_l = yf_l + (g.alphas ? 2 : 1) * sav_plane;       // [3][nvec] vector block + Adam state
+    float* sav_a = vec_l + 3 * nvec;                            // [L][MB][256] activations
+    float* sav_x = sav_a + sav_plane;                           // xhat (batchnorm only)
+    float* sav_d = sav_a + (g.bn ? 2 : 1) * sav_plane;          // yS - yV (alphas only)
+
+    float* W = a.plane;
+    float* Mv = a.plane + a.plane_stride;
+    float* Vv = Mv + a.plane_stride;
+    float* sb = a.stepbuf + cd.step_off;
+    const int64_t cvec_off = cd.vec_off;
+    const int cgidx = cd.gidx;
+    int nlbits = 0;
+#pragma unroll
+    for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
+    const int nvalid = a.nvalid;
+    const float nf = (float)nvalid;
+    const AdamC ac = a.ac;
+    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(a.gstep + 1));
+
+    // ------------------------------------------------------------------ entry: every global read of the chain is
+    // requested here, in the order the results are needed (the memory counter retires in order): the sweep's partial
+    // sums first, then the vector block, the weight tiles of all products and last the labels (a dependent pair of loads
+    // that nothing needs before the loss, fetched by wave 1 so that wave 0 never waits for them)
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int per_cell = MB * 64;   // float4 partial-sum items per cell; L * per_cell <= 512: one item per thread
+    constexpr int PB = 16;
+    const bool has_item = tid < L * per_cell;
+    const int pi = has_item ? tid / per_cell : 0, pit = tid - pi * per_cell;
+    const int ns = cd.nch_s[pi], nch = has_item ? ns + cd.nch_v[pi] : 0;
+    const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[pi] * MB) << 8) + pit * 4;
+    f32x4 p8[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u)
+        if (u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)u * MB) << 8));
+    float vw = 0.f, vm = 0.f, vv = 0.f;   // nvec = 4 * 96 + Cp <= 448: one element of the vector block per thread
+    if (tid < nvec) { vw = W[cvec_off + tid]; vm = Mv[cvec_off + tid]; vv = Vv[cvec_off + tid]; }
+    f32x4 tP[MFAS_MAX_CELLS], tT[MFAS_MAX_CELLS], tHT[4], tH = z4;   // prev-out tile of cell i, its transpose, head^T, head
+#pragma unroll
+    for (int i = 0; i < MFAS_MAX_CELLS; ++i) { tP[i] = z4; tT[i] = z4; tHT[i] = z4; }
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 1; i < MFAS_MAX_CELLS; ++i)
+            if (i < L) {
+                tP[i] = *reinterpret_cast<const f32x4*>(W + cd.seg_off[i][2] + lane * 4);
+                tT[i] = *reinterpret_cast<const f32x4*>(a.wt + cd.outT_off[i] + lane * 4);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < ncb) tHT[u] = *reinterpret_cast<const f32x4*>(a.wt + cd.headT_off + ((int64_t)u << 8) + lane * 4);
+    }
+    if (wave < ncb) tH = *reinterpret_cast<const f32x4*>(W + cd.head_off + ((int64_t)wave << 8) + lane * 4);
+    int lab = 0;
+    if (wave == 1 && lane < nvalid) {
+        const int64_t row = a.order ? (int64_t)a.order[a.pos_t + lane] : (int64_t)(a.base_t + lane);
+        lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
+    }
+    // dropout keep bits of this lane's elements (wave 0 owns the row block): bit (i*MB + mb)*4 + q — computed while the
+    // loads above are in flight, used by the forward AND the backward pass
+    const int r = l15;
+    const bool colok = r < R;
+    uint32_t keep = 0xFFFFFFFFu;
+    if (wave == 0 && g.use_drop) {
+#pragma unroll
+        for (int i = 0; i < MFAS_MAX_CELLS; ++i)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (!drop_keep(h0, i, (uint32_t)((mb * 16 + 4 * lg + q) * R + r), g.drop_thr)) keep &= ~(1u << ((i * MB + mb) * 4 + q));
+    }
+    // phase 0: reduce the sweep's column-chunk partial sums (fixed order) into LDS; stage the vector block
+    if (has_item) {
+        f32x4 accS = z4, accV = z4;
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+            if (u < nch) {
+                if (u < ns) accS += p8[u]; else accV += p8[u];
+            }
+        for (int ch0 = PB; ch0 < nch; ch0 += PB) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+                if (ch0 + u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)(ch0 + u) * MB) << 8));
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+                if (ch0 + u < nch) {
+                    if (ch0 + u < ns) accS += p8[u]; else accV += p8[u];
+                }
+        }
+        if (g.alphas) {
+            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS;
+            *reinterpret_cast<f32x4*>(yf_l + sav_plane + tid * 4) = accV;
+        } else {
+            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS + accV;
+        }
+    }
+    if (tid < nvec) { vec_l[tid] = vw; vec_l[nvec + tid] = vm; vec_l[2 * nvec + tid] = vv; }
+    const float* vecW = vec_l;
+    const float* vecM = vec_l + nvec;
+    const float* vecV = vec_l + 2 * nvec;
+    lds_barrier();
+    CT_STAMP(0);
+
+    // ------------------------------------------------------------------ forward: wave 0, all cells, no barrier
+    if (wave == 0) {
+        for (int i = 0; i < L; ++i) {
+            CT_STAMP(1 + i);
+            const int nl = (nlbits >> (2 * i)) & 3;
+            const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
+            const int vbl = i * g.vec_cell_stride;
+            const float bias = vecW[vbl + VEC_B * Rp + r];
+            float gam = 1.f, bet = 0.f;
+            if (g.bn) { gam = vecW[vbl + VEC_G * Rp + r]; bet = vecW[vbl + VEC_BE * Rp + r]; }
+            float sgS = 1.0f, sgV = 1.0f;
+            if (g.alphas) {
+                const float sg = 1.0f / (1.0f + expf(-vecW[vbl + 5 * Rp]));
+                sgS = sg;
+                sgV = 1.0f - sg;
+                if (lane == 0) {
+                    sb[g.sb_gsc + i * 2] = sgS;
+                    sb[g.sb_gsc + i * 2 + 1] = sgV;
+                }
+            }
+            f32x4 acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int o = ((i * MB + mb) << 8) + lane * 4;
+                acc[mb] = *reinterpret_cast<const f32x4*>(yf_l + o);
+                if (g.alphas) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yf_l + sav_plane + o);
+                    *reinterpret_cast<f32x4*>(sav_d + o) = acc[mb] - yv;
+                    acc[mb] = acc[mb] * sgS + yv * sgV;
+                }
+            }
+            if (i > 0) {
+                const f32x4 w = pick4(tP, i);
+                const float* xprev = xo_l + (i - 1) * Bp * SX;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xprev + (mb * 16 + l15) * SX + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w[q], acc[mb]);
+                }
+            }
+            float av[MB][4];
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    const float v = act_fwd(acc[mb][q] + bias, nl);
+                    av[mb][q] = v;
+                    if (b < nvalid) s += v;
+                }
+            float zv[MB][4];
+            if (g.bn) {
+                const float mu = colsum(s) / nf;
+                float s2 = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        const float dlt = av[mb][q] - mu;
+                        if (b < nvalid) s2 += dlt * dlt;
+                    }
+                const float var = colsum(s2) / nf;
+                const float rstd = 1.0f / sqrtf(var + g.bn_eps);
+                f32x4 xh4[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float xh = (av[mb][q] - mu) * rstd;
+                        xh4[mb][q] = xh;
+                        zv[mb][q] = xh * gam + bet;
+                    }
+                if (lg == 0) {
+                    rstd_l[i * Rp + r] = rstd;
+                    if (colok) {   // running stats: momentum 0.1, unbiased variance
+                        float rm = vecW[vbl + VEC_RM * Rp + r], rv = vecW[vbl + VEC_RV * Rp + r];
+                        const float unb = var * (nf / (nf - 1.0f));
+                        rm += g.bn_mom * (mu - rm);
+                        rv += g.bn_mom * (unb - rv);
+                        W[vb + VEC_RM * Rp + r] = rm;
+                        W[vb + VEC_RV * Rp + r] = rv;
+                    }
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    *reinterpret_cast<f32x4*>(sav_x + ((i * MB + mb) << 8) + lane * 4) = xh4[mb];
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zv[mb][q] = av[mb][q];
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = av[mb][q];
+                *reinterpret_cast<f32x4*>(sav_a + ((i * MB + mb) << 8) + lane * 4) = a4;
+            }
+            float* xcur = xo_l + i * Bp * SX;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float o = zv[mb][q];
+                    if (g.use_drop) o = ((keep >> ((i * MB + mb) * 4 + q)) & 1u) ? o * g.drop_scale : 0.0f;
+                    if (!(colok && b < nvalid)) o = 0.0f;
+                    xcur[b * SX + r] = o;
+                }
+        }
+    }
+    if (wave == 1 && lane < Bp) lab_l[lane] = lab;   // visible to the loss after the head's barrier
+    lds_barrier();
+    CT_STAMP(5);
+
+    // ------------------------------------------------------------------ out_i -> step buffer (x operand of the sweep's
+    // OUT / HEAD segments), coalesced, by everyone; head on waves < ncb
+    {
+        float* xo_g = sb + g.sb_xo;   // [L][Bp][Rp]
+        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) xo_g[e] = xo_l[(e >> 4) * SX + (e & 15)];
+        const float* xl = xo_l + (L - 1) * Bp * SX;
+        if (wave < ncb) {
+            const int c = wave * 16 + l15;
+            const float bias = vecW[g.vec_head + c];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x4 acc = z4;
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xl + (mb * 16 + l15) * SX + 4 * lg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], tH[q], acc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lg_l[(mb * 16 + 4 * lg + q) * SC + c] = acc[q] + bias;
+            }
+        }
+    }
+    lds_barrier();
+    CT_STAMP(6);
+    if (g.loss_mode == 1) {
+        if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
+    } else if (tid < LPR * Bp) {
+        softmax_rows<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+    }
+    lds_barrier();
+    CT_STAMP(7);
+    if (tid == CHAIN_THREADS - 64) {
+        float ls = 0.f, cs = 0.f;
+        for (int b = 0; b < Bp; ++b) { ls += red_l[b]; cs += red_l[Bp + b]; }
+        DevStats& st = a.stats[(int64_t)cgidx * a.E + a.epoch];
+        st.train_loss += (double)ls;
+        st.train_corr += (long long)cs;
+        if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
+    }
+    if (wave != 0) {   // dlogits -> step buffer (dy operand of the HEAD segment); head-bias Adam
+        float* dlg = sb + g.sb_dlog;
+        for (int e = tid - 64; e < Bp * Cp; e += CHAIN_THREADS - 64) {
+            const int b = e / Cp, c = e - b * Cp;
+            dlg[e] = lg_l[b * SC + c];
+        }
+        const int hc = tid - (CHAIN_THREADS - 256);
+        if (hc >= 0 && hc < C) {
+            float gsum = 0.f;
+            for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + hc];
+            const int64_t o = cvec_off + g.vec_head + hc;
+            float w = vecW[g.vec_head + hc], m = vecM[g.vec_head + hc], v = vecV[g.vec_head + hc];
+            adam1(w, m, v, gsum, ac);
+            W[o] = w; Mv[o] = m; Vv[o] = v;
+        }
+    } else {
+        // -------------------------------------------------------------- backward: wave 0, all cells, no barrier
+        for (int i = L - 1; i >= 0; --i) {
+            CT_STAMP(8 + (L - 1 - i));
+            const int nl = (nlbits >> (2 * i)) & 3;
+            const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
+            const int vbl = i * g.vec_cell_stride;
+            const bool from_head = (i == L - 1);
+            float gr = 0.f;
+            if (g.bn) gr = vecW[vbl + VEC_G * Rp + r] * rstd_l[i * Rp + r];
+            const int64_t ob = vb + VEC_B * Rp + r, og = vb + VEC_G * Rp + r, obe = vb + VEC_BE * Rp + r;
+            float pw[3] = {0.f, 0.f, 0.f}, pm[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f};
+            if (lg == 0 && colok) {
+                const int lb = vbl + VEC_B * Rp + r, lgm = vbl + VEC_G * Rp + r, lbe = vbl + VEC_BE * Rp + r;
+                pw[0] = vecW[lb]; pm[0] = vecM[lb]; pv[0] = vecV[lb];
+                if (g.bn) {
+                    pw[1] = vecW[lgm]; pm[1] = vecM[lgm]; pv[1] = vecV[lgm];
+                    pw[2] = vecW[lbe]; pm[2] = vecM[lbe]; pv[2] = vecV[lbe];
+                }
+            }
+            f32x4 a4[MB], xh4[MB], df4[MB], acc[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int o = ((i * MB + mb) << 8) + lane * 4;
+                a4[mb] = *reinterpret_cast<const f32x4*>(sav_a + o);
+                xh4[mb] = z4;
+                df4[mb] = z4;
+                if (g.bn) xh4[mb] = *reinterpret_cast<const f32x4*>(sav_x + o);
+                if (g.alphas) df4[mb] = *reinterpret_cast<const f32x4*>(sav_d + o);
+                acc[mb] = z4;
+            }
+            if (from_head) {   // d_out = dlogits . Wc: even / odd class blocks in two chains (as mma_tiles)
+                f32x4 acc2[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc2[mb] = z4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < ncb) {
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(lg_l + (mb * 16 + l15) * SC + u * 16 + 4 * lg);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (u & 1) acc2[mb] = MFMA16(x4[q], tHT[u][q], acc2[mb]);
+                                else acc[mb] = MFMA16(x4[q], tHT[u][q], acc[mb]);
+                            }
+                        }
+                    }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] += acc2[mb];
+            } else {
+                const f32x4 w = pick4(tT, i + 1);
+                const float* src = dy_l + (i + 1) * Bp * SX;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(src + (mb * 16 + l15) * SX + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w[q], acc[mb]);
+                }
+            }
+            float dz[MB][4];
+            float sdz = 0.f, sdzx = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float d = acc[mb][q];
+                    if (g.use_drop) d = ((keep >> ((i * MB + mb) * 4 + q)) & 1u) ? d * g.drop_scale : 0.0f;
+                    if (!(b < nvalid)) d = 0.f;
+                    dz[mb][q] = d;
+                    sdz += d;
+                    if (g.bn) sdzx += d * xh4[mb][q];
+                }
+            float dgam = 0.f, dbet = 0.f;
+            if (g.bn) {
+                dbet = colsum(sdz);
+                dgam = colsum(sdzx);
+                const float k1 = dbet / nf, k2 = dgam / nf;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        const float da = gr * (dz[mb][q] - k1 - xh4[mb][q] * k2);
+                        dz[mb][q] = b < nvalid ? da : 0.f;
+                    }
+            }
+            float sdy = 0.f, dalpha = 0.f;
+            float* dcur = dy_l + i * Bp * SX;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = mb * 16 + 4 * lg + q;
+                    float dy = act_bwd(a4[mb][q], dz[mb][q], nl);
+                    if (!colok) dy = 0.f;
+                    sdy += dy;
+                    dalpha += dy * df4[mb][q];
+                    dcur[b * SX + r] = dy;
+                }
+            const float db = colsum(sdy);
+            if (lg == 0 && colok) {   // Adam on the column's vector parameters (one owner lane per column)
+                adam1(pw[0], pm[0], pv[0], db, ac);
+                W[ob] = pw[0]; Mv[ob] = pm[0]; Vv[ob] = pv[0];
+                if (g.bn) {
+                    adam1(pw[1], pm[1], pv[1], dgam, ac);
+                    W[og] = pw[1]; Mv[og] = pm[1]; Vv[og] = pv[1];
+                    adam1(pw[2], pm[2], pv[2], dbet, ac);
+                    W[obe] = pw[2]; Mv[obe] = pm[2]; Vv[obe] = pv[2];
+                }
+            }
+            if (g.alphas) {   // d(alpha_i) = sigma'(alpha) * sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]
+                for (int o = 32; o > 0; o >>= 1) dalpha += __shfl_xor(dalpha, o);
+                if (lane == 0) {
+                    const float tot = dalpha;
+                    const int64_t o = vb + 5 * Rp;
+                    float w = vecW[vbl + 5 * Rp], m = vecM[vbl + 5 * Rp], v = vecV[vbl + 5 * Rp];
+                    const float sg = 1.0f / (1.0f + expf(-w));
+                    adam1(w, m, v, tot * sg * (1.0f - sg), ac);
+                    W[o] = w; Mv[o] = m; Vv[o] = v;
+                }
+            }
+        }
+    }
+    lds_barrier();
+    CT_STAMP(12);
+    {   // dy_i -> step buffer (dy operand of the sweep), coalesced
+        float* dy_g = sb + g.sb_dy;   // [L][Bp][Rp]
+        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) dy_g[e] = dy_l[(e >> 4) * SX + (e & 15)];
+    }
+}

@@ -1,0 +1,206 @@
+// common.hip.h — device-side records (SegDesc, TapDesc, CandDev, Geo), small math helpers and LDS row staging
+// (part of the single translation unit mfas_hip.hip; see the header comment there and DESIGN.md)
+#pragma once
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define KIND_S 0
+#define KIND_V 1
+#define KIND_OUT 2
+#define KIND_HEAD 3
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(MFAS_EHIP, std::string(#x) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Device-side descriptors
+// ------------------------------------------------------------------------------------------------
+struct SegDesc {          // one workgroup of k_sweep / k_pack
+    int32_t cand, kind, cell, tap;
+    int32_t k0, cc;       // first column inside the segment, chunk columns (multiple of 16)
+    int32_t rows_p, width;  // padded rows; FEAT: table row width (elements)
+    int64_t w_off;        // float offset (within a plane) of this chunk: tiles [rb][kb][256]
+    int64_t wt_off;       // OUT/HEAD: float offset in the transposed arena, else -1
+    int32_t part_idx;     // FEAT: chunk index within the cell's partial list
+    int32_t rows, cols;   // true rows (R or C) / true columns of the whole segment
+    int64_t src_off;      // flat-parameter offset of the matrix this segment belongs to
+    int32_t src_ld, src_col0;
+    uint32_t init_seed;   // hash seed of that matrix (device init)
+    float init_bound;
+};
+
+#define TAP_MAX_ITEMS 8
+struct TapDesc {          // tap-major workgroup (R < 128): one feature chunk shared by up to 8 segments of that tap
+    int32_t kind, tap, k0, cc;      // modality (KIND_S / KIND_V), tap index, first column, columns
+    int32_t rows_p, width, nitems, _pad;
+    int32_t cand[TAP_MAX_ITEMS], cell[TAP_MAX_ITEMS], part_idx[TAP_MAX_ITEMS];
+    int64_t w_off[TAP_MAX_ITEMS];   // plane offset of each item's chunk: tiles [rb][kb][256]
+};
+
+struct CandDev {
+    int32_t L;
+    int32_t conf[MFAS_MAX_CELLS][3];
+    int64_t seg_off[MFAS_MAX_CELLS][3];   // plane offset of S / V / OUT segment of cell i (-1: none)
+    int32_t seg_cc[MFAS_MAX_CELLS][3];    // chunk columns of that segment
+    int32_t seg_cols[MFAS_MAX_CELLS][3];  // padded columns
+    int64_t head_off;
+    int64_t outT_off[MFAS_MAX_CELLS];     // transposed arena offset of cell i's OUT segment
+    int64_t headT_off;
+    int64_t vec_off;                      // plane offset of the vector block
+    int32_t nch_s[MFAS_MAX_CELLS], nch_v[MFAS_MAX_CELLS];
+    int32_t part_cell_off[MFAS_MAX_CELLS];  // first partial-slot index of cell i
+    int64_t step_off;                     // float offset of this candidate's step buffers
+    uint32_t drop_seed;
+    int32_t gidx;                         // index of this candidate in the population (stats / status slot)
+    // flat (reference state_dict order) offsets of this candidate's parameters
+    int64_t f_alpha, f_W[MFAS_MAX_CELLS], f_b[MFAS_MAX_CELLS], f_bn[MFAS_MAX_CELLS], f_Wc, f_bc;
+    int32_t K_in[MFAS_MAX_CELLS];   // in_features of cell i
+    int32_t _pad2[4];
+};
+
+struct DevStats {
+    double train_loss, dev_loss;
+    long long train_corr, dev_corr;
+};
+
+struct AdamC {
+    float ss, bc2s, w1, b2, w2, eps, wd;
+};
+
+struct Geo {             // geometry shared by all candidates of a population
+    int32_t R, C, Rp, Cp, nrb, ncb, B, Bp, MB;
+    int32_t bn, alphas, multitask, use_drop;
+    float drop_scale, bn_eps, bn_mom;
+    uint32_t drop_thr;
+    // per-candidate step-buffer sub-offsets (floats)
+    int64_t sb_part, sb_dy, sb_xo, sb_dlog, sb_sav, sb_yf, sb_gsc, sb_size;
+    int32_t vec_cell_stride;   // 5*Rp + 16
+    int32_t vec_head;          // offset of head bias inside the vector block
+    int32_t sw[MFAS_MAX_TAPS], vw[MFAS_MAX_TAPS];   // table row strides of the taps (width padded to 16)
+    int32_t loss_mode;         // 0 softmax CE + accuracy, 1 weighted BCE + F1-samples
+    float f1_th;
+};
+
+// vector block of a candidate (inside every plane): per cell [b | gamma | beta | rm | rv | alpha(16)], then bc[Cp]
+#define VEC_B 0
+#define VEC_G 1
+#define VEC_BE 2
+#define VEC_RM 3
+#define VEC_RV 4
+
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352DU;
+    x ^= x >> 15;
+    x *= 0x846CA68BU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float act_fwd(float y, int nl) {
+    if (nl == 0) return y <= 0.0f ? 0.0f : y;   // torch.relu: NaN propagates (fmaxf would swallow it)
+    if (nl == 1) return 1.0f / (1.0f + expf(-y));
+    return y > 0.0f ? y : 0.01f * y;
+}
+__device__ __forceinline__ float act_bwd(float a, float da, int nl) {
+    if (nl == 0) return a <= 0.0f ? 0.0f : da;  // threshold_backward(grad, result, 0)
+    if (nl == 1) return da * (1.0f - a) * a;
+    return a > 0.0f ? da : 0.01f * da;   // leaky: sign(a) == sign(y)
+}
+
+__device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, const AdamC& c) {
+    g = g + c.wd * w;
+    m = m + c.w1 * (g - m);
+    v = v * c.b2;
+    v = v + (c.w2 * g) * g;
+    const float denom = sqrtf(v) / c.bc2s + c.eps;
+    w = w - c.ss * (m / denom);
+}
+
+// sum over the 4 lane groups that share (lane & 15): column reduction of an MFMA D block
+__device__ __forceinline__ float colsum(float x) {
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+
+__device__ __forceinline__ int64_t tile_addr(int64_t seg_off, int rows_p, int cc, int rb, int kb) {
+    const int nkb_c = cc >> 4;
+    const int chunk = kb / nkb_c;
+    const int kbi = kb - chunk * nkb_c;
+    return seg_off + (int64_t)chunk * rows_p * cc + ((int64_t)rb * nkb_c + kbi) * 256;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row staging: table rows (any dtype) -> f32 LDS tile [rows][stride]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_table(float* dst, int stride, const void* tab, int dtype, int width,
+                                            int col0, int ncols, const int32_t* ord, int64_t pos,
+                                            int base, int nvalid, int nrows, int tid, int nthreads) {
+    if (dtype == MFAS_DT_F32) {
+        const int vpr = ncols >> 2;
+        for (int e = tid; e < nrows * vpr; e += nthreads) {
+            const int b = e / vpr, c = (e - b * vpr) << 2;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (b < nvalid) {
+                const int64_t row = ord ? (int64_t)ord[pos + b] : (int64_t)(base + b);
+                val = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(tab) + row * width + col0 + c);
+            }
+            *reinterpret_cast<f32x4*>(dst + b * stride + c) = val;
+        }
+    } else {
+        const int vpr = ncols >> 3;
+        for (int e = tid; e < nrows * vpr; e += nthreads) {
+            const int b = e / vpr, c = (e - b * vpr) << 3;
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+            if (b < nvalid) {
+                const int64_t row = ord ? (int64_t)ord[pos + b] : (int64_t)(base + b);
+                const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(tab) +
+                                                                  row * width + col0 + c);
+                const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (dtype == MFAS_DT_BF16) {
+                        f[2 * j] = __uint_as_float(w[j] << 16);
+                        f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000U);
+                    } else {
+                        f[2 * j] = __half2float(__ushort_as_half((unsigned short)(w[j] & 0xFFFFU)));
+                        f[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(w[j] >> 16)));
+                    }
+                }
+                lo = (f32x4){f[0], f[1], f[2], f[3]};
+                hi = (f32x4){f[4], f[5], f[6], f[7]};
+            }
+            *reinterpret_cast<f32x4*>(dst + b * stride + c) = lo;
+            *reinterpret_cast<f32x4*>(dst + b * stride + c + 4) = hi;
+        }
+    }
+}
+
+// f32 row-major global [nrows][src_stride] -> LDS [nrows][stride]
+__device__ __forceinline__ void stage_f32(float* dst, int stride, const float* src, int src_stride, int ncols,
+                                          int nrows, int tid, int nthreads) {
+    const int vpr = ncols >> 2;
+    for (int e = tid; e < nrows * vpr; e += nthreads) {
+        const int b = e / vpr, c = (e - b * vpr) << 2;
+        *reinterpret_cast<f32x4*>(dst + b * stride + c) =
+            *reinterpret_cast<const f32x4*>(src + (int64_t)b * src_stride + c);
+    }
+}
+
+// U = tiles of W/m/v in flight per wave (x3 planes).  A workgroup has 2 waves per SIMD, so two workgroups share a CU only
+// inside a 128-VGPR budget (WPE = 4 waves per SIMD).  MB == 1 always runs that way with U = 2 (U = 4 spills, no gain).
+// MB == 2 has two builds: WPE = 2 (up to 256 VGPRs, one workgroup per CU, U = 2: nothing spills, best when the co-scheduled
+// chain's latency bounds the launch) and WPE = 4 (U = 1, the chain code spills a little, two workgroups per CU: +10..19 %
+// when the sweep bounds the launch).  Deeper batches (U = 4, 6 at WPE = 2) measured 8-12 % slower.
+template <int MB, int WPE> struct SweepU { static constexpr int v = (MB == 2 && WPE == 4) ? 1 : 2; };

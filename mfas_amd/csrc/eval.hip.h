@@ -1,0 +1,265 @@
+// eval.hip.h — eval-mode forward over table rows (dev accuracy / F1, mfas_population_forward)
+// (part of the single translation unit mfas_hip.hip; see the header comment there and DESIGN.md)
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// k_eval — eval-mode forward (BN running stats, no dropout) over a block of table rows
+// ------------------------------------------------------------------------------------------------
+struct EvalArgs {
+    const CandDev* cands;
+    const float* plane;
+    mfas_table tab;
+    int64_t row0, nrows;
+    int32_t cand0;
+    int32_t epoch, E;
+    Geo g;
+    float* logits;        // optional (nrows, C) for candidate cand0
+    DevStats* stats;      // optional: dev_corr / dev_loss of stats[cand*E + epoch]
+    long long* corr_out;  // optional single counter
+    const float* pos_w;   // loss_mode 1
+};
+
+#define EVAL_CE 128   // staged feature columns per pass
+
+template <int MBE, int NRBW>
+__global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int cand = a.cand0 + blockIdx.y;
+    const CandDev& cd = a.cands[cand];
+    const Geo& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int ME = MBE * 16;
+    const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
+    const int SX = Rp + 4, SC = Cp + 4, SS = EVAL_CE + 4;
+    // LDS kept to <= 80 KiB so that two workgroups share a CU (one stages features while the other runs MFMAs):
+    // ONE activation buffer (extra barrier per cell) and the logits alias the feature staging tile.
+    float* xs = lds;                     // [ME][SS]   feature staging tile; later the logits [ME][SC]
+    float* xo_l = xs + ME * max(SS, SC); // [ME][SX]   out_{i-1} -> out_i
+    float* lg_l = xs;
+    const float* W = a.plane;
+    const int64_t brow = a.row0 + (int64_t)blockIdx.x * ME;
+    const int nvalid = (int)min((int64_t)ME, a.row0 + a.nrows - brow);
+
+    for (int i = 0; i < L; ++i) {
+        const float* xprev = xo_l;
+        float* xcur = xo_l;
+        const int nl = cd.conf[i][2];
+        const int64_t vb = cd.vec_off + (int64_t)i * g.vec_cell_stride;
+        float sgS = 1.0f, sgV = 1.0f;
+        if (g.alphas) {
+            const float sg = 1.0f / (1.0f + expf(-W[vb + 5 * Rp]));
+            sgS = sg;
+            sgV = 1.0f - sg;
+        }
+        f32x4 acc[NRBW][MBE];
+#pragma unroll
+        for (int j = 0; j < NRBW; ++j)
+#pragma unroll
+            for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int sv = 0; sv < 2; ++sv) {
+            const int tap = cd.conf[i][sv];
+            const void* tp = sv == 0 ? a.tab.s[tap] : a.tab.v[tap];
+            const int cols = cd.seg_cols[i][sv], cc = cd.seg_cc[i][sv];
+            const int tw = sv == 0 ? g.sw[tap] : g.vw[tap];
+            if (g.alphas && sv == 1) {   // switch modality: fold the S sum with its scale, restart for V
+#pragma unroll
+                for (int j = 0; j < NRBW; ++j)
+#pragma unroll
+                    for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * (sgS / sgV);
+            }
+            for (int c0 = 0; c0 < cols; c0 += EVAL_CE) {
+                const int nc = min(EVAL_CE, cols - c0);
+                if constexpr (NRBW <= 2) {
+                    // this chunk's weight tiles are requested BEFORE the feature staging so that their L2 latency
+                    // overlaps the staging barriers (8 k-blocks x NRBW row blocks = up to 64 VGPRs)
+                    f32x4 wt[EVAL_CE / 16][NRBW];
+#pragma unroll
+                    for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl)
+#pragma unroll
+                        for (int j = 0; j < NRBW; ++j) {
+                            const int rb = wave + 4 * j;
+                            if (kbl < (nc >> 4) && rb < nrb)
+                                wt[kbl][j] = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][sv], Rp, cc, rb, (c0 >> 4) + kbl) + lane * 4);
+                        }
+                    __syncthreads();
+                    stage_table(xs, SS, tp, a.tab.dtype, tw, c0, nc, nullptr, 0, (int)brow, nvalid, ME, tid, 256);
+                    __syncthreads();
+#pragma unroll
+                    for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl)
+                        if (kbl < (nc >> 4)) {
+#pragma unroll
+                            for (int j = 0; j < NRBW; ++j) {
+                                const int rb = wave + 4 * j;
+                                if (rb < nrb) {
+#pragma unroll
+                                    for (int mb = 0; mb < MBE; ++mb) {
+                                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], wt[kbl][j][q], acc[j][mb]);
+                                    }
+                                }
+                            }
+                        }
+                } else {
+                    __syncthreads();
+                    stage_table(xs, SS, tp, a.tab.dtype, tw, c0, nc, nullptr, 0, (int)brow, nvalid, ME, tid, 256);
+                    __syncthreads();
+                    for (int kbl = 0; kbl < (nc >> 4); ++kbl) {
+                        const int kb = (c0 >> 4) + kbl;
+#pragma unroll
+                        for (int j = 0; j < NRBW; ++j) {
+                            const int rb = wave + 4 * j;
+                            if (rb < nrb) {
+                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][sv], Rp, cc, rb, kb) + lane * 4);
+#pragma unroll
+                                for (int mb = 0; mb < MBE; ++mb) {
+                                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], w4[q], acc[j][mb]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (g.alphas) {
+#pragma unroll
+            for (int j = 0; j < NRBW; ++j)
+#pragma unroll
+                for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * sgV;
+        }
+        if (i > 0) {
+#pragma unroll
+            for (int j = 0; j < NRBW; ++j) {
+                const int rb = wave + 4 * j;
+                if (rb < nrb) {
+                    for (int kb = 0; kb < nrb; ++kb) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][2], Rp, Rp, rb, kb) + lane * 4);
+#pragma unroll
+                        for (int mb = 0; mb < MBE; ++mb) {
+                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xprev + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], w4[q], acc[j][mb]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // every wave is done reading out_{i-1} before out_i overwrites it
+        }
+#pragma unroll
+        for (int j = 0; j < NRBW; ++j) {
+            const int rb = wave + 4 * j;
+            if (rb < nrb) {
+                const int r = rb * 16 + l15;
+                const float bias = W[vb + VEC_B * Rp + r];
+                float sc = 1.0f, sh = 0.0f, rm = 0.0f;
+                if (g.bn) {
+                    rm = W[vb + VEC_RM * Rp + r];
+                    sc = 1.0f / sqrtf(W[vb + VEC_RV * Rp + r] + g.bn_eps);
+                }
+                const float gam = g.bn ? W[vb + VEC_G * Rp + r] : 1.0f;
+                sh = g.bn ? W[vb + VEC_BE * Rp + r] : 0.0f;
+#pragma unroll
+                for (int mb = 0; mb < MBE; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b = mb * 16 + 4 * lg + q;
+                        float o = act_fwd(acc[j][mb][q] + bias, nl);
+                        if (g.bn) o = ((o - rm) * sc) * gam + sh;
+                        if (!(r < R)) o = 0.f;
+                        xcur[b * SX + r] = o;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    {
+        const float* xl = xo_l;
+        for (int cb = wave; cb < ncb; cb += 4) {
+            f32x4 hacc[MBE];
+#pragma unroll
+            for (int mb = 0; mb < MBE; ++mb) hacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < nrb; ++kb) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.head_off, Cp, Rp, cb, kb) + lane * 4);
+#pragma unroll
+                for (int mb = 0; mb < MBE; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xl + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hacc[mb] = MFMA16(x4[q], w4[q], hacc[mb]);
+                }
+            }
+            const int c = cb * 16 + l15;
+            const float bias = W[cd.vec_off + g.vec_head + c];
+#pragma unroll
+            for (int mb = 0; mb < MBE; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lg_l[(mb * 16 + 4 * lg + q) * SC + c] = hacc[mb][q] + bias;
+        }
+    }
+    __syncthreads();
+    if (a.logits) {
+        for (int e = tid; e < nvalid * C; e += 256) {
+            const int b = e / C, c = e - b * C;
+            a.logits[(brow - a.row0 + b) * C + c] = lg_l[b * SC + c];
+        }
+    }
+    if (tid < ME) {   // ME <= 64: exactly wave 0
+        float loss = 0.f;
+        long long corr = 0;
+        if (tid < nvalid && g.loss_mode == 1) {
+            // F1 'samples' (sklearn f1_score(average='samples')): per row 2|P&T| / (|P|+|T|), 0 when both are empty;
+            // accumulated as 32.32 fixed point so that the sum is order-independent
+            const float* row = lg_l + tid * SC;
+            const int64_t grow = brow + tid;
+            const float* z = a.tab.multilabel + grow * C;
+            int tp = 0, np = 0, nt = 0;
+            float ls = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float sg = 1.0f / (1.0f + expf(-row[c]));
+                const bool pr = sg > g.f1_th, tr = z[c] > 0.5f;
+                tp += (pr && tr) ? 1 : 0; np += pr ? 1 : 0; nt += tr ? 1 : 0;
+                ls += a.pos_w[c] * z[c] * -logf(sg) + (1.0f - z[c]) * -logf(1.0f - sg);
+            }
+            loss = ls / (float)C;
+            corr = (np + nt) > 0 ? (long long)((((unsigned long long)(2 * tp)) << 32) / (unsigned long long)(np + nt)) : 0;
+        } else if (tid < nvalid) {
+            const float* row = lg_l + tid * SC;
+            const int64_t grow = brow + tid;
+            const int lab = a.tab.label[grow];
+            float mx = row[0];
+            for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
+            loss = -(row[lab] - mx - logf(se));
+            int best = 0;
+            float bv;
+            if (g.multitask) {
+                const float* vl = a.tab.vlogit + grow * C;
+                const float* sl = a.tab.slogit + grow * C;
+                bv = (row[0] + vl[0]) + sl[0];
+                for (int c = 1; c < C; ++c) {
+                    const float t = (row[c] + vl[c]) + sl[c];
+                    if (t > bv) { bv = t; best = c; }
+                }
+            } else {
+                bv = row[0];
+                for (int c = 1; c < C; ++c)
+                    if (row[c] > bv) { bv = row[c]; best = c; }
+            }
+            corr = best == lab ? 1 : 0;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            loss += __shfl_xor(loss, o);
+            corr += __shfl_xor(corr, o);
+        }
+        if (tid == 0) {
+            if (a.stats) {
+                DevStats& st = a.stats[(int64_t)cand * a.E + a.epoch];
+                atomicAdd(reinterpret_cast<unsigned long long*>(&st.dev_corr), (unsigned long long)corr);
+                atomicAdd(&st.dev_loss, (double)loss);
+            }
+            if (a.corr_out) atomicAdd(reinterpret_cast<unsigned long long*>(a.corr_out), (unsigned long long)corr);
+        }
+    }
+}

@@ -1,0 +1,246 @@
+// sweep.hip.h — the HBM-bound sweep: dW + Adam + next-step forward per weight tile (per-segment and tap-major decompositions)
+// (part of the single translation unit mfas_hip.hip; see the header comment there and DESIGN.md)
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// tile_run — the fused per-tile work shared by both sweep decompositions, for ONE row block `rb` over the k-blocks
+// kb0, kb0+kbs, ... < nkb of a chunk: request SWEEP_U tiles of W/m/v, then per tile
+//   dW^T = x_t^T dy (4*MB f32 MFMAs; D image == the tile image)  ->  Adam(+L2) on 4 elements/lane in registers  ->
+//   store W, m, v (+ transposed copy T for OUT/HEAD)  ->  y_{t+1} += x_{t+1} W_new^T (4*MB f32 MFMAs) into yacc.
+// ------------------------------------------------------------------------------------------------
+template <int MB, bool NT, int SWEEP_U>
+__device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const int rb, const int nkb, const int kb0,
+                                         const int kbs, const float* xt, const int ST, const float* xn, const int SN,
+                                         const float (&dyf)[MB * 4], const float gsc, const AdamC& ac, const bool upd,
+                                         const bool fwd, f32x4 (&yacc)[MB], float* T, const int tstride_rb,
+                                         const int lane) {
+    const int l15 = lane & 15, lg = lane >> 4;
+    for (int kbb = kb0; kbb < nkb; kbb += SWEEP_U * kbs) {
+        f32x4 w4[SWEEP_U], m4[SWEEP_U], v4[SWEEP_U];
+#pragma unroll
+        for (int u = 0; u < SWEEP_U; ++u) {
+            const int kb = kbb + u * kbs;
+            if (kb < nkb) {
+                const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+                // state larger than the Infinity Cache is streamed once per step: nontemporal (+5 % HBM rate)
+                w4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Wp + off))
+                           : *reinterpret_cast<const f32x4*>(Wp + off);
+                if (upd) {
+                    m4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mp + off))
+                               : *reinterpret_cast<const f32x4*>(Mp + off);
+                    v4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vp + off))
+                               : *reinterpret_cast<const f32x4*>(Vp + off);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SWEEP_U; ++u) {
+            const int kb = kbb + u * kbs;
+            if (kb < nkb) {
+                const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+                if (upd) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < MB * 4; ++j)
+                        acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float w = w4[u][q], m = m4[u][q], v = v4[u][q];
+                        adam1(w, m, v, acc[q] * gsc, ac);
+                        w4[u][q] = w;
+                        m4[u][q] = m;
+                        v4[u][q] = v;
+                    }
+                    if (NT) {
+                        __builtin_nontemporal_store(w4[u], reinterpret_cast<f32x4*>(Wp + off));
+                        __builtin_nontemporal_store(m4[u], reinterpret_cast<f32x4*>(Mp + off));
+                        __builtin_nontemporal_store(v4[u], reinterpret_cast<f32x4*>(Vp + off));
+                    } else {
+                        *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
+                        *reinterpret_cast<f32x4*>(Mp + off) = m4[u];
+                        *reinterpret_cast<f32x4*>(Vp + off) = v4[u];
+                    }
+                    if (T) {   // keep the transposed copy used by the backward chain in step (OUT / HEAD only)
+                        float* Tt = T + ((int64_t)kb * tstride_rb + rb) * 256;
+                        const int base = (((l15 >> 2) * 16 + 4 * lg) << 2) + (l15 & 3);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Tt[base + 4 * q] = w4[u][q];
+                    }
+                }
+                if (fwd) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * SN + kb * 16 + 4 * lg);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][q], yacc[mb]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sweep — fused dW + Adam + next-step forward.  One workgroup = ALL row blocks of one weight segment
+// over a chunk of `cc` columns: x_t / x_{t+1} / dy are staged ONCE in LDS, then every wave streams whole
+// row blocks (contiguous 1 KiB tiles), requesting the W/m/v tiles of 4 k-blocks before consuming them.
+// ------------------------------------------------------------------------------------------------
+struct SweepArgs {
+    const SegDesc* desc;
+    const TapDesc* tdesc;   // tap-major work list (may be empty)
+    int32_t ntap, _padt;
+    const CandDev* cands;
+    float* plane;
+    int64_t plane_stride;
+    float* wt;
+    float* stepbuf;
+    mfas_table tab;
+    const int32_t* order;
+    int64_t pos_t, pos_n;
+    int32_t base_t, base_n, nvalid_t, nvalid_n;
+    int32_t do_update, do_forward;
+    AdamC ac;
+    Geo g;
+};
+
+#define STEP_NW 8
+#define STEP_THREADS (STEP_NW * 64)
+
+template <int MB, bool NT, int U>
+__device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, float* lds) {
+    const SegDesc d = a.desc[bid];
+    const CandDev& cd = a.cands[d.cand];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int Bp = MB * 16;
+    const int cc = d.cc, rows_p = d.rows_p, nrb = rows_p >> 4, nkb = cc >> 4;
+    const int ST = cc + 16;   // x_t stride: conflict-free ds_read_b32 column reads
+    const int SN = cc + 4;    // x_{t+1} stride: 16 B aligned rows for ds_read_b128
+    const int SD = rows_p + 16;
+    float* xt = lds;
+    float* xn = xt + Bp * ST;
+    float* dyl = xn + Bp * SN;
+    float* wred = dyl + Bp * SD;   // [8 waves][nrb][MB][256], only when the chunk is k-split over waves
+    const bool feat = d.kind <= KIND_V;
+    const bool upd = a.do_update != 0;
+    const bool fwd = (a.do_forward != 0) && feat;
+    if (!upd && !fwd) return;
+    float* sb = a.stepbuf + cd.step_off;
+
+    if (upd) {
+        if (feat) {
+            const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
+            stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_t, a.base_t, a.nvalid_t, Bp, tid, STEP_THREADS);
+        } else {
+            const int xcell = d.kind == KIND_OUT ? d.cell - 1 : cd.L - 1;
+            stage_f32(xt, ST, sb + a.g.sb_xo + (int64_t)xcell * Bp * a.g.Rp + d.k0, a.g.Rp, cc, Bp, tid, STEP_THREADS);
+        }
+        const float* dsrc = d.kind == KIND_HEAD ? sb + a.g.sb_dlog : sb + a.g.sb_dy + (int64_t)d.cell * Bp * a.g.Rp;
+        stage_f32(dyl, SD, dsrc, rows_p, rows_p, Bp, tid, STEP_THREADS);
+    }
+    if (fwd) {
+        const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
+        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_n, a.base_n, a.nvalid_n, Bp, tid, STEP_THREADS);
+    }
+    __syncthreads();
+
+    float* Wp = a.plane + d.w_off;
+    float* Mp = Wp + a.plane_stride;
+    float* Vp = Mp + a.plane_stride;
+    const AdamC ac = a.ac;
+    // alpha scaling of the gradient of S / V columns (aux_models.py:103-111): sigma(alpha_t) as used by this
+    // step's forward, published by k_chain (alpha itself has already been stepped); 1.0 when alphas are off
+    float gsc = 1.0f;
+    if (a.g.alphas && feat && upd) gsc = sb[a.g.sb_gsc + d.cell * 2 + d.kind];
+
+    // Work split: with >= 8 row blocks every wave owns whole row blocks (streams contiguous tiles, no
+    // reduction); with fewer (R < 128) the waves split the k blocks and reduce through LDS.
+    const bool split_k = nrb < STEP_NW;
+    const int rb0 = split_k ? 0 : wave, rbs = split_k ? 1 : STEP_NW;
+    const int kb0 = split_k ? wave : 0, kbs = split_k ? STEP_NW : 1;
+    float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * nrb * MB) << 8);
+
+    for (int rb = rb0; rb < nrb; rb += rbs) {
+        float dyf[MB * 4];
+#pragma unroll
+        for (int j = 0; j < MB * 4; ++j) dyf[j] = upd ? dyl[(4 * j + lg) * SD + rb * 16 + l15] : 0.f;
+        f32x4 yacc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        tile_run<MB, NT, U>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
+                         d.wt_off >= 0 ? a.wt + d.wt_off + (int64_t)(d.k0 >> 4) * nrb * 256 : nullptr, nrb, lane);
+        if (fwd) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                if (split_k)
+                    *reinterpret_cast<f32x4*>(wred + (((wave * nrb + rb) * MB + mb) << 8) + lane * 4) = yacc[mb];
+                else   // partial slot in MFMA D layout [chunk][rb][mb][lane][4]
+                    *reinterpret_cast<f32x4*>(part + ((rb * MB + mb) << 8) + lane * 4) = yacc[mb];
+            }
+        }
+    }
+    if (!fwd || !split_k) return;
+    __syncthreads();
+    // deterministic cross-wave reduction (fixed order 0..7)
+    for (int e = tid; e < nrb * MB * 64; e += STEP_THREADS) {
+        const int slot = e >> 6, ln = e & 63;
+        f32x4 s = *reinterpret_cast<const f32x4*>(wred + (slot << 8) + ln * 4);
+#pragma unroll
+        for (int w = 1; w < STEP_NW; ++w)
+            s += *reinterpret_cast<const f32x4*>(wred + ((w * nrb * MB + slot) << 8) + ln * 4);
+        *reinterpret_cast<f32x4*>(part + (slot << 8) + ln * 4) = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweep_tap_body — the same fused dW + Adam + next-step forward for SMALL R (1, 2 or 4 row blocks): a column chunk of
+// ONE feature tap is staged once and shared by up to 8/nrb segments (candidates x cells) that read this tap; every wave
+// owns one (segment, row block), streams its contiguous tiles and writes its forward partial directly — no cross-wave
+// reduction, and the feature staging (1/3 of the traffic at R=16) is amortised over the segments.
+// ------------------------------------------------------------------------------------------------
+template <int MB, bool NT, int U>
+__device__ __forceinline__ void sweep_tap_body(const SweepArgs& a, const int bid, float* lds) {
+    const TapDesc& d = a.tdesc[bid];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int Bp = MB * 16;
+    const int cc = d.cc, rows_p = d.rows_p, nrb = rows_p >> 4, nkb = cc >> 4;
+    const int ST = cc + 16, SN = cc + 4;
+    float* xt = lds;
+    float* xn = xt + Bp * ST;
+    const bool upd = a.do_update != 0;
+    const bool fwd = a.do_forward != 0;
+    if (!upd && !fwd) return;
+    const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
+    if (upd) stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_t, a.base_t, a.nvalid_t, Bp, tid, STEP_THREADS);
+    if (fwd) stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_n, a.base_n, a.nvalid_n, Bp, tid, STEP_THREADS);
+    __syncthreads();
+    const int item = wave / nrb, rb = wave - item * nrb;
+    if (item >= d.nitems) return;
+    const CandDev& cd = a.cands[d.cand[item]];
+    float* sb = a.stepbuf + cd.step_off;
+    const int cell = d.cell[item];
+    float dyf[MB * 4];
+#pragma unroll
+    for (int j = 0; j < MB * 4; ++j) dyf[j] = 0.f;
+    if (upd) {
+        const float* dsrc = sb + a.g.sb_dy + (int64_t)cell * Bp * a.g.Rp;
+#pragma unroll
+        for (int j = 0; j < MB * 4; ++j) dyf[j] = dsrc[(4 * j + lg) * rows_p + rb * 16 + l15];
+    }
+    float gsc = 1.0f;
+    if (a.g.alphas && upd) gsc = sb[a.g.sb_gsc + cell * 2 + d.kind];
+    float* Wp = a.plane + d.w_off[item];
+    float* Mp = Wp + a.plane_stride;
+    float* Vp = Mp + a.plane_stride;
+    const AdamC ac = a.ac;
+    f32x4 yacc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile_run<MB, NT, U>(Wp, Mp, Vp, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc, nullptr, nrb, lane);
+    if (fwd) {
+        float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[cell] + d.part_idx[item]) * nrb * MB) << 8);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            *reinterpret_cast<f32x4*>(part + ((rb * MB + mb) << 8) + lane * 4) = yacc[mb];
+    }
+}
