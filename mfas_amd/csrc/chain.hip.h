@@ -714,37 +714,36 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
     // that nothing needs before the loss, fetched by wave 1 so that wave 0 never waits for them)
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int per_cell = MB * 64;   // float4 partial-sum items per cell; L * per_cell <= 512: one item per thread
-    constexpr int PB = 16;
+    constexpr int PB = 16;              // partial-sum chunks requested per thread before any is consumed
     const bool has_item = tid < L * per_cell;
-    const int pi = has_item ? tid / per_cell : 0, pit = tid - pi * per_cell;
+    // (per_cell = MB * 64: the cell index is wave-uniform -> scalar loads of cd.nch_* / part_cell_off)
+    const int pi = __builtin_amdgcn_readfirstlane(has_item ? tid / per_cell : 0), pit = tid - pi * per_cell;
     const int ns = cd.nch_s[pi], nch = has_item ? ns + cd.nch_v[pi] : 0;
     const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[pi] * MB) << 8) + pit * 4;
+    // every load below is UNCONDITIONAL (indices clamped to something valid): with a statically known number of loads in
+    // flight the compiler can wait for exactly the ones it consumes instead of draining the whole queue at first use
     f32x4 p8[PB];
 #pragma unroll
-    for (int u = 0; u < PB; ++u)
-        if (u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)u * MB) << 8));
-    float vw = 0.f, vm = 0.f, vv = 0.f;   // nvec = 4 * 96 + Cp <= 448: one element of the vector block per thread
-    if (tid < nvec) { vw = W[cvec_off + tid]; vm = Mv[cvec_off + tid]; vv = Vv[cvec_off + tid]; }
-    f32x4 tP[MFAS_MAX_CELLS], tT[MFAS_MAX_CELLS], tHT[4], tH = z4;   // prev-out tile of cell i, its transpose, head^T, head
-#pragma unroll
-    for (int i = 0; i < MFAS_MAX_CELLS; ++i) { tP[i] = z4; tT[i] = z4; tHT[i] = z4; }
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 1; i < MFAS_MAX_CELLS; ++i)
-            if (i < L) {
-                tP[i] = *reinterpret_cast<const f32x4*>(W + cd.seg_off[i][2] + lane * 4);
-                tT[i] = *reinterpret_cast<const f32x4*>(a.wt + cd.outT_off[i] + lane * 4);
-            }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < ncb) tHT[u] = *reinterpret_cast<const f32x4*>(a.wt + cd.headT_off + ((int64_t)u << 8) + lane * 4);
+    for (int u = 0; u < PB; ++u) {
+        const int uu = u < nch ? u : 0;
+        p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)uu * MB) << 8));
     }
-    if (wave < ncb) tH = *reinterpret_cast<const f32x4*>(W + cd.head_off + ((int64_t)wave << 8) + lane * 4);
-    int lab = 0;
-    if (wave == 1 && lane < nvalid) {
-        const int64_t row = a.order ? (int64_t)a.order[a.pos_t + lane] : (int64_t)(a.base_t + lane);
-        lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
+    const int vi = tid < nvec ? tid : 0;   // nvec = 4 * 96 + Cp <= 448: one element of the vector block per thread
+    const float vw = W[cvec_off + vi], vm = Mv[cvec_off + vi], vv = Vv[cvec_off + vi];
+    // weight tiles of every product (all waves fetch them — 11 KiB, uniform control flow; wave 0 / waves < ncb use them)
+    f32x4 tP[MFAS_MAX_CELLS], tT[MFAS_MAX_CELLS], tHT[4], tH;   // prev-out tile of cell i, its transpose, head^T, head
+    tP[0] = z4; tT[0] = z4;
+#pragma unroll
+    for (int i = 1; i < MFAS_MAX_CELLS; ++i) {
+        const float* fp = i < L ? W + cd.seg_off[i][2] : W + cvec_off;
+        const float* tp = i < L ? a.wt + cd.outT_off[i] : W + cvec_off;
+        tP[i] = *reinterpret_cast<const f32x4*>(fp + lane * 4);
+        tT[i] = *reinterpret_cast<const f32x4*>(tp + lane * 4);
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        tHT[u] = *reinterpret_cast<const f32x4*>(a.wt + cd.headT_off + ((int64_t)(u < ncb ? u : 0) << 8) + lane * 4);
+    tH = *reinterpret_cast<const f32x4*>(W + cd.head_off + ((int64_t)(wave < ncb ? wave : 0) << 8) + lane * 4);
     // dropout keep bits of this lane's elements (wave 0 owns the row block): bit (i*MB + mb)*4 + q — computed while the
     // loads above are in flight, used by the forward AND the backward pass
     const int r = l15;
@@ -785,6 +784,13 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
         }
     }
     if (tid < nvec) { vec_l[tid] = vw; vec_l[nvec + tid] = vm; vec_l[2 * nvec + tid] = vv; }
+    // labels: a dependent pair of loads that nothing needs before the loss; requested last, by wave 1, consumed after the
+    // forward pass
+    int lab = 0;
+    if (wave == 1 && lane < nvalid) {
+        const int64_t row = a.order ? (int64_t)a.order[a.pos_t + lane] : (int64_t)(a.base_t + lane);
+        lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
+    }
     const float* vecW = vec_l;
     const float* vecM = vec_l + nvec;
     const float* vecV = vec_l + 2 * nvec;
