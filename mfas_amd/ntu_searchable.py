@@ -218,11 +218,56 @@ def set_central_states(model, state_dict, using_dataparallel=False):
 PROFILE: List[tuple] = []   # (launches, total ms, algorithmic bytes/launch) of k_sweep per call when args.engine_profile
 
 
-def _require_loader(x, name) -> FeatureLoader:
-    if not isinstance(x, FeatureLoader):
-        raise TypeError(f"dataloaders['{name}'] must be a mfas_amd.FeatureLoader over a HIP-resident FeatureTable; "
-                        "there is no raw-video / CPU path")
-    return x
+def _require_loader(x, name, device=None) -> FeatureLoader:
+    """SURVEY §8(b) dataloaders contract.  Fast path: a FeatureLoader over a HIP-resident table.  Otherwise any iterable
+    of reference-shaped batches ``{'rgb': {v0..v3[, vlogit]}, 'ske': {s0..s3[, slogit]}, 'label'}`` whose taps are
+    already pooled to (B, width) (train_searchable/ntu.py:35-43 reads exactly these keys): it is drained ONCE into a
+    device-resident FeatureTable (cached on the loader object) and from then on only its batch size and shuffle flag
+    matter.  Raw video / skeleton tensors are rejected: there are no backbones here."""
+    if isinstance(x, FeatureLoader):
+        return x
+    cached = getattr(x, "_mfas_feature_loader", None)
+    if cached is not None:
+        return cached
+    if device is None or not hasattr(x, "__iter__"):
+        raise TypeError(f"dataloaders['{name}'] must be a mfas_amd.FeatureLoader over a HIP-resident FeatureTable (or an "
+                        "iterable of pooled-tap batches); there is no raw-video / CPU path")
+    taps, labels, extra = {}, [], {}
+    bsz = 0
+    for batch in x:
+        rgb, ske = batch["rgb"], batch["ske"]
+        if not hasattr(rgb, "items") or not hasattr(ske, "items"):
+            raise TypeError(f"dataloaders['{name}']: 'rgb' / 'ske' must map tap names (v0.., s0..) to pooled (B, width) "
+                            "tensors; raw video needs the frozen backbones, which are outside this engine")
+        for src in (rgb, ske):
+            for k, v in src.items():
+                if v is None:
+                    continue
+                v = torch.as_tensor(v)
+                if k in ("vlogit", "slogit"):
+                    extra.setdefault(k, []).append(v.reshape(v.shape[0], -1).float())
+                elif len(k) >= 2 and k[0] in "sv" and k[1:].isdigit():
+                    if v.dim() > 2:          # GlobalPooling2D semantics (aux_models.py:58-64) for un-pooled maps
+                        v = v.reshape(v.shape[0], v.shape[1], -1).float().mean(2)
+                    taps.setdefault(k, []).append(v)
+        lab = torch.as_tensor(batch["label"]).reshape(-1)
+        labels.append(lab)
+        bsz = max(bsz, int(lab.numel()))
+    if not labels:
+        raise ValueError(f"dataloaders['{name}'] yielded no batches")
+    dev = torch.device(device)
+    table = FeatureTable({k: torch.cat(v).to(dev) for k, v in taps.items()},
+                         torch.cat(labels).to(dev).to(torch.int32),
+                         vlogit=torch.cat(extra["vlogit"]).to(dev) if "vlogit" in extra else None,
+                         slogit=torch.cat(extra["slogit"]).to(dev) if "slogit" in extra else None)
+    sampler = getattr(x, "sampler", None)
+    shuffle = sampler is not None and type(sampler).__name__ == "RandomSampler"
+    fl = FeatureLoader(table, int(getattr(x, "batch_size", None) or bsz), shuffle=shuffle)
+    try:
+        x._mfas_feature_loader = fl
+    except Exception:
+        pass
+    return fl
 
 
 def make_order(N, epochs, shuffle, seed, device):
@@ -248,9 +293,9 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
                         "(reference behaviour, ntu_searchable.py:86-89)")
     if not train_only_central_params:
         raise NotImplementedError("backbone fine-tuning needs raw video; the engine trains central_params() only")
-    train_l = _require_loader(dataloaders["train"], "train")
-    dev_l = _require_loader(dataloaders["dev"], "dev")
     device = torch.device(device)
+    train_l = _require_loader(dataloaders["train"], "train", device)
+    dev_l = _require_loader(dataloaders["dev"], "dev", device)
     hp = _hp if _hp is not None else Hyper.from_args(args)
     hp.multitask = False    # ntu_searchable.py:82-84 never forwards multitask to the train loop
     if getattr(args, "multitask", False) and _hp is None:

@@ -28,8 +28,8 @@ def train_ntu_track_acc(model, criteria, optimizer, scheduler, dataloaders, data
     starts from a fresh Adam state like a newly built torch.optim.Adam) under the per-batch LR of
     ``scheduler``; returns the best dev accuracy (0-d float64 tensor) and leaves the best-epoch weights in
     ``model`` in eval mode (ntu.py:82-87).  ``criteria`` is CrossEntropyLoss by construction of the path."""
-    train_l = _require_loader(dataloaders["train"], "train")
-    dev_l = _require_loader(dataloaders["dev"], "dev")
+    train_l = _require_loader(dataloaders["train"], "train", device)
+    dev_l = _require_loader(dataloaders["dev"], "dev", device)
     device = torch.device(device) if device is not None else train_l.table.device
     model = model.module if isinstance(model, torch.nn.DataParallel) else model
     hp = _adam_hyper(model.hyper(multitask), optimizer)
@@ -63,7 +63,7 @@ def train_ntu_track_acc(model, criteria, optimizer, scheduler, dataloaders, data
 
 def test_ntu_track_acc(model, dataloaders, dataset_sizes, device=None, multitask=False):
     """Accuracy over dataloaders['test'] in eval mode (ntu.py:92-125)."""
-    test_l = _require_loader(dataloaders["test"], "test")
+    test_l = _require_loader(dataloaders["test"], "test", device)
     device = torch.device(device) if device is not None else test_l.table.device
     model = model.module if isinstance(model, torch.nn.DataParallel) else model
     model.train(False)

@@ -242,3 +242,41 @@ def test_global_pooling_kernel(dev):
     gbs = big.numel() * 4 * 10 / (time.perf_counter() - t0) / 1e9
     print(f"global_pool: {gbs:.0f} GB/s on a 268 MB f32 tap")
     assert gbs > 1000
+
+
+def test_generic_pooled_tap_loader_is_accepted(dev):
+    """dataloaders may be any iterable of reference-shaped batches {'rgb','ske','label'} carrying pooled
+    taps (here a torch DataLoader over a dict Dataset): drained once into a HIP table, same result as a FeatureLoader."""
+    import mfas_amd as M
+    from types import SimpleNamespace
+
+    t = O.synth_table(96, 41, snr=1.0)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 96
+
+        def __getitem__(self, i):
+            return {"rgb": {k: torch.from_numpy(t[k][i]) for k in ("v0", "v1", "v2", "v3")},
+                    "ske": {k: torch.from_numpy(t[k][i]) for k in ("s0", "s1", "s2", "s3")},
+                    "label": int(t["label"][i])}
+
+    args = SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=0.0, inner_representation_size=16, batchnorm=True,
+                           alphas=False, multitask=False, weightsharing=False, batchsize=16, eta_max=1e-3, eta_min=1e-6,
+                           Ti=1, Tm=2, use_dataparallel=False, verbose=False, epochs=2, engine_init="device")
+    confs = [np.array(CONFS["c4"]), np.array(CONFS["l2"])]
+    generic = {"train": torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False),
+               "dev": torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False)}
+    tab = M.FeatureTable.from_numpy(t, dev)
+    fast = {"train": M.FeatureLoader(tab, 16, shuffle=False), "dev": M.FeatureLoader(tab, 16, shuffle=False)}
+    M.train_sampled_models(confs[:1], M.Searchable_Skeleton_Image_Net, generic, args, dev)   # drains the loaders (a DataLoader draws from the torch RNG)
+    torch.manual_seed(3)
+    a = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, generic, args, dev)
+    torch.manual_seed(3)
+    b = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, fast, args, dev)
+    assert a == b and all(0.0 <= x <= 1.0 for x in a)
+    assert getattr(generic["train"], "_mfas_feature_loader", None) is not None      # drained once, then cached
+    with pytest.raises(TypeError):      # raw video cannot be served: no backbones in this engine
+        M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net,
+                               {"train": [{"rgb": torch.zeros(2, 3, 8, 32, 32), "ske": torch.zeros(2, 3, 8, 25, 2), "label": torch.zeros(2)}],
+                                "dev": fast["dev"]}, args, dev)
