@@ -50,6 +50,7 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--random_search", action="store_true", default=False)
     p.add_argument("--engine_init", default="torch", choices=["torch", "device"])
+    p.add_argument("--timing", action="store_true", help="print how the wall time splits into candidate training (GPU) and the controller / surrogate (CPU)")
     p.add_argument("--controller_threads", type=int, default=4,
                    help="torch CPU threads for the 81k-parameter surrogate (more threads only add overhead)")
     return p.parse_args(argv)
@@ -78,6 +79,21 @@ def main(argv=None):
     rank0 = int(os.environ.get("RANK", "0")) == 0
     if rank0:
         print("MFAS for NTU Started!!!!")
+    spent = {"train": 0.0, "calls": 0, "cands": 0}
+    if args.timing:
+        from mfas_amd import ntu_searchable as _ntu
+        inner = _ntu.train_sampled_models
+
+        def timed(confs, *a, **kw):
+            torch.cuda.synchronize()
+            t = time.time()
+            out = inner(confs, *a, **kw)
+            torch.cuda.synchronize()
+            spent["train"] += time.time() - t
+            spent["calls"] += 1
+            spent["cands"] += len(confs)
+            return out
+        _ntu.train_sampled_models = timed
     t0 = time.time()
     if args.random_search:
         from mfas_amd import ntu_searchable as ntu
@@ -89,6 +105,10 @@ def main(argv=None):
     el = time.time() - t0
     if rank0:
         print("Search complete in {:.0f}m {:.0f}s".format(el // 60, el % 60))
+        if args.timing:
+            print("timing: {:.2f} s total = {:.2f} s candidate training ({} calls, {} candidates, {:.1f} cand/s) + {:.2f} s "
+                  "controller/surrogate".format(el, spent["train"], spent["calls"], spent["cands"],
+                                                spent["cands"] / max(spent["train"], 1e-9), el - spent["train"]))
         k_best, k_accs, _ = data.get_k_best(5)
         print("Now listing best architectures")
         for c, a in sorted(zip(k_best, k_accs), key=lambda t: -t[1]):
