@@ -50,6 +50,8 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--random_search", action="store_true", default=False)
     p.add_argument("--engine_init", default="torch", choices=["torch", "device"])
+    p.add_argument("--surrogate_device", default="cpu", choices=["cpu", "gpu"],
+                   help="where the 81k-parameter LSTM surrogate trains (the reference puts it on its training device)")
     p.add_argument("--timing", action="store_true", help="print how the wall time splits into candidate training (GPU) and the controller / surrogate (CPU)")
     p.add_argument("--controller_threads", type=int, default=4,
                    help="torch CPU threads for the 81k-parameter surrogate (more threads only add overhead)")
@@ -101,7 +103,7 @@ def main(argv=None):
                                     {"train_sampled_fun": ntu.train_sampled_models,
                                      "get_layer_confs": ntu.get_possible_layer_configurations}, device)
     else:
-        data = searcher.search()
+        data = searcher.search(surrogate_device=device if args.surrogate_device == "gpu" else "cpu")
     el = time.time() - t0
     if rank0:
         print("Search complete in {:.0f}m {:.0f}s".format(el // 60, el % 60))
