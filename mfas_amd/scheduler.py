@@ -1,65 +1,67 @@
-"""Per-batch cosine annealing with warm restarts.
+"""Learning-rate schedules of the path, engine-first.
 
-Mirrors ``LRCosineAnnealingScheduler`` / ``FixedScheduler`` of the reference
-(/root/reference/models/auxiliary/scheduler.py:12-46, :50-62): same constructor, ``step()``,
-``update_optimizer()`` and attribute names.  The engine does not round-trip an optimizer
-state_dict every batch; it consumes the whole eta sequence up front (``eta_table``).
+The HIP engine consumes a whole run's learning rates up front (``eta_table(n)`` -> float64 array, turned into per-step
+Adam scalars by ``adam_step_scalars``) instead of pushing one value per batch through ``optimizer.state_dict()``.
+For code written against the reference (/root/reference/models/auxiliary/scheduler.py:12-46 cosine annealing with warm
+restarts, :50-62 fixed rate) the same objects also answer ``step()`` / ``update_optimizer(optimizer)`` and expose the
+reference's attribute names (``eta, eta_min, eta_max, Ti, Tm, Tcur, nbpe, iteration_counter``).
+
+Rule (float64, like the reference's numpy scalars): with c the number of steps since the last restart,
+``eta = eta_min + (eta_max - eta_min)/2 * (1 + cos(pi * (c/nbpe) / Ti))``; when that value reaches ``eta_min`` (within
+1e-10) the period is multiplied by ``Tm`` and c starts again at 0 — the restart step itself still reports ``eta_min``.
 """
+
 import numpy as np
+
+_RESTART_SLACK = 1e-10
+
+
+def _set_lr(optimizer, lr):
+    for group in optimizer.param_groups:
+        group["lr"] = lr
 
 
 class LRCosineAnnealingScheduler:
     def __init__(self, eta_max, eta_min, Ti, Tmultiplier, num_batches_per_epoch):
-        self.eta_min = eta_min
-        self.eta_max = eta_max
-        self.Ti = Ti
-        self.Tcur = 0.0
+        self.eta_max, self.eta_min = eta_max, eta_min
+        self.Ti, self.Tm = Ti, Tmultiplier
         self.nbpe = num_batches_per_epoch
-        self.iteration_counter = 0.0
+        self.iteration_counter = 0.0      # steps since the last restart
+        self.Tcur = 0.0                   # the same in epochs
         self.eta = eta_max
-        self.Tm = Tmultiplier
-
-    def _compute_rule(self):
-        self.eta = self.eta_min + 0.5 * (self.eta_max - self.eta_min) * (1 + np.cos(np.pi * self.Tcur / self.Ti))
-        return self.eta
-
-    def step(self):
-        self.Tcur = self.iteration_counter / self.nbpe
-        self.iteration_counter = self.iteration_counter + 1.0
-        eta = self._compute_rule()
-        if eta <= self.eta_min + 1e-10:      # warm restart (scheduler.py:35-38)
-            self.Tcur = 0
-            self.Ti = self.Ti * self.Tm
-            self.iteration_counter = 0
-        return eta
-
-    def update_optimizer(self, optimizer):
-        for group in optimizer.param_groups:
-            group["lr"] = self.eta
 
     def eta_table(self, n):
-        """The next n learning rates (advances the scheduler exactly like n ``step()`` calls)."""
-        out = np.empty(n, np.float64)
-        for i in range(n):
-            self.step()
-            out[i] = self.eta
-        return out
+        """The next ``n`` learning rates; the object ends up where ``n`` calls of ``step()`` would leave it."""
+        table = np.empty(int(n), np.float64)
+        half_span = 0.5 * (self.eta_max - self.eta_min)
+        for k in range(int(n)):
+            self.Tcur = self.iteration_counter / self.nbpe
+            self.iteration_counter += 1.0
+            self.eta = self.eta_min + half_span * (1 + np.cos(np.pi * self.Tcur / self.Ti))
+            table[k] = self.eta
+            if self.eta <= self.eta_min + _RESTART_SLACK:
+                self.Ti, self.Tcur, self.iteration_counter = self.Ti * self.Tm, 0, 0
+        return table
+
+    def step(self):
+        return float(self.eta_table(1)[0])
+
+    def update_optimizer(self, optimizer):
+        _set_lr(optimizer, self.eta)
 
 
 class FixedScheduler:
     def __init__(self, lr):
-        self.lr = lr
-        self.eta = lr
+        self.lr = self.eta = lr
+
+    def eta_table(self, n):
+        return np.full(int(n), self.lr, np.float64)
 
     def step(self):
         return self.lr
 
     def update_optimizer(self, optimizer):
-        for group in optimizer.param_groups:
-            group["lr"] = self.lr
-
-    def eta_table(self, n):
-        return np.full(n, self.lr, np.float64)
+        _set_lr(optimizer, self.lr)
 
 
 def adam_step_scalars(etas, beta1=0.9, beta2=0.999):

@@ -10,7 +10,17 @@ import torch
 import torch.nn as nn
 
 
+def _reference_init(module):
+    """surrogate.py:26-30: every Linear starts at U(-0.1, 0.1) weights and bias 1.8 (the LSTM keeps PyTorch's default)."""
+    for m in module.modules():
+        if isinstance(m, nn.Linear):
+            m.weight.data.uniform_(-0.1, 0.1)
+            m.bias.data.fill_(1.8)
+
+
 class SimpleRecurrentSurrogate(nn.Module):
+    """conf rows (s, v, nl) -> embedding -> LSTM over the cells -> predicted accuracy in (0, 1)."""
+
     def __init__(self, num_hidden=100, number_input_feats=3, size_ebedding=100):
         super().__init__()
         self.num_hidden = num_hidden
@@ -18,65 +28,66 @@ class SimpleRecurrentSurrogate(nn.Module):
         self.lstm = nn.LSTM(size_ebedding, num_hidden)
         self.hid2val = nn.Linear(num_hidden, 1)
         self.nonlinearity = nn.Sigmoid()
-        for m in self.modules():
-            if isinstance(m, nn.Linear):
-                m.weight.data.uniform_(-0.1, 0.1)
-                m.bias.data.fill_(1.8)
+        _reference_init(self)
 
     def forward(self, sequence_of_operations):
-        """(seq_len, batch, 3) -> (batch, 1)."""
-        embeds = torch.stack([self.embedding(s) for s in sequence_of_operations], dim=0)
-        lstm_out, _ = self.lstm(embeds)
-        return self.nonlinearity(self.hid2val(lstm_out[-1]))
+        """(seq_len, batch, 3) float -> (batch, 1).  The embedding is applied cell by cell (one GEMM per position, as the
+        reference does) so that batched and single-sequence calls go through the same kernels per position."""
+        per_cell = [self.embedding(cell) for cell in sequence_of_operations]
+        hidden_states, _ = self.lstm(torch.stack(per_cell, dim=0))
+        return self.nonlinearity(self.hid2val(hidden_states[-1]))
 
     def eval_model(self, sequence_of_operations_np, device):
+        """One configuration (L, 3) -> python-indexable scalar (kept for API parity; the controller predicts in batches,
+        tools.predict_accuracies_with_surrogate)."""
         seq = torch.from_numpy(np.expand_dims(sequence_of_operations_np, 1)).float().to(device)
         return self.forward(seq).cpu().data.numpy()[0, 0]
 
 
 class SurrogateDataloader:
+    """The surrogate's growing training set: one bucket per configuration length, one entry per distinct configuration
+    (keyed by its bytes) holding the best accuracy seen for it; buckets and entries keep insertion order."""
+
     def __init__(self):
         self._dict_data = {}
 
     def add_datum(self, datum_conf, datum_acc):
         bucket = self._dict_data.setdefault(len(datum_conf), {})
         key = datum_conf.data.tobytes()
-        if key in bucket:
-            datum_acc = max(datum_acc, bucket[key][1])      # keep the best accuracy seen for a conf
-        bucket[key] = (datum_conf, datum_acc)
+        seen = bucket.get(key)
+        bucket[key] = (datum_conf, datum_acc if seen is None else max(datum_acc, seen[1]))
+
+    def _entries(self):
+        for bucket in self._dict_data.values():
+            yield list(bucket.values())
 
     def get_data(self, to_torch=False):
+        """([ (seq_len, n, 3) float32 per bucket ], [ (n, 1) float32 per bucket ])."""
+        wrap = torch.from_numpy if to_torch else (lambda x: x)
         confs, accs = [], []
-        for _, bucket in self._dict_data.items():
-            c = np.asarray([d[0] for d in bucket.values()], np.float32)
-            confs.append(np.array(np.transpose(c, (1, 0, 2)), np.float32))          # (seq_len, n, 3)
-            accs.append(np.expand_dims(np.array([d[1] for d in bucket.values()], np.float32), 1))
-        if to_torch:
-            confs = [torch.from_numpy(c) for c in confs]
-            accs = [torch.from_numpy(a) for a in accs]
+        for entries in self._entries():
+            stacked = np.asarray([c for c, _ in entries], np.float32)            # (n, seq_len, 3)
+            confs.append(wrap(np.ascontiguousarray(stacked.transpose(1, 0, 2))))
+            accs.append(wrap(np.asarray([[a] for _, a in entries], np.float32)))
         return confs, accs
 
     def get_k_best(self, k):
-        confs, accs = [], []
-        for _, bucket in self._dict_data.items():
-            for d in bucket.values():
-                confs.append(d[0])
-                accs.append(d[1])
-        accs = np.array(accs)
+        flat = [e for entries in self._entries() for e in entries]
+        accs = np.array([a for _, a in flat])
         top = np.argpartition(accs, -k)[-k:]
-        return [confs[i] for i in top], [accs[i] for i in top], top
+        return [flat[i][0] for i in top], [accs[i] for i in top], top
 
 
 def train_simple_surrogate(model, criterion, optimizer, data_tensors, num_epochs, device):
-    loss = None
+    """surrogate.py:133-157: ``num_epochs`` passes over the buckets, one optimizer step per bucket; returns the last loss."""
+    buckets = [(x.to(device), y.to(device)) for x, y in zip(*data_tensors)]
+    last = None
+    model.train(True)
     for _ in range(num_epochs):
-        model.train(True)
-        for inputs, outputs in zip(data_tensors[0], data_tensors[1]):
-            inputs, outputs = inputs.to(device), outputs.to(device)
+        for x, y in buckets:
             optimizer.zero_grad()
-            with torch.set_grad_enabled(True):
-                loss = criterion(model(inputs), outputs)
-                loss.backward()
-                optimizer.step()
+            last = criterion(model(x), y)
+            last.backward()
+            optimizer.step()
     model.train(False)
-    return loss.item()
+    return last.item()
