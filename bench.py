@@ -198,6 +198,13 @@ def main():
                 traffic = json.load(open(tp))["per_launch"]["total_bytes"]
             except Exception:
                 traffic = None
+        mfma = None         # MfmaUtil (%) of the same kernel from the committed PMC pass (tools/pmc_mfma.py)
+        mp = os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")
+        if os.path.exists(mp) and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1:
+            try:
+                mfma = json.load(open(mp))["k_step"]["MfmaUtil"]["mean"]
+            except Exception:
+                mfma = None
         stream = None       # live ceiling of THIS box for the sweep's access pattern (no compute), same units as `achieved`
         if world == 1:
             import ctypes
@@ -220,7 +227,8 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "launches": n_launch, "avg_launch_us": (ms / n_launch * 1e3) if n_launch else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "stream_ceiling": stream, "frac_of_stream": (achieved / stream) if (achieved and stream) else None},
+                         "stream_ceiling": stream, "frac_of_stream": (achieved / stream) if (achieved and stream) else None,
+                         "mfma_util_pct": mfma},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(train, dev, a)
