@@ -134,6 +134,15 @@ class FeatureTable:
         self.multilabel = None if multilabel is None else multilabel.to(torch.float32).contiguous()
         self.device = dev
 
+    def check_labels(self, C: int):
+        """Labels must lie in [0, C) (checked once per table and class count; one small device reduction)."""
+        if getattr(self, "_labels_ok", None) == C:
+            return
+        lo, hi = int(self.label.min()), int(self.label.max())
+        if lo < 0 or hi >= C:
+            raise IndexError(f"Target {hi if hi >= C else lo} is out of bounds for {C} classes")
+        self._labels_ok = C
+
     def __len__(self):
         return self.N
 
@@ -326,6 +335,10 @@ class Population:
         if order is not None:
             order = order.to(device=self.device, dtype=torch.int32).contiguous()
             assert order.numel() >= epochs * len(train)
+        if self.hp.loss_mode == 0:      # CrossEntropyLoss raises on a target outside [0, C); the kernels index by it
+            for t in (train, dev):
+                if t is not None:
+                    t.check_labels(self.hp.C)
         stats = np.zeros((self.K, epochs), dtype=[("train_loss_sum", "f8"), ("dev_loss_sum", "f8"),
                                                   ("train_corrects", "i8"), ("dev_corrects", "i8")])
         status = np.zeros(self.K, np.int32)

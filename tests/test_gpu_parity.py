@@ -334,6 +334,11 @@ def test_error_behaviour(dev):
     t17 = O.synth_table(17, 1)          # final train batch of size 1 with BN: the reference raises
     with pytest.raises(RuntimeError, match="size 1"):
         pop.train(table(t17, dev), table(t17, dev), 1, etas_for(ohp, 17))
+    bad = O.synth_table(32, 1)
+    bad["label"] = bad["label"].copy()
+    bad["label"][5] = 60                # CrossEntropyLoss: "Target 60 is out of bounds"
+    with pytest.raises(IndexError, match="out of bounds"):
+        pop.train(table(bad, dev), None, 1, etas_for(ohp, 32))
     pop.close()
 
 
