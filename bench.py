@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--chunk-cols", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo only to exercise the N>1 path on a 1-GPU box")
+    ap.add_argument("--no-profile", action="store_true", help="no HIP-event sampling of the dominant kernel (roofline fields become null)")
     ap.add_argument("--no-bn", action="store_true", help="search-script defaults: no BatchNorm")
     ap.add_argument("--mixed-confs", action="store_true", help="population of sampled L=1..4 confs instead of conf 4")
     a = ap.parse_args()
@@ -156,7 +157,7 @@ def main():
     args = SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=a.drpt, inner_representation_size=a.R,
                            batchnorm=not a.no_bn, alphas=False, multitask=False, weightsharing=False, batchsize=a.batch,
                            eta_max=1e-3, eta_min=1e-6, Ti=1, Tm=2, use_dataparallel=False, verbose=False,
-                           epochs=a.epochs, engine_init="device", engine_profile=True,
+                           epochs=a.epochs, engine_init="device", engine_profile=not a.no_profile,
                            engine_chunk_cols=a.chunk_cols)
     confs = [np.array(CONF4) for _ in range(a.pop * world)]
     if a.mixed_confs:
