@@ -517,3 +517,27 @@ def test_second_train_call_is_a_fresh_optimizer(dev):
     assert abs(s2["train_loss_sum"][0, 0] / 64 - h2[0]["train_loss"]) < 1e-3
     assert s2["dev_corrects"][0, 0] == h2[0]["dev_corrects"]
     pop.close()
+
+
+def test_degenerate_shapes(dev):
+    """A train set smaller than one batch, a dev set smaller than an eval row block, one candidate with one cell, and a
+    population call that trains zero steps — against the oracle."""
+    from mfas_amd import best_dev_accuracy
+    ohp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=2)
+    conf = np.array(CONFS["l1"])
+    ttr, tdv = O.synth_table(10, 81, snr=1.0), O.synth_table(5, 82, snr=1.0)      # 10 < B: every epoch is ONE ragged batch
+    pop = mk_pop(ohp, [conf], dev)
+    pop.set_state_dict(0, O.init_params(conf, ohp, 3))
+    stats, status = pop.train(table(ttr, dev), table(tdv, dev), 2, etas_for(ohp, 10))
+    hist = []
+    want = O.train_candidate(conf, ohp, O.init_params(conf, ohp, 3), ttr, tdv, history=hist)
+    for e in range(2):
+        assert abs(stats["train_loss_sum"][0, e] / 10 - hist[e]["train_loss"]) < 1e-4
+        assert stats["dev_corrects"][0, e] == hist[e]["dev_corrects"]
+    assert best_dev_accuracy(stats[0], 5) == pytest.approx(want, abs=1e-12)
+    assert not status.any()
+    # zero train steps: parameters untouched, statistics zero
+    before = pop.get_params(0).clone()
+    stats, status = pop.train(table(ttr, dev), None, 1, etas_for(ohp, 10), max_steps=0)
+    assert torch.equal(before, pop.get_params(0)) and stats["train_loss_sum"].sum() == 0 and stats["train_corrects"].sum() == 0
+    pop.close()
