@@ -9,6 +9,8 @@ import numpy as np
 import torch
 import torch.optim as op
 
+from .. import avmnist_searchable as avmnist
+from .. import mmimdb_searchable as mmimdb
 from .. import ntu_searchable as ntu
 from ..engine import FeatureLoader
 from . import surrogate as surr
@@ -94,24 +96,33 @@ class ModelSearcher:
         return s_data
 
 
-class NTUSearcher(ModelSearcher):
-    """models/searchable.py:233-260 on feature tables: `tables` = {'train': FeatureTable ('trainexp' split),
-    'dev': FeatureTable}; both loaders shuffle like the reference's DataLoaders (:248)."""
+class _TableSearcher(ModelSearcher):
+    """A searcher over HIP-resident feature tables: `tables` = {'train': FeatureTable, 'dev': FeatureTable}.  Subclasses
+    name the searchable module (`model_type`) and the module providing train_sampled_models /
+    get_possible_layer_configurations (`methods_module`)."""
+    model_type = None
+    methods_module = None
+    shuffle = {"train": True, "dev": True}
 
     def __init__(self, args, device, tables):
         super().__init__(args)
         self.device = device
-        self.dataloaders = {x: FeatureLoader(tables[x], args.batchsize, shuffle=True) for x in ("train", "dev")}
+        self.dataloaders = {x: FeatureLoader(tables[x], args.batchsize, shuffle=self.shuffle[x]) for x in ("train", "dev")}
+
+    def _methods(self):
+        return {"train_sampled_fun": self.methods_module.train_sampled_models,
+                "get_layer_confs": self.methods_module.get_possible_layer_configurations}
 
     def search(self, surrogate_device="cpu"):
+        methods = self._methods()
+        if getattr(self.args, "randsearch", False):
+            return self._randsearch(self.model_type, self.dataloaders, methods, self.device)
         surrogate = surr.SimpleRecurrentSurrogate(100, 3, 100).to(surrogate_device)
         surrogate_dict = {"model": surrogate, "criterion": torch.nn.MSELoss()}
-        methods = {"train_sampled_fun": ntu.train_sampled_models,
-                   "get_layer_confs": ntu.get_possible_layer_configurations}
         # the (81k-parameter) surrogate lives where the caller wants it; the candidates train on self.device
         if str(surrogate_device) != str(self.device):
             return self._epnas_split(surrogate_dict, methods, self.device, surrogate_device)
-        return self._epnas(ntu.Searchable_Skeleton_Image_Net, surrogate_dict, self.dataloaders, methods, self.device)
+        return self._epnas(self.model_type, surrogate_dict, self.dataloaders, methods, self.device)
 
     def _epnas_split(self, surrogate_dict, methods, train_device, surrogate_device):
         """_epnas with the candidates on `train_device` and the (tiny) surrogate on `surrogate_device`."""
@@ -121,4 +132,26 @@ class NTUSearcher(ModelSearcher):
             return inner(confs, model_type, dataloaders, args, train_device, **kw)
 
         m = dict(methods, train_sampled_fun=train_on_gpu)
-        return self._epnas(ntu.Searchable_Skeleton_Image_Net, surrogate_dict, self.dataloaders, m, surrogate_device)
+        return self._epnas(self.model_type, surrogate_dict, self.dataloaders, m, surrogate_device)
+
+
+class NTUSearcher(_TableSearcher):
+    """models/searchable.py:233-260 on feature tables ('trainexp' / 'dev' splits); both loaders shuffle like the
+    reference's DataLoaders (:248)."""
+    model_type = ntu.Searchable_Skeleton_Image_Net
+    methods_module = ntu
+
+
+class AVMNISTSearcher(_TableSearcher):
+    """models/searchable.py:184-227 on feature tables (train = samples 0..49,999 shuffled, dev = 50,000..54,999 in
+    order); `args.randsearch` selects the random-search driver as in the reference."""
+    shuffle = {"train": True, "dev": False}
+    model_type = avmnist.Searchable_Audio_Image_Net
+    methods_module = avmnist
+
+
+class MMIMDBSearcher(_TableSearcher):
+    """The reference has no MM-IMDB searcher; this is the NTU one bound to the MM-IMDB searchable."""
+    shuffle = {"train": True, "dev": False}
+    model_type = mmimdb.Searchable_Text_Image_Net
+    methods_module = mmimdb

@@ -104,3 +104,29 @@ def test_mmimdb_mirror_population(dev):
     best = MM.train_mmimdb_track_f1(model, MM.WeightedCrossEntropyWithLogits(args.pos_weight), opt, sched, ld,
                                     {"train": 512, "dev": 256}, device=dev, num_epochs=3)
     assert 0.05 < best < 1.0 and not model.training
+
+
+def test_searchers_for_the_other_datasets(dev):
+    """MMIMDBSearcher / AVMNISTSearcher: the controller (_epnas, and _randsearch via args.randsearch) bound to the
+    MM-IMDB and AV-MNIST searchables, a short search on tiny tables."""
+    import mfas_amd as M
+    from mfas_amd.search import AVMNISTSearcher, MMIMDBSearcher
+    common = dict(vid_len=(8, 32), drpt=0.5, inner_representation_size=16, batchnorm=False, alphas=False, multitask=False,
+                  weightsharing=False, batchsize=16, eta_max=1e-3, eta_min=1e-6, Ti=1, Tm=2, use_dataparallel=False,
+                  verbose=False, epochs=1, search_iterations=2, max_progression_levels=2, num_samples=3, lr_surrogate=0.001,
+                  epochs_surrogate=5, initial_temperature=10.0, final_temperature=0.2, temperature_decay=4.0, engine_init="device")
+    np.random.seed(0)
+    torch.manual_seed(0)
+    args = SimpleNamespace(num_outputs=23, pos_weight=O.mm_pos_weight(23).tolist(), randsearch=False, **common)
+    tabs = {"train": mm_table(O.synth_table_mm(256, 61), dev, torch.float16), "dev": mm_table(O.synth_table_mm(128, 62), dev, torch.float16)}
+    data = MMIMDBSearcher(args, dev, tabs).search()
+    confs, f1s, _ = data.get_k_best(3)
+    assert len(confs) == 3 and all(0.0 < f <= 1.0 for f in f1s) and max(len(c) for c in confs) <= 2
+    # AV-MNIST, random-search driver
+    from tests.test_avmnist import tables as av_tables
+    ttr, tdv = av_tables()
+    args = SimpleNamespace(num_outputs=10, channels=3, randsearch=True, **common)
+    tabs = {"train": M.FeatureTable.from_numpy(ttr, dev), "dev": M.FeatureTable.from_numpy(tdv, dev)}
+    data = AVMNISTSearcher(args, dev, tabs).search()
+    confs, accs, _ = data.get_k_best(2)
+    assert len(confs) == 2 and all(0.0 <= a <= 1.0 for a in accs)
