@@ -194,8 +194,8 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         while (target * g.nrb < 64 * 16 && target < lds_max) target <<= 1;      // >= 64 tiles per workgroup
         while (target > 64 && tot_cols / target < 320.0) target >>= 1;           // ... but keep >= ~320 workgroups
         // R >= 128, measured on MI355X: 64-column chunks (finer, better-balanced workgroups) win once
-        // the chain is hidden under the other group's sweep (K >= 24); below that fewer partial chunks matter more
-        if (g.nrb >= 8) target = std::min(target, K >= 24 ? 64 : 256);   // (K >= 24 at R >= 128 <=> fused schedule)
+        // the chain is hidden under the other group's sweep (K >= 20); below that fewer partial chunks matter more
+        if (g.nrb >= 8) target = std::min(target, K >= 20 ? 64 : 256);   // (K >= 20 at R >= 128 <=> fused schedule)
     }
     target = std::max(16, (target / 16) * 16);
     p->cands.resize(K);
@@ -381,10 +381,11 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(hipMemcpy(p->d_cands, p->cands.data(), sizeof(CandDev) * K, hipMemcpyHostToDevice));
     CREATE_CHK(hipMemcpy(p->d_descs, p->descs.data(), sizeof(SegDesc) * p->descs.size(), hipMemcpyHostToDevice));
     {   // candidate groups: two halves balanced by work (descriptor columns), contiguous ranges
-        // Two groups (the chain of one runs under the sweep of the other).  Measured on MI355X: pays from ~24 candidates
-        // both at R=128 (a group's sweep then outlasts the ~50 us chain) and at R=16 (two half-size chain launches under
-        // the sweeps beat chain + sweep back to back: 124 vs 105 cand/s at 50 candidates).
-        int ngroups = K >= 24 ? 2 : 1;
+        // Two groups (the chain of one runs under the sweep of the other).  Measured on MI355X (cand/s, unfused vs fused):
+        // general chain, R=128: 16 candidates 104 vs 96, 20: 103 vs 110, 32: 119 vs 142 -> fused from 20;
+        // lean chain, R=16 (18 us, cheap enough to run as its own launch over all CUs): 32: 348 vs 307, 40: 361 vs 364,
+        // 50: 430 vs 475, 100: 582 vs 677, 200: 566 vs 600, 256: 630 vs 619, 512: 685 vs 641 -> fused only for 40 <= K < 224.
+        int ngroups = p->lean_chain ? ((K >= 40 && K < 224) ? 2 : 1) : (K >= 20 ? 2 : 1);
         if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
         int split = K;
         if (ngroups == 2) {
