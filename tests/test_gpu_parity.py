@@ -99,7 +99,9 @@ def check_state(pop, k, params, st, steps, lr=1e-3, tag=""):
             continue
         a = got[key].numpy()
         lim = 0.03 if a.size >= 1000 else 0.06          # small vectors: a handful of round-off-level elements
-        assert frac_bad(a, v, 1e-4, 2e-6 * steps) <= lim, (tag, key, frac_bad(a, v, 1e-4, 2e-6 * steps))
+        # BN running statistics are an EMA of batch moments: they inherit the weights' allowed 1e-4 deviations of every step
+        rtol = 1e-3 if key.endswith(("running_mean", "running_var")) else 1e-4
+        assert frac_bad(a, v, rtol, 2e-6 * steps) <= lim, (tag, key, frac_bad(a, v, rtol, 2e-6 * steps))
         assert np.abs(a - v).max() <= lr * steps, (tag, key)
     for key in st.m:
         # small vectors: a ReLU/dropout kink flipped by round-off moves one sample's share of a column sum (1/B), so a
