@@ -78,6 +78,9 @@ typedef struct mfas_population mfas_population; /* opaque; owns its device works
 
 const char* mfas_last_error(void);
 int mfas_version(void);
+/* "mfas-src-digest:<16 hex>": sha256 prefix of the sources (the csrc .hip / .hip.h files and this header) the loaded library
+ * was compiled from; __graft_entry__.build() rebuilds when it differs from the tree and tests assert it matches. */
+const char* mfas_source_digest(void);
 
 /* Replaces the model/optimizer construction half of train_sampled_models' population loop
  * (ntu_searchable.py:38-72): K candidates, confs[k][cell][{ske_tap, vis_tap, nonlinearity}],
@@ -140,6 +143,11 @@ int mfas_stream_probe(int64_t bytes_per_plane, int32_t iters, double* gb_per_s);
  * x / out are device pointers of dtype MFAS_DT_* ; f32 accumulation.  The step that builds an mfas_table from raw taps. */
 int mfas_global_pool(const void* x, int32_t dtype, int64_t rows, int64_t inner, void* out, int32_t out_dtype,
                      void* hip_stream);
+
+/* snapshot_best bookkeeping: a dev metric must EXCEED `threshold` to replace the kept parameters (best_acc = 0,
+ * train_searchable/ntu.py:18; best_f1 = init_f1, train_searchable/mmimdb.py:18).  Default 0.  If no epoch exceeds it the
+ * INITIAL parameters are restored, like the reference's best_model_sd (ntu.py:17,86). */
+int mfas_population_set_best_threshold(mfas_population* pop, double threshold);
 
 /* loss_mode 1: per-class positive weights of WeightedCrossEntropyWithLogits (HOST float[C]; default all 1). */
 int mfas_population_set_pos_weight(mfas_population* pop, const float* pos_weight);

@@ -71,6 +71,8 @@ def main(argv=None):
     torch.set_num_threads(max(1, args.controller_threads))
     torch.manual_seed(args.seed)          # every rank runs the same (seeded) controller
     np.random.seed(args.seed)
+    import random
+    random.seed(args.seed)                # tools.sample_k_configurations_directly draws depths with random.randint
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.feature_dtype]
     if args.synthetic:
         tables = {"train": M.FeatureTable.synthetic(args.synthetic[0], 1, device, dt),

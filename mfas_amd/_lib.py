@@ -48,6 +48,8 @@ def lib():
     P = C.c_void_p
     L.mfas_last_error.restype = C.c_char_p
     L.mfas_version.restype = C.c_int
+    L.mfas_source_digest.restype = C.c_char_p
+    L.mfas_population_set_best_threshold.argtypes = [P, C.c_double]
     L.mfas_population_create.argtypes = [C.POINTER(mfas_hyper), P, P, P, C.c_int32, C.c_int32, P,
                                          C.c_int32, C.POINTER(P)]
     L.mfas_population_destroy.argtypes = [P]
@@ -72,7 +74,8 @@ def lib():
 EXPORTS = ["mfas_last_error", "mfas_version", "mfas_population_create", "mfas_population_destroy",
            "mfas_population_param_count", "mfas_population_set_params", "mfas_population_get_params",
            "mfas_population_init", "mfas_population_train", "mfas_population_forward",
-           "mfas_population_sweep_profile", "mfas_population_set_profiling", "mfas_population_set_pos_weight", "mfas_global_pool", "mfas_stream_probe"]
+           "mfas_population_sweep_profile", "mfas_population_set_profiling", "mfas_population_set_pos_weight", "mfas_global_pool", "mfas_stream_probe", "mfas_source_digest",
+           "mfas_population_set_best_threshold"]
 
 
 def check(rc):

@@ -196,7 +196,9 @@ __device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, float* lg_l,
     }
     const float lse = mx + logf(se);
     if (sub == 0) {
-        red_l[b] = ok ? -(row[lab] - lse) : 0.f;
+        float ls = ok ? -(row[lab] - lse) : 0.f;
+        if (vl) ls = (ls + row_ce(vl, C, lab)) + row_ce(sl, C, lab);   // multitask 3-term loss (ntu.py:60-61); constants w.r.t. the central parameters
+        red_l[b] = ls;
         red_l[Bp + b] = (ok && bi == lab) ? 1.f : 0.f;
     }
 #pragma unroll

@@ -126,6 +126,16 @@ __device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, con
     w = w - c.ss * (m / denom);
 }
 
+// cross entropy of one row of C logits against `lab` (one lane, serial): the constant unimodal terms of the multitask
+// loss, criteria[1](output[1], label) + criteria[2](output[2], label) (train_searchable/ntu.py:60-61)
+__device__ __forceinline__ float row_ce(const float* x, int C, int lab) {
+    float mx = x[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+    return -(x[lab] - mx - logf(se));
+}
+
 // sum over the 4 lane groups that share (lane & 15): column reduction of an MFMA D block
 __device__ __forceinline__ float colsum(float x) {
     x += __shfl_xor(x, 16);

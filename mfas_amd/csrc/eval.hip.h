@@ -51,6 +51,9 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
             sgS = sg;
             sgV = 1.0f - sg;
         }
+        // sigma(alpha) rounds to exactly 1 for alpha >~ 17: the V modality then contributes v * 0 (aux_models.py:103-111);
+        // (accS * sgS / sgV + accV) * sgV would be inf * 0, so that case keeps accS * sgS and skips the V columns
+        const bool vdead = g.alphas && !(sgV > 0.0f);
         f32x4 acc[NRBW][MBE];
 #pragma unroll
         for (int j = 0; j < NRBW; ++j)
@@ -65,7 +68,8 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
 #pragma unroll
                 for (int j = 0; j < NRBW; ++j)
 #pragma unroll
-                    for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * (sgS / sgV);
+                    for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * (vdead ? sgS : sgS / sgV);
+                if (vdead) break;
             }
             for (int c0 = 0; c0 < cols; c0 += EVAL_CE) {
                 const int nc = min(EVAL_CE, cols - c0);
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
 #pragma unroll
             for (int j = 0; j < NRBW; ++j)
 #pragma unroll
-                for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * sgV;
+                for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * (vdead ? 1.0f : sgV);
         }
         if (i > 0) {
 #pragma unroll
@@ -242,6 +246,8 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
                     const float t = (row[c] + vl[c]) + sl[c];
                     if (t > bv) { bv = t; best = c; }
                 }
+                // 3-term multitask loss (train_searchable/ntu.py:60-61): + CE(visual logits) + CE(skeleton logits)
+                loss = (loss + row_ce(vl, C, lab)) + row_ce(sl, C, lab);
             } else {
                 bv = row[0];
                 for (int c = 1; c < C; ++c)

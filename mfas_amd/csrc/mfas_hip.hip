@@ -116,12 +116,18 @@ struct mfas_population {
     int64_t prof_launches = 0;
     double prof_ms = 0.0, bytes_per_launch = 0.0, prof_bytes = 0.0;
     double alg_state_bytes = 0.0, alg_feat_elems = 0.0;
+    double best_threshold = 0.0;    // snapshot_best: a dev metric must exceed this to count (init_f1, mmimdb.py:18; 0 for NTU)
 };
 
 static inline int ceil16(int x) { return (x + 15) & ~15; }
 
 extern "C" const char* mfas_last_error(void) { return g_err.c_str(); }
-extern "C" int mfas_version(void) { return 100; }
+extern "C" int mfas_version(void) { return 200; }
+#ifndef MFAS_SRC_DIGEST
+#define MFAS_SRC_DIGEST "unknown"
+#endif
+// sha256 (first 16 hex digits) of the sources this library was built from, baked in by __graft_entry__.build()
+extern "C" const char* mfas_source_digest(void) { return "mfas-src-digest:" MFAS_SRC_DIGEST; }
 
 static int pick_chunk(int cols_p, int target) {
     int best = 16;
@@ -598,7 +604,12 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     // every call is a freshly built torch.optim.Adam (ntu_searchable.py:65; main_found_ntu.py:108,128): zero exp_avg / exp_avg_sq
     HIPCHK(hipMemsetAsync(p->plane + p->plane_stride, 0, sizeof(float) * 2 * (size_t)p->plane_stride, p->stream));
     if (snapshot_best && !p->best) HIPCHK(hipMalloc(&p->best, sizeof(float) * (size_t)p->plane_stride));
-    std::vector<double> best_acc(K, 0.0);
+    // best_model_sd starts as a copy of the INITIAL state_dict (train_searchable/ntu.py:17) and is what the model is
+    // left with if no epoch's dev metric beats the starting threshold (0 for accuracy, init_f1 for F1)
+    if (snapshot_best && max_steps < 0)
+        HIPCHK(hipMemcpyAsync(p->best, p->plane, sizeof(float) * (size_t)p->plane_stride, hipMemcpyDeviceToDevice, p->stream));
+    std::vector<double> best_acc(K, p->best_threshold);
+    const double metric_scale = g.loss_mode == 1 ? 1.0 / 4294967296.0 : 1.0;   // F1 sums are 32.32 fixed point
     std::vector<DevStats> hstats((size_t)K * epochs);
 
     const mfas_hyper& hp = p->hp;
@@ -720,8 +731,8 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
                 HIPCHK(hipMemcpyAsync(hstats.data(), p->d_stats, sizeof(DevStats) * K * epochs, hipMemcpyDeviceToHost, p->stream));
                 HIPCHK(hipStreamSynchronize(p->stream));
                 for (int k = 0; k < K; ++k) {
-                    const double acc = (double)hstats[(size_t)k * epochs + ep].dev_corr / (double)dev->N;
-                    if (acc > best_acc[k]) {   // strict >, from 0 (train_searchable/ntu.py:82)
+                    const double acc = (double)hstats[(size_t)k * epochs + ep].dev_corr * metric_scale / (double)dev->N;
+                    if (acc > best_acc[k]) {   // strict >, from 0 (train_searchable/ntu.py:82) / init_f1 (mmimdb.py:18)
                         best_acc[k] = acc;
                         HIPCHK(hipMemcpyAsync(p->best + p->cand_plane_base[k], p->plane + p->cand_plane_base[k],
                                               sizeof(float) * p->cand_plane_size[k], hipMemcpyDeviceToDevice, p->stream));
@@ -730,11 +741,12 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             }
         }
     }
-    if (snapshot_best && do_dev) {
-        for (int k = 0; k < K; ++k)
-            if (best_acc[k] > 0.0)
-                HIPCHK(hipMemcpyAsync(p->plane + p->cand_plane_base[k], p->best + p->cand_plane_base[k],
-                                      sizeof(float) * p->cand_plane_size[k], hipMemcpyDeviceToDevice, p->stream));
+    if (snapshot_best && do_dev) {   // model.load_state_dict(best_model_sd) (:86), unconditionally
+        HIPCHK(hipMemcpyAsync(p->plane, p->best, sizeof(float) * (size_t)p->plane_stride, hipMemcpyDeviceToDevice, p->stream));
+        // the transposed OUT / HEAD tiles the backward chain reads still hold the last epoch's weights: re-derive them
+        PackArgs pa = pack_args(p, PK_WT, 0, nullptr);
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)p->descs.size()), dim3(256), 0, p->stream, pa);
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(hstats.data(), p->d_stats, sizeof(DevStats) * K * epochs, hipMemcpyDeviceToHost, p->stream));
     std::vector<int32_t> hstatus(K, 0);
@@ -834,6 +846,12 @@ extern "C" int mfas_population_set_pos_weight(mfas_population* p, const float* w
     if (!p || !w) return fail(MFAS_EINVAL, "null");
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipMemcpy(p->d_posw, w, sizeof(float) * p->g.C, hipMemcpyHostToDevice));
+    return MFAS_OK;
+}
+
+extern "C" int mfas_population_set_best_threshold(mfas_population* p, double threshold) {
+    if (!p) return fail(MFAS_EINVAL, "null");
+    p->best_threshold = threshold;
     return MFAS_OK;
 }
 

@@ -7,6 +7,7 @@
 #define PK_SET 0
 #define PK_GET 1
 #define PK_INIT 2
+#define PK_WT 3     // re-derive the transposed OUT / HEAD tiles (wt arena) from plane 0
 
 struct PackArgs {
     const SegDesc* desc;
@@ -34,6 +35,7 @@ __global__ void __launch_bounds__(256) k_pack(const PackArgs a) {
     float* Wp = a.plane + d.w_off;
     uint32_t h0 = 0;
     if (a.mode == PK_INIT) h0 = d_hash_h0(d_param_seed(a.seeds[d.cand], d.init_seed));
+    if (a.mode == PK_WT && d.wt_off < 0) return;
     for (int e = threadIdx.x; e < d.rows_p * d.cc; e += 256) {
         const int tile = e >> 8, within = e & 255, lane = within >> 2, q = within & 3;
         const int rb = tile / nkb, kb = tile - rb * nkb;
@@ -46,13 +48,17 @@ __global__ void __launch_bounds__(256) k_pack(const PackArgs a) {
             continue;
         }
         float val = 0.f;
-        if (ok) {
-            if (a.mode == PK_SET) val = a.flat[d.src_off + fidx];
-            else val = (d_hash_u01(h0, (uint32_t)fidx) * 2.0f - 1.0f) * d.init_bound;
+        if (a.mode == PK_WT) {
+            val = Wp[e];
+        } else {
+            if (ok) {
+                if (a.mode == PK_SET) val = a.flat[d.src_off + fidx];
+                else val = (d_hash_u01(h0, (uint32_t)fidx) * 2.0f - 1.0f) * d.init_bound;
+            }
+            Wp[e] = val;
+            Wp[a.plane_stride + e] = 0.f;
+            Wp[2 * a.plane_stride + e] = 0.f;
         }
-        Wp[e] = val;
-        Wp[a.plane_stride + e] = 0.f;
-        Wp[2 * a.plane_stride + e] = 0.f;
         if (d.wt_off >= 0) {
             const int l15 = lane & 15, lg = lane >> 4;
             float* T = a.wt + d.wt_off + ((int64_t)((d.k0 >> 4) + kb) * nrb + rb) * 256;

@@ -263,6 +263,13 @@ class Population:
             cf[k, :len(c)] = c
             nc[k] = len(c)
         ds = None if drop_seeds is None else np.asarray(drop_seeds, np.uint32)
+        self._used_taps = {}        # tap name -> (declared width, first configuration / cell that selects it)
+        for k, c in enumerate(self.confs):
+            for i, (sj, vj, _) in enumerate(c):
+                if 0 <= sj < len(hp.s_sizes):
+                    self._used_taps.setdefault(f"s{int(sj)}", (int(hp.s_sizes[int(sj)]), k, i))
+                if 0 <= vj < len(hp.v_sizes):
+                    self._used_taps.setdefault(f"v{int(vj)}", (int(hp.v_sizes[int(vj)]), k, i))
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         with torch.cuda.device(idx):
@@ -283,6 +290,18 @@ class Population:
             self.close()
         except Exception:
             pass
+
+    def _check_table(self, table: "FeatureTable"):
+        """Every tap a configuration of this population selects must be present in the table with exactly the width the
+        hyper-parameters declare (the kernels index rows with stride ceil16(width)); the reference raises a Linear shape
+        error in that case (ntu_searchable.py:236-240)."""
+        for name, (want, k, i) in self._used_taps.items():
+            have = table.widths.get(name)
+            if have is None:
+                raise ValueError(f"configuration {k} cell {i} selects tap {name}, which the feature table does not hold")
+            if have != want:
+                raise ValueError(f"tap {name}: the feature table is {have} wide but the hyper-parameters declare {want} "
+                                 "(mat1 and mat2 shapes cannot be multiplied in the reference)")
 
     def param_count(self, k: int) -> int:
         n = self.lib.mfas_population_param_count(self._h, k)
@@ -339,6 +358,9 @@ class Population:
             for t in (train, dev):
                 if t is not None:
                     t.check_labels(self.hp.C)
+        for t in (train, dev):
+            if t is not None:
+                self._check_table(t)
         stats = np.zeros((self.K, epochs), dtype=[("train_loss_sum", "f8"), ("dev_loss_sum", "f8"),
                                                   ("train_corrects", "i8"), ("dev_corrects", "i8")])
         status = np.zeros(self.K, np.int32)
@@ -354,6 +376,7 @@ class Population:
     def forward(self, k: int, table: FeatureTable, row0: int = 0, nrows: Optional[int] = None,
                 count: bool = False):
         nrows = len(table) - row0 if nrows is None else nrows
+        self._check_table(table)
         logits = torch.empty((nrows, self.hp.C), dtype=torch.float32, device=self.device)
         corr = C.c_int64(0)
         tc = table.to_c()
@@ -367,6 +390,10 @@ class Population:
         w = np.ascontiguousarray(np.asarray(w, np.float32))
         assert w.size == self.hp.C
         _lib.check(self.lib.mfas_population_set_pos_weight(self._h, w.ctypes.data))
+
+    def set_best_threshold(self, threshold: float):
+        """snapshot_best: the dev metric an epoch must EXCEED to replace the kept parameters (init_f1; 0 for accuracy)."""
+        _lib.check(self.lib.mfas_population_set_best_threshold(self._h, float(threshold)))
 
     def set_profiling(self, on: bool):
         _lib.check(self.lib.mfas_population_set_profiling(self._h, int(on)))

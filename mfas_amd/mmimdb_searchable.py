@@ -89,6 +89,7 @@ def train_mmimdb_track_f1(model, criterion, optimizer, scheduler, dataloaders, d
     pop.set_pos_weight(getattr(criterion, "w", np.ones(hp.C, np.float32)))
     pop.set_params(0, model.flat_params())
     order = make_order(N_tr, num_epochs, train_l.shuffle, seed + 1, device)
+    pop.set_best_threshold(float(init_f1))      # best_f1 = init_f1 (mmimdb.py:18): the kept weights follow the same threshold
     stats, status = pop.train(train_l.table, dev_l.table, num_epochs, etas, order=order, snapshot_best=True)
     if verbose:
         for e in range(num_epochs):

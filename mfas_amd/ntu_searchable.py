@@ -308,7 +308,7 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
     nb = -(-N_tr // B)
     num_batches_per_epoch = N_tr / B              # float, ntu_searchable.py:30
 
-    seed_base = popmod.broadcast_seed(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), device)
+    seed_base = popmod.broadcast_seed(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), device, confs)
     if getattr(args, "weightsharing", False):
         if hp.loss_mode != 0:
             raise NotImplementedError("weight sharing is wired for the single-label (NTU) searchable only")
@@ -317,7 +317,7 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
 
     rank, world = popmod.dist_info()
     costs = [popmod.candidate_cost(confs[i], hp.R, hp.s_sizes, hp.v_sizes, hp.C) for i in wanted]
-    owner = popmod.assign(costs, world)
+    owner, cap = popmod.shard(costs, world)
     mine = [i for i, o in zip(wanted, owner) if o == rank]
 
     local_acc, models = [], {}
@@ -375,7 +375,7 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
                 m.train(False)
                 models[i] = m
         pop.close()
-    accs_all = popmod.gather_accuracies(mine, local_acc, K, device)
+    accs_all = popmod.gather_accuracies(mine, local_acc, K, device, cap=cap)
     real_accuracies = [accs_all[i] for i in wanted]
     if return_model:
         # models live on the rank that trained them; other ranks get None placeholders

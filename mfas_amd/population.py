@@ -21,13 +21,21 @@ def dist_info():
     return 0, 1
 
 
+# One train step of a candidate costs ~24*P_i bytes of streaming PLUS a serial chain of L_i cells that no
+# amount of bandwidth shortens; in the small-population regime the search runs in (6-8 candidates per GPU) the second
+# term dominates.  Measured on MI355X: ~4 us per cell of chain latency ~ 20 KB of streaming at 5 TB/s per
+# cell, i.e. ~850 parameters' worth of bytes per cell at R=16 and ~6,800 at R=128 -> LATENCY_PARAMS_PER_CELL * R/16.
+LATENCY_PARAMS_PER_CELL = 850
+
+
 def candidate_cost(conf, R: int, s_sizes, v_sizes, C: int = 60) -> int:
-    """Parameter count P_i: per-step work of a candidate is ~24*P_i bytes."""
+    """Cost of one train step in parameter units: P_i (bandwidth term) + a latency term proportional to the depth L_i."""
     conf = np.asarray(conf).reshape(-1, 3)
     p = 0
     for i, (s, v, _) in enumerate(conf):
         p += R * (s_sizes[int(s)] + v_sizes[int(v)] + (R if i else 0)) + R
-    return int(p + R * C + C)
+    lat = len(conf) * LATENCY_PARAMS_PER_CELL * max(1, R // 16)
+    return int(p + R * C + C + lat)
 
 
 def assign(costs: Sequence[int], world: int) -> List[int]:
@@ -42,9 +50,12 @@ def assign(costs: Sequence[int], world: int) -> List[int]:
     return owner
 
 
-def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: int, device=None) -> List[float]:
-    """All ranks end up with the K accuracies in input order.  One all_gather of ceil(K/W) doubles
-    (+ their indices) per call — latency-bound, a few hundred bytes."""
+def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: int, device=None,
+                      cap: int | None = None) -> List[float]:
+    """All ranks end up with the K accuracies in input order: ONE all_gather of `cap` (index, accuracy) pairs per rank
+    and one device-to-host copy — latency-bound, a few hundred bytes.  `cap` (the largest per-rank share) is known to
+    every rank from assign(); without it ceil(K/W)+1 is only an upper bound for round-robin-like assignments, so
+    callers that shard with assign() pass it."""
     rank, world = dist_info()
     if world == 1:
         out = [0.0] * K
@@ -53,35 +64,60 @@ def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: i
         return out
     backend = dist.get_backend()
     dev = torch.device("cpu") if backend == "gloo" else (device or torch.device("cuda", torch.cuda.current_device()))
-    cap = -(-K // world) + 1
-    cap = max(cap, max(len(local_idx), 1))
-    capt = torch.tensor([cap], dtype=torch.int64, device=dev)
-    dist.all_reduce(capt, op=dist.ReduceOp.MAX)
-    cap = int(capt.item())
-    buf = torch.full((cap, 2), -1.0, dtype=torch.float64, device=dev)
+    if cap is None:
+        cap = K
+    assert len(local_idx) <= cap, (len(local_idx), cap)
+    host = np.full((cap, 2), -1.0, np.float64)
     for j, (i, a) in enumerate(zip(local_idx, local_acc)):
-        buf[j, 0] = float(i)
-        buf[j, 1] = float(a)
-    bufs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(bufs, buf)
+        host[j, 0] = float(i)
+        host[j, 1] = float(a)
+    buf = torch.from_numpy(host).to(dev)
+    allb = torch.empty((world * cap, 2), dtype=torch.float64, device=dev)   # rank-major concatenation
+    dist.all_gather_into_tensor(allb, buf)
     out = [float("nan")] * K
-    for b in bufs:
-        b = b.cpu().numpy()
-        for i, a in b:
-            if i >= 0:
-                out[int(i)] = float(a)
+    for i, a in allb.cpu().numpy():
+        if i >= 0:
+            out[int(i)] = float(a)
     assert not any(np.isnan(out)), "a candidate was trained by no rank"
     return out
 
 
-def broadcast_seed(seed: int, device=None) -> int:
-    """Rank 0's seed to everyone (so that init / shuffle / dropout streams do not depend on the
-    world size)."""
+def shard(costs: Sequence[int], world: int):
+    """owner per candidate (assign) and the largest per-rank share (the all_gather's row count), both computed locally
+    and identically on every rank."""
+    owner = assign(costs, world)
+    counts = [0] * world
+    for o in owner:
+        counts[o] += 1
+    return owner, max(counts + [1])
+
+
+def conf_digest(confs) -> int:
+    """Order-sensitive 62-bit digest of a list of configurations (checked across ranks before sharding)."""
+    import hashlib
+    h = hashlib.sha256()
+    for c in confs:
+        a = np.ascontiguousarray(np.asarray(c, np.int64).reshape(-1, 3))
+        h.update(np.int64(len(a)).tobytes())
+        h.update(a.tobytes())
+    return int.from_bytes(h.digest()[:8], "little") >> 2
+
+
+def broadcast_seed(seed: int, device=None, confs=None) -> int:
+    """Rank 0's seed to everyone (so that init / shuffle / dropout streams do not depend on the world size).  The same
+    broadcast carries rank 0's digest of the configuration list: every rank runs the (seeded) controller redundantly
+    (SURVEY §8e), and a rank whose sampler drifted (an unseeded RNG, a float that rounded differently) must not
+    silently train a different population — it raises instead."""
     rank, world = dist_info()
     if world == 1:
         return int(seed)
     backend = dist.get_backend()
     dev = torch.device("cpu") if backend == "gloo" else (device or torch.device("cuda", torch.cuda.current_device()))
-    t = torch.tensor([int(seed)], dtype=torch.int64, device=dev)
+    mine = conf_digest(confs) if confs is not None else 0
+    t = torch.tensor([int(seed), mine], dtype=torch.int64, device=dev)
     dist.broadcast(t, src=0)
-    return int(t.item())
+    seed0, dig0 = (int(x) for x in t.cpu().tolist())
+    if confs is not None and dig0 != mine:
+        raise RuntimeError(f"rank {rank}: sampled_configurations differ from rank 0's (digest {mine:#x} vs {dig0:#x}); "
+                           "the controller must be seeded identically on every rank (random / numpy / torch)")
+    return seed0

@@ -660,17 +660,12 @@ def g13():
 
 
 # ------------------------------------------------------------------ G14 full-size reproducibility envelope
-def g14():
-    """Same full-size deterministic recipe as G13 (3 epochs, 4 BLAS threads), started from NT=16 round-off-sized
-    perturbations of the initial weight matrices (O.perturb_params(init_params(conf, hp, 77), trial), trial 0 = exact).
-    The oracle and the engine are run from the same starts in tests/test_fullsize.py: the three ensembles must agree in
-    distribution (means within the standard error), which is the strongest statement chaos allows at this size."""
-    ttr = dict(O.synth_table(10000, 1, snr=0.15, quant="bf16"), vlogit=np.zeros((10000, 60), np.float32), slogit=np.zeros((10000, 60), np.float32))
-    tdv = dict(O.synth_table(5600, 2, snr=0.15, quant="bf16"), vlogit=np.zeros((5600, 60), np.float32), slogit=np.zeros((5600, 60), np.float32))
+def _envelope(name, snr, NT):
+    ttr = dict(O.synth_table(10000, 1, snr=snr, quant="bf16"), vlogit=np.zeros((10000, 60), np.float32), slogit=np.zeros((10000, 60), np.float32))
+    tdv = dict(O.synth_table(5600, 2, snr=snr, quant="bf16"), vlogit=np.zeros((5600, 60), np.float32), slogit=np.zeros((5600, 60), np.float32))
     conf = np.array(CONFS["c4"])
     args = mkargs(inner_representation_size=128, batchnorm=True, drpt=0.0, epochs=3, batchsize=16)
     torch.set_num_threads(4)
-    NT = 16
     hists, bests = [], []
     for trial in range(NT):
         class CapP(Capture):
@@ -689,12 +684,148 @@ def g14():
         h = parse_hist(buf.getvalue())
         hists.append(h)
         bests.append(float(accs[0]))
-        print("g14 trial", trial, bests[-1], h[:, 1:].ravel(), flush=True)
+        print(name, "trial", trial, bests[-1], h[:, 1:].ravel(), flush=True)
     # hist[trial][2*epoch + phase] = (phase, loss, acc)
-    save("g14_fullsize_envelope.npz", hist=np.array(hists), best_acc=np.array(bests), rel=np.array([1e-7]))
+    save(name, hist=np.array(hists), best_acc=np.array(bests), rel=np.array([1e-7]), snr=np.array([snr]))
+
+
+def g14():
+    """Same full-size deterministic recipe as G13 (3 epochs, 4 BLAS threads), started from NT=64 round-off-sized
+    perturbations of the initial weight matrices (O.perturb_params(init_params(conf, hp, 77), trial), trial 0 = exact).
+    The oracle and the engine are run from the same starts in tests/test_fullsize.py: the three ensembles must agree in
+    distribution (means within the standard error), which is the strongest statement chaos allows at this size."""
+    _envelope("g14_fullsize_envelope.npz", 0.15, int(os.environ.get("G14_NT", "64")))
+
+
+def g14m():
+    """G14 in the SENSITIVE regime (mid-range accuracy): same recipe at snr = G14M_SNR (default 0.08)."""
+    _envelope("g14m_fullsize_midrange.npz", float(os.environ.get("G14M_SNR", "0.08")), int(os.environ.get("G14_NT", "64")))
+
+
+# ------------------------------------------------------------------ G15 the bench workload itself (stochastic, E=10)
+class ShuffleLoader(ListLoader):
+    """DataLoader(shuffle=True) stand-in (models/searchable.py:248): a fresh torch.randperm per epoch."""
+
+    def __iter__(self):
+        N = len(self.dataset)
+        perm = torch.randperm(N)
+        for i in range(0, N, self.B):
+            sl = perm[i:i + self.B]
+            rgb = D({k: self.t[k][sl] for k in ("v0", "v1", "v2", "v3", "vlogit")})
+            ske = D({k: self.t[k][sl] for k in ("s0", "s1", "s2", "s3", "slogit")})
+            yield {"rgb": rgb, "ske": ske, "label": self.t["label"][sl]}
+
+
+def g15():
+    """BASELINE configs[1] exactly as bench.py runs it, through the unchanged reference: conf 4, R=128, --batchnorm,
+    drpt 0.5, B=16, shuffled train order, E=10, N_train=10,000, N_dev=5,600, bf16-rounded taps
+    (synth_table(N, seed, snr=G15_SNR, quant='bf16')), params = init_params(conf, hp, 3000 + 10*seed),
+    torch.manual_seed(300 + seed) for the reference's dropout / shuffle streams; NS seeds.
+    The statistic: best dev accuracy (and the per-epoch dev accuracies) over seeds."""
+    snr = float(os.environ.get("G15_SNR", "0.06"))
+    NS = int(os.environ.get("G15_NS", "16"))
+    E = int(os.environ.get("G15_E", "10"))
+    ttr = dict(O.synth_table(10000, 1, snr=snr, quant="bf16"), vlogit=np.zeros((10000, 60), np.float32), slogit=np.zeros((10000, 60), np.float32))
+    tdv = dict(O.synth_table(5600, 2, snr=snr, quant="bf16"), vlogit=np.zeros((5600, 60), np.float32), slogit=np.zeros((5600, 60), np.float32))
+    conf = np.array(CONFS["c4"])
+    args = mkargs(inner_representation_size=128, batchnorm=True, drpt=0.5, epochs=E, batchsize=16)
+    torch.set_num_threads(int(os.environ.get("G15_THREADS", "4")))
+    loaders = {"train": ShuffleLoader(ttr, 16), "dev": ListLoader(tdv, 16)}
+    bests, hists = [], []
+    for seed in range(NS):
+        torch.manual_seed(300 + seed)
+        accs, _, hist = run_tsm([conf], args, loaders, 3000 + 10 * seed)
+        bests.append(accs[0])
+        hists.append(hist)
+        print("g15 seed", seed, accs[0], hist[1::2, 2], flush=True)
+    if os.environ.get("G15_PROBE"):
+        return
+    save("g15_bench_workload.npz", best_acc=np.array(bests), hist=np.array(hists),
+         meta=np.array([10000, 5600, snr, 128, 16, E, 1, 0.5]))   # N,Ndev,snr,R,B,epochs,bn,drpt
+
+
+# ------------------------------------------------------------------ G16 weight sharing (next#4)
+def g16():
+    """--weightsharing through the unchanged train_sampled_models (ntu_searchable.py:74-75,91-92,123-174): 4 confs where
+    conf 1 and conf 3 re-use cell "0.L_640_16.A_relu" of conf 0 and conf 2 re-uses nothing at index 0 (other activation)
+    but shares cell 1's key with conf 3.  Deterministic mode (drpt=0 + BN, unshuffled), R=16, B=16, 3 epochs;
+    train = synth_table(256, 41, snr=1.5), dev = synth_table(128, 42, snr=1.5); params of candidate i = init_params(seed 50+i)
+    (then overwritten by the shared cells, as in the reference).  Stored: accuracies, per-epoch history, the published
+    state_dict after every candidate, every candidate's final central parameters."""
+    out = {}
+    ttr, tdv = table(256, 41, with_logits=False, snr=1.5), table(128, 42, with_logits=False, snr=1.5)
+    confs = [[[0, 0, 0]],
+             [[0, 0, 0], [1, 1, 1]],
+             [[0, 0, 1], [1, 1, 1]],
+             [[0, 0, 0], [1, 1, 1], [2, 0, 0]]]
+    args = mkargs(inner_representation_size=16, batchnorm=True, drpt=0.0, epochs=3, batchsize=16, weightsharing=True)
+    cap = Capture(50)
+    sd = {}
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        accs = ntu.train_sampled_models([np.array(c) for c in confs], cap, {"train": ListLoader(ttr, 16), "dev": ListLoader(tdv, 16)},
+                                        args, "cpu", state_dict=sd)
+    text = buf.getvalue()
+    out["accs"] = np.array([float(a) for a in accs])
+    out["hist"] = parse_hist(text)
+    out["events"] = np.array(re.findall(r"(Creating|Updating|Loaded) shared weight with ID: (\S+)", text))
+    for name, lsd in sd.items():
+        for k, v in lsd.items():
+            if "num_batches" not in k:
+                put(out, "shared/" + name + "/" + k, v.detach().cpu().numpy())
+    for i, m in enumerate(cap.models):
+        for k, v in central_sd(m).items():
+            if "num_batches" not in k:
+                put(out, f"final{i}/" + k, v)
+    for i, c in enumerate(confs):
+        out[f"conf{i}"] = np.array(c)
+    save("g16_weightsharing.npz", **out)
+
+
+# ------------------------------------------------------------------ G17 main_found_ntu two-phase schedule (next#4)
+def g17():
+    """main_found_ntu.train_model (:94-157) unchanged, on stub backbones: phase 1 = 1 epoch, Adam(lr=eta_max/10) whose lr the
+    scheduler overwrites from the first step; phase 2 = args.epochs epochs with a fresh Adam + scheduler over
+    rmode.parameters() (== the central parameters here: the stubs own none), both with multitask (3-term loss, summed-
+    logit argmax); then test_ntu_track_acc.  Deterministic mode (drpt=0 + BN), conf 0, R=16, B=16, 3 epochs;
+    train/dev/test = synth_table(256/128/96, 61/62/63, snr=1.0, with_logits); params = init_params(conf, hp, 70)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_main_found", "/root/reference/main_found_ntu.py")
+    for name in ("torchvision", "torchvision.transforms", "torchvision.datasets", "cv2"):
+        sys.modules.setdefault(name, type(sys)(name))
+    import types
+    if "models.aux" not in sys.modules:     # D6: broken intra-repo import in datasets / mains
+        pass
+    mf = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mf)
+    except Exception as e:                   # the script's own imports (datasets.ntu -> cv2 ...) may fail: restate nothing,
+        raise RuntimeError(f"main_found_ntu.py does not import here: {e!r}")
+    out = {}
+    ttr, tdv, tte = table(256, 61, snr=1.0), table(128, 62, snr=1.0), table(96, 63, snr=1.0)
+    for mt in (True, False):
+        conf = np.array(CONFS["c0"])
+        args = mkargs(inner_representation_size=16, batchnorm=True, drpt=0.0, epochs=3, batchsize=16, multitask=mt,
+                      test_cp="", verbose=True)
+        rmode = ntu.Searchable_Skeleton_Image_Net(args, conf)
+        load_det(rmode, conf, args, 70)
+        loaders = {"train": ListLoader(ttr, 16), "dev": ListLoader(tdv, 16), "test": ListLoader(tte, 16)}
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            acc = mf.train_model(rmode, conf, loaders, args, "cpu")
+        text = buf.getvalue()
+        pre = "mt/" if mt else "st/"
+        out[pre + "test_acc"] = np.array(float(acc))
+        out[pre + "hist"] = parse_hist(text)
+        out[pre + "interm"] = np.array(float(re.search(r"Intermediate val accuracy: (?:tensor\()?([0-9.]+)", text).group(1)))
+        out[pre + "final"] = np.array(float(re.search(r"Final val accuracy: (?:tensor\()?([0-9.]+)", text).group(1)))
+        for k, v in central_sd(rmode).items():
+            if "num_batches" not in k:
+                put(out, pre + "final/" + k, v)
+    save("g17_found_twophase.npz", **out)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g14m", "g15", "g16", "g17"]
     for w in which:
         globals()[w]()

@@ -153,13 +153,17 @@ def test_assignment_is_balanced_and_deterministic():
     rng = np.random.default_rng(0)
     confs = [rng.integers(0, 4, (rng.integers(1, 5), 3)) % [4, 4, 2] for _ in range(50)]
     costs = [P.candidate_cost(c, 16, O.S_SIZES, O.V_SIZES) for c in confs]
-    assert P.candidate_cost(CONFS["c4"], 16, O.S_SIZES, O.V_SIZES) == 124732
+    # P_i (124,732 for conf 4 at R=16) + the depth-proportional latency term
+    assert P.candidate_cost(CONFS["c4"], 16, O.S_SIZES, O.V_SIZES) == 124732 + 4 * P.LATENCY_PARAMS_PER_CELL
+    assert P.candidate_cost(CONFS["c4"], 128, O.S_SIZES, O.V_SIZES) == 1040444 + 4 * 8 * P.LATENCY_PARAMS_PER_CELL   # (no BN affine in the cost)
     for world in (1, 2, 4, 8):
         own = P.assign(costs, world)
         assert own == P.assign(costs, world)
         loads = [sum(c for c, o in zip(costs, own) if o == r) for r in range(world)]
         assert max(loads) - min(loads) <= max(costs)
         assert sorted(set(own)) == list(range(world))
+        own2, cap = P.shard(costs, world)
+        assert own2 == own and cap == max(own.count(r) for r in range(world))
 
 
 WORKER = r"""
@@ -171,13 +175,22 @@ dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.
 rank, world = P.dist_info()
 K = 7
 costs = [100, 30, 70, 10, 90, 50, 20]
-own = P.assign(costs, world)
+own, cap = P.shard(costs, world)
 mine = [i for i in range(K) if own[i] == rank]
 acc = [0.01 * (i + 1) for i in mine]          # stand-in for the engine's result of candidate i
-out = P.gather_accuracies(mine, acc, K)
+out = P.gather_accuracies(mine, acc, K, cap=cap)     # ONE all_gather, cap known locally
 assert np.allclose(out, [0.01 * (i + 1) for i in range(K)]), out
-seed = P.broadcast_seed(1234 + rank)
+confs = [np.array([[i % 4, (i + 1) % 4, i % 2]]) for i in range(K)]
+seed = P.broadcast_seed(1234 + rank, confs=confs)
 assert seed == 1234
+# a rank whose controller drifted (different sampled configurations) must raise, not train a different population
+bad = confs if rank == 0 else confs[::-1]
+try:
+    P.broadcast_seed(7, confs=bad)
+    drift = False
+except RuntimeError:
+    drift = True
+assert drift == (rank != 0), (rank, drift)
 print("rank", rank, "ok", mine, flush=True)
 dist.destroy_process_group()
 """
