@@ -25,6 +25,20 @@ struct ChainArgs {
     const float* pos_w;   // loss_mode 1: per-class positive weights
 };
 
+// what changes from one train step to the next (k_step / k_chain take it from the launch arguments, the persistent loop
+// computes it from its step counter)
+struct ChainStep {
+    int64_t pos_t;
+    int32_t base_t, nvalid, gstep, epoch;
+    float ss, bc2s;
+};
+__device__ __forceinline__ ChainStep chain_step_of(const ChainArgs& a) {
+    ChainStep c;
+    c.pos_t = a.pos_t; c.base_t = a.base_t; c.nvalid = a.nvalid; c.gstep = a.gstep; c.epoch = a.epoch;
+    c.ss = a.ac.ss; c.bc2s = a.ac.bc2s;
+    return c;
+}
+
 #define CHAIN_NW STEP_NW
 #define CHAIN_THREADS STEP_THREADS
 
@@ -35,8 +49,8 @@ __device__ __forceinline__ bool drop_keep(uint32_t h0, int cell, uint32_t idx, u
 }
 
 // acc[mb] += X[b][0..16*nk) . tile(k)   (X in LDS row-major with stride sx; tiles: 256 floats each, stride tstride)
-template <int MB>
-__device__ __forceinline__ void lds_x_times_tiles(f32x4 (&acc)[MB], const float* X, int sx, const float* tiles,
+template <int MB, bool COH>
+__device__ __forceinline__ void lds_x_times_tiles(f32x4 (&acc)[MB], const float* X, int sx, const float* tbase, int64_t tidx,
                                                   int64_t tstride, int nk, int lane) {
     // same arithmetic as mma_tiles: even / odd k-blocks in two independent chains, summed at the end
     const int l15 = lane & 15, lg = lane >> 4;
@@ -47,7 +61,7 @@ __device__ __forceinline__ void lds_x_times_tiles(f32x4 (&acc)[MB], const float*
         f32x4 w8[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (k0 + u < nk) w8[u] = *reinterpret_cast<const f32x4*>(tiles + (int64_t)(k0 + u) * tstride + lane * 4);
+            if (k0 + u < nk) w8[u] = ldc4<COH>(tbase, tidx + (int64_t)(k0 + u) * tstride + lane * 4);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (k0 + u < nk) {
@@ -74,10 +88,11 @@ __device__ __forceinline__ void lds_barrier() {
 
 // Software pipelining of the chain: the weight tiles of a product do not depend on the activations, so a wave
 // requests the NEXT product's tiles (<= 8 tiles = 32 VGPRs) before it starts the current one.
-__device__ __forceinline__ void issue_tiles(f32x4 (&w8)[8], const float* tiles, int nk, int lane) {
+template <bool COH>
+__device__ __forceinline__ void issue_tiles(f32x4 (&w8)[8], const float* tbase, int64_t tidx, int nk, int lane) {
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-        if (u < nk) w8[u] = *reinterpret_cast<const f32x4*>(tiles + (int64_t)u * 256 + lane * 4);
+        if (u < nk) w8[u] = ldc4<COH>(tbase, tidx + (int64_t)u * 256 + lane * 4);
 }
 
 // acc[mb] += X[b][0..16*nk) . w8[k]; even / odd k-blocks accumulate in two independent MFMA chains
@@ -138,8 +153,8 @@ __device__ __forceinline__ void bce_rows(float* lg_l, int SC, float* red, int Bp
 // sub+LPR, ... (<= 8 classes per lane, exp kept).  Leaves dlogits = (softmax - onehot)/nvalid in place, the row's loss in
 // red[b] and its top-1 hit in red[Bp + b] (multitask: argmax of central + visual + skeleton logits).
 template <int MB, int NC>
-__device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, float* lg_l, const int SC, float* red_l, const int* lab_l,
-                                                const int nvalid, const float nf, const int tid) {
+__device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, const ChainStep& cs, float* lg_l, const int SC, float* red_l,
+                                                const int* lab_l, const int nvalid, const float nf, const int tid) {
     constexpr int Bp = MB * 16;
     constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
     const Geo& g = a.g;
@@ -175,7 +190,7 @@ __device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, float* lg_l,
     const float* vl = nullptr;
     const float* sl = nullptr;
     if (g.multitask && ok) {
-        const int64_t grow = a.order ? (int64_t)a.order[a.pos_t + b] : (int64_t)(a.base_t + b);
+        const int64_t grow = a.order ? (int64_t)a.order[cs.pos_t + b] : (int64_t)(cs.base_t + b);
         vl = a.tab.vlogit + grow * C;
         sl = a.tab.slogit + grow * C;
     }
@@ -218,22 +233,22 @@ __device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, float* lg_l,
 }
 
 template <int MB>
-__device__ __forceinline__ void softmax_rows(const ChainArgs& a, float* lg_l, const int SC, float* red_l, const int* lab_l,
-                                             const int nvalid, const float nf, const int tid) {
+__device__ __forceinline__ void softmax_rows(const ChainArgs& a, const ChainStep& cs, float* lg_l, const int SC, float* red_l,
+                                             const int* lab_l, const int nvalid, const float nf, const int tid) {
     constexpr int Bp = MB * 16;
     constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
-    if (a.g.Cp <= 4 * LPR) softmax_rows_nc<MB, 4>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
-    else softmax_rows_nc<MB, 8>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+    if (a.g.Cp <= 4 * LPR) softmax_rows_nc<MB, 4>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+    else softmax_rows_nc<MB, 8>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
 }
 
 #ifdef MFAS_CHAIN_TIMING
-#define CT_STAMP(slot) do { if (threadIdx.x == 0 && bid == 0 && a.gstep == 3) a.status[64 + (slot)] = (int32_t)(__builtin_readcyclecounter() - ct0); } while (0)
+#define CT_STAMP(slot) do { if (threadIdx.x == 0 && bid == 0 && cs.gstep == 3) a.status[64 + (slot)] = (int32_t)(__builtin_readcyclecounter() - ct0); } while (0)
 #else
 #define CT_STAMP(slot) do { } while (0)
 #endif
 
-template <int MB, bool PF>
-__device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, float* lds) {
+template <int MB, bool PF, bool COH = false>
+__device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds) {
 #ifdef MFAS_CHAIN_TIMING
     const unsigned long long ct0 = __builtin_readcyclecounter();
 #endif
@@ -284,15 +299,18 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
         }
         vecW = vl; vecM = vl + nvec; vecV = vl + 2 * nvec;   // visible after the phase-0 barrier below
     }
-    const int nvalid = a.nvalid;
+    const int nvalid = cs.nvalid;
     const float nf = (float)nvalid;
-    const AdamC ac = a.ac;
-    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(a.gstep + 1));
+    AdamC ac = a.ac;
+    ac.ss = cs.ss;
+    ac.bc2s = cs.bc2s;
+    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(cs.gstep + 1));
+    const int64_t sbo = cd.step_off;   // this candidate's step buffers inside a.stepbuf (COH accesses index from the base)
 
     if (tid < Bp) {
         int lab = 0;
         if (tid < nvalid) {
-            const int64_t row = a.order ? (int64_t)a.order[a.pos_t + tid] : (int64_t)(a.base_t + tid);
+            const int64_t row = a.order ? (int64_t)a.order[cs.pos_t + tid] : (int64_t)(cs.base_t + tid);
             lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
         }
         lab_l[tid] = lab;
@@ -305,14 +323,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
         for (int e = tid; e < L * per_cell; e += CHAIN_THREADS) {
             const int i = e / per_cell, it = e - i * per_cell;
             const int ns = cd.nch_s[i], nch = ns + cd.nch_v[i];
-            const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8) + it * 4;
+            const int64_t part = sbo + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8) + it * 4;
             f32x4 accS = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
             constexpr int PB = PF ? 16 : 8;   // partial-sum loads in flight per thread
             for (int ch0 = 0; ch0 < nch; ch0 += PB) {
                 f32x4 p8[PB];
 #pragma unroll
                 for (int u = 0; u < PB; ++u)
-                    if (ch0 + u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)(ch0 + u) * nrb * MB) << 8));
+                    if (ch0 + u < nch) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)(ch0 + u) * nrb * MB) << 8));
 #pragma unroll
                 for (int u = 0; u < PB; ++u)
                     if (ch0 + u < nch) {
@@ -336,8 +354,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
     for (int u = 0; u < 8; ++u) { wa[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; wb[u] = wa[u]; }
     // products in order: P_1..P_{L-1} (prev-out block of cell i), head, then backward: head^T, outT_{L-1}..outT_1
     if (pf) {
-        if (L > 1) { if (wave < nrb) issue_tiles(wa, W + cd.seg_off[1][2] + (int64_t)wave * nrb * 256, nrb, lane); }
-        else if (wave < ncb) issue_tiles(wa, W + cd.head_off + (int64_t)wave * nrb * 256, nrb, lane);
+        if (L > 1) { if (wave < nrb) issue_tiles<COH>(wa, W, cd.seg_off[1][2] + (int64_t)wave * nrb * 256, nrb, lane); }
+        else if (wave < ncb) issue_tiles<COH>(wa, W, cd.head_off + (int64_t)wave * nrb * 256, nrb, lane);
     }
 
     CT_STAMP(0);
@@ -345,8 +363,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
     for (int i = 0; i < L; ++i) {
         CT_STAMP(1 + i);
         if (pf && i >= 1) {   // wa holds P_i; request the NEXT product's tiles now: P_{i+1}, or the head after the last cell
-            if (i + 1 < L) { if (wave < nrb) issue_tiles(wb, W + cd.seg_off[i + 1][2] + (int64_t)wave * nrb * 256, nrb, lane); }
-            else if (wave < ncb) issue_tiles(wb, W + cd.head_off + (int64_t)wave * nrb * 256, nrb, lane);
+            if (i + 1 < L) { if (wave < nrb) issue_tiles<COH>(wb, W, cd.seg_off[i + 1][2] + (int64_t)wave * nrb * 256, nrb, lane); }
+            else if (wave < ncb) issue_tiles<COH>(wb, W, cd.head_off + (int64_t)wave * nrb * 256, nrb, lane);
         }
         const float* xprev = xo_l + ((i + 1) & 1) * Bp * SX;
         float* xcur = xo_l + (i & 1) * Bp * SX;
@@ -359,8 +377,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             sgS = sg;
             sgV = 1.0f - sg;
             if (tid == 0) {
-                sb[g.sb_gsc + i * 2] = sgS;
-                sb[g.sb_gsc + i * 2 + 1] = sgV;
+                stc1<COH>(sb + g.sb_gsc + i * 2, sgS);
+                stc1<COH>(sb + g.sb_gsc + i * 2 + 1, sgV);
             }
         }
         for (int rb = wave; rb < nrb; rb += CHAIN_NW) {
@@ -383,7 +401,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             }
             if (i > 0) {
                 if (pf) mma_tiles<MB>(acc, xprev, SX, wa, nrb, lane);
-                else lds_x_times_tiles<MB>(acc, xprev, SX, W + cd.seg_off[i][2] + (int64_t)rb * nrb * 256, 256, nrb, lane);
+                else lds_x_times_tiles<MB, COH>(acc, xprev, SX, W, cd.seg_off[i][2] + (int64_t)rb * nrb * 256, 256, nrb, lane);
             }
             float av[MB][4];
             float s = 0.f;
@@ -457,7 +475,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
                         o = drop_keep(h0, i, (uint32_t)(b * R + r), g.drop_thr) ? o * g.drop_scale : 0.0f;
                     if (!(colok && b < nvalid)) o = 0.0f;
                     xcur[b * SX + r] = o;
-                    xo_g[b * Rp + r] = o;
+                    stc1<COH>(xo_g + b * Rp + r, o);
                 }
         }
         if (pf && i >= 1) {
@@ -472,7 +490,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
     {
         const float* xl = xo_l + ((L - 1) & 1) * Bp * SX;
         if (pf && wave < nrb)   // first backward product: d_out = dlogits . Wc  (transposed head tiles of this row block)
-            issue_tiles(wb, a.wt + cd.headT_off + (int64_t)wave * ncb * 256, ncb, lane);
+            issue_tiles<COH>(wb, a.wt, cd.headT_off + (int64_t)wave * ncb * 256, ncb, lane);
         for (int cb = wave; cb < ncb; cb += CHAIN_NW) {
             f32x4 acc[MB];
 #pragma unroll
@@ -480,7 +498,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
             const int c = cb * 16 + l15;
             const float bias = vecW[g.vec_head + c];
             if (pf) mma_tiles<MB>(acc, xl, SX, wa, nrb, lane);
-            else lds_x_times_tiles<MB>(acc, xl, SX, W + cd.head_off + (int64_t)cb * nrb * 256, 256, nrb, lane);
+            else lds_x_times_tiles<MB, COH>(acc, xl, SX, W, cd.head_off + (int64_t)cb * nrb * 256, 256, nrb, lane);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -492,15 +510,15 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
     if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
     } else if (tid < LPR * Bp) {
-        softmax_rows<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+        softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
     }
     lds_barrier();
     if (tid == CHAIN_THREADS - 64) {   // last wave: keeps the read-modify-write of the statistics off wave 0
-        float ls = 0.f, cs = 0.f;
-        for (int b = 0; b < Bp; ++b) { ls += red_l[b]; cs += red_l[Bp + b]; }
-        DevStats& st = a.stats[(int64_t)cgidx * a.E + a.epoch];
+        float ls = 0.f, ncor = 0.f;
+        for (int b = 0; b < Bp; ++b) { ls += red_l[b]; ncor += red_l[Bp + b]; }
+        DevStats& st = a.stats[(int64_t)cgidx * a.E + cs.epoch];
         st.train_loss += (double)ls;
-        st.train_corr += (long long)cs;
+        st.train_corr += (long long)ncor;
         if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
     }
     CT_STAMP(7);
@@ -509,7 +527,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
         float* dlg = sb + g.sb_dlog;
         for (int e = tid; e < Bp * Cp; e += CHAIN_THREADS) {
             const int b = e / Cp, c = e - b * Cp;
-            dlg[e] = lg_l[b * SC + c];
+            stc1<COH>(dlg + e, lg_l[b * SC + c]);
         }
         const int hc = tid - (CHAIN_THREADS - 256);   // head-bias columns on the upper four waves
         if (hc >= 0 && hc < C) {
@@ -531,7 +549,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
     for (int i = L - 1; i >= 0; --i) {
         CT_STAMP(8 + (L - 1 - i));
         if (pf && i >= 1 && wave < nrb)   // next backward product (cell i-1) uses the transposed prev-out block of cell i
-            issue_tiles(wb, a.wt + cd.outT_off[i] + (int64_t)wave * nrb * 256, nrb, lane);
+            issue_tiles<COH>(wb, a.wt, cd.outT_off[i] + (int64_t)wave * nrb * 256, nrb, lane);
         const int nl = (nlbits >> (2 * i)) & 3;
         const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
         const int vbl = i * g.vec_cell_stride;
@@ -539,7 +557,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
         const float* src = from_head ? lg_l : dy_l + ((i + 1) & 1) * Bp * SX;
         const int sstride = from_head ? SC : SX;
         const int nkk = from_head ? ncb : nrb;
-        const float* T = a.wt + (from_head ? cd.headT_off : cd.outT_off[i + 1]);
+        const int64_t Tidx = from_head ? cd.headT_off : cd.outT_off[i + 1];
         float* dcur = dy_l + (i & 1) * Bp * SX;
         float dalpha = 0.f;
         for (int rb = wave; rb < nrb; rb += CHAIN_NW) {
@@ -573,7 +591,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (pf) mma_tiles<MB>(acc, src, sstride, wa, nkk, lane);
-            else lds_x_times_tiles<MB>(acc, src, sstride, T + (int64_t)rb * nkk * 256, 256, nkk, lane);
+            else lds_x_times_tiles<MB, COH>(acc, src, sstride, a.wt, Tidx + (int64_t)rb * nkk * 256, 256, nkk, lane);
             float dz[MB][4];
             float sdz = 0.f, sdzx = 0.f;
 #pragma unroll
@@ -615,7 +633,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int bid, fl
                     sdy += dy;
                     dalpha += dy * df4[mb][q];
                     dcur[b * SX + r] = dy;
-                    dy_g[b * Rp + r] = dy;
+                    stc1<COH>(dy_g + b * Rp + r, dy);
                 }
             const float db = colsum(sdy);
             if (lg == 0 && colok) {   // Adam on the column's vector parameters (one owner lane per column)
@@ -669,8 +687,8 @@ __device__ __forceinline__ f32x4 pick4(const f32x4 (&t)[MFAS_MAX_CELLS], int i) 
     switch (i) { case 0: return t[0]; case 1: return t[1]; case 2: return t[2]; default: return t[3]; }
 }
 
-template <int MB>
-__device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, float* lds) {
+template <int MB, bool COH = false>
+__device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds) {
 #ifdef MFAS_CHAIN_TIMING
     const unsigned long long ct0 = __builtin_readcyclecounter();
 #endif
@@ -705,10 +723,13 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
     int nlbits = 0;
 #pragma unroll
     for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
-    const int nvalid = a.nvalid;
+    const int nvalid = cs.nvalid;
     const float nf = (float)nvalid;
-    const AdamC ac = a.ac;
-    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(a.gstep + 1));
+    AdamC ac = a.ac;
+    ac.ss = cs.ss;
+    ac.bc2s = cs.bc2s;
+    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(cs.gstep + 1));
+    const int64_t sbo = cd.step_off;
 
     // ------------------------------------------------------------------ entry: every global read of the chain is
     // requested here, in the order the results are needed (the memory counter retires in order): the sweep's partial
@@ -721,14 +742,14 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
     // (per_cell = MB * 64: the cell index is wave-uniform -> scalar loads of cd.nch_* / part_cell_off)
     const int pi = __builtin_amdgcn_readfirstlane(has_item ? tid / per_cell : 0), pit = tid - pi * per_cell;
     const int ns = cd.nch_s[pi], nch = has_item ? ns + cd.nch_v[pi] : 0;
-    const float* part = sb + g.sb_part + (((int64_t)cd.part_cell_off[pi] * MB) << 8) + pit * 4;
+    const int64_t part = sbo + g.sb_part + (((int64_t)cd.part_cell_off[pi] * MB) << 8) + pit * 4;
     // every load below is UNCONDITIONAL (indices clamped to something valid): with a statically known number of loads in
     // flight the compiler can wait for exactly the ones it consumes instead of draining the whole queue at first use
     f32x4 p8[PB];
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
         const int uu = u < nch ? u : 0;
-        p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)uu * MB) << 8));
+        p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)uu * MB) << 8));
     }
     const int vi = tid < nvec ? tid : 0;   // nvec = 4 * 96 + Cp <= 448: one element of the vector block per thread
     const float vw = W[cvec_off + vi], vm = Mv[cvec_off + vi], vv = Vv[cvec_off + vi];
@@ -737,15 +758,14 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
     tP[0] = z4; tT[0] = z4;
 #pragma unroll
     for (int i = 1; i < MFAS_MAX_CELLS; ++i) {
-        const float* fp = i < L ? W + cd.seg_off[i][2] : W + cvec_off;
-        const float* tp = i < L ? a.wt + cd.outT_off[i] : W + cvec_off;
-        tP[i] = *reinterpret_cast<const f32x4*>(fp + lane * 4);
-        tT[i] = *reinterpret_cast<const f32x4*>(tp + lane * 4);
+        // (cells beyond L: any valid address — the loads stay unconditional, their values are never used)
+        tP[i] = ldc4<COH>(W, (i < L ? cd.seg_off[i][2] : cvec_off) + lane * 4);
+        tT[i] = ldc4<COH>(a.wt, (i < L ? cd.outT_off[i] : cd.headT_off) + lane * 4);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-        tHT[u] = *reinterpret_cast<const f32x4*>(a.wt + cd.headT_off + ((int64_t)(u < ncb ? u : 0) << 8) + lane * 4);
-    tH = *reinterpret_cast<const f32x4*>(W + cd.head_off + ((int64_t)(wave < ncb ? wave : 0) << 8) + lane * 4);
+        tHT[u] = ldc4<COH>(a.wt, cd.headT_off + ((int64_t)(u < ncb ? u : 0) << 8) + lane * 4);
+    tH = ldc4<COH>(W, cd.head_off + ((int64_t)(wave < ncb ? wave : 0) << 8) + lane * 4);
     // dropout keep bits of this lane's elements (wave 0 owns the row block): bit (i*MB + mb)*4 + q — computed while the
     // loads above are in flight, used by the forward AND the backward pass
     const int r = l15;
@@ -771,7 +791,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
         for (int ch0 = PB; ch0 < nch; ch0 += PB) {
 #pragma unroll
             for (int u = 0; u < PB; ++u)
-                if (ch0 + u < nch) p8[u] = *reinterpret_cast<const f32x4*>(part + (((int64_t)(ch0 + u) * MB) << 8));
+                if (ch0 + u < nch) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)(ch0 + u) * MB) << 8));
 #pragma unroll
             for (int u = 0; u < PB; ++u)
                 if (ch0 + u < nch) {
@@ -790,7 +810,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
     // forward pass
     int lab = 0;
     if (wave == 1 && lane < nvalid) {
-        const int64_t row = a.order ? (int64_t)a.order[a.pos_t + lane] : (int64_t)(a.base_t + lane);
+        const int64_t row = a.order ? (int64_t)a.order[cs.pos_t + lane] : (int64_t)(cs.base_t + lane);
         lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
     }
     const float* vecW = vec_l;
@@ -815,8 +835,8 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
                 sgS = sg;
                 sgV = 1.0f - sg;
                 if (lane == 0) {
-                    sb[g.sb_gsc + i * 2] = sgS;
-                    sb[g.sb_gsc + i * 2 + 1] = sgV;
+                    stc1<COH>(sb + g.sb_gsc + i * 2, sgS);
+                    stc1<COH>(sb + g.sb_gsc + i * 2 + 1, sgV);
                 }
             }
             f32x4 acc[MB];
@@ -922,7 +942,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
     // OUT / HEAD segments), coalesced, by everyone; head on waves < ncb
     {
         float* xo_g = sb + g.sb_xo;   // [L][Bp][Rp]
-        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) xo_g[e] = xo_l[(e >> 4) * SX + (e & 15)];
+        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(xo_g + e, xo_l[(e >> 4) * SX + (e & 15)]);
         const float* xl = xo_l + (L - 1) * Bp * SX;
         if (wave < ncb) {
             const int c = wave * 16 + l15;
@@ -943,23 +963,23 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
     if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
     } else if (tid < LPR * Bp) {
-        softmax_rows<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+        softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
     }
     lds_barrier();
     CT_STAMP(7);
     if (tid == CHAIN_THREADS - 64) {
-        float ls = 0.f, cs = 0.f;
-        for (int b = 0; b < Bp; ++b) { ls += red_l[b]; cs += red_l[Bp + b]; }
-        DevStats& st = a.stats[(int64_t)cgidx * a.E + a.epoch];
+        float ls = 0.f, ncor = 0.f;
+        for (int b = 0; b < Bp; ++b) { ls += red_l[b]; ncor += red_l[Bp + b]; }
+        DevStats& st = a.stats[(int64_t)cgidx * a.E + cs.epoch];
         st.train_loss += (double)ls;
-        st.train_corr += (long long)cs;
+        st.train_corr += (long long)ncor;
         if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
     }
     if (wave != 0) {   // dlogits -> step buffer (dy operand of the HEAD segment); head-bias Adam
         float* dlg = sb + g.sb_dlog;
         for (int e = tid - 64; e < Bp * Cp; e += CHAIN_THREADS - 64) {
             const int b = e / Cp, c = e - b * Cp;
-            dlg[e] = lg_l[b * SC + c];
+            stc1<COH>(dlg + e, lg_l[b * SC + c]);
         }
         const int hc = tid - (CHAIN_THREADS - 256);
         if (hc >= 0 && hc < C) {
@@ -1099,6 +1119,6 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const int bid, fl
     CT_STAMP(12);
     {   // dy_i -> step buffer (dy operand of the sweep), coalesced
         float* dy_g = sb + g.sb_dy;   // [L][Bp][Rp]
-        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) dy_g[e] = dy_l[(e >> 4) * SX + (e & 15)];
+        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(dy_g + e, dy_l[(e >> 4) * SX + (e & 15)]);
     }
 }

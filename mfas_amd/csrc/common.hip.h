@@ -37,6 +37,8 @@ struct SegDesc {          // one workgroup of k_sweep / k_pack
     int32_t src_ld, src_col0;
     uint32_t init_seed;   // hash seed of that matrix (device init)
     float init_bound;
+    int32_t rb0, seg_nrb; // row-split units: first row block of this unit inside the segment, row blocks of the whole segment
+                          // (rows_p = rows of THIS unit; w_off already points at row block rb0 of the chunk)
 };
 
 #define TAP_MAX_ITEMS 8
@@ -197,14 +199,55 @@ __device__ __forceinline__ void stage_table(float* dst, int stride, const void* 
     }
 }
 
-// f32 row-major global [nrows][src_stride] -> LDS [nrows][stride]
-__device__ __forceinline__ void stage_f32(float* dst, int stride, const float* src, int src_stride, int ncols,
+// ------------------------------------------------------------------------------------------------
+// Coherent (COH) accesses for data that workgroups exchange INSIDE one launch (the persistent step loop, persist.hip.h).
+// gfx950 has 8 XCDs with private, mutually non-coherent L2s and per-CU L1s that other CUs' stores never refresh, so
+// exchanged data is stored write-through (`sc1`) and loaded with `sc1` (L1 bypass, coherent level) — no fences needed
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"; cdna_hip_programming.md G16 R1).
+// 16-byte accesses go through raw-buffer builtins (the compiler counts them in its s_waitcnt bookkeeping): `base` must be
+// wave-uniform (a kernel-argument pointer) and the element index must stay below 2^30 floats (checked on the host).
+// With COH = false the same helpers are ordinary loads / stores: the launch-per-phase schedule pays nothing.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define MFAS_AUX_SC1 16
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+}
+template <bool COH>
+__device__ __forceinline__ f32x4 ldc4(const float* base, int64_t idx) {
+    if constexpr (COH) {
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(mk_rsrc(base), (int)(uint32_t)(idx << 2), 0, MFAS_AUX_SC1);
+        return __builtin_bit_cast(f32x4, r);
+    } else {
+        return *reinterpret_cast<const f32x4*>(base + idx);
+    }
+}
+template <bool COH>
+__device__ __forceinline__ void stc4(float* base, int64_t idx, f32x4 v) {
+    if constexpr (COH)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), mk_rsrc(base), (int)(uint32_t)(idx << 2), 0, MFAS_AUX_SC1);
+    else
+        *reinterpret_cast<f32x4*>(base + idx) = v;
+}
+template <bool COH>
+__device__ __forceinline__ void stc1(float* p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dword sc1
+    else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ float ldc1(const float* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load_dword sc1
+    else return *p;
+}
+
+// f32 row-major global base[idx0 + b * src_stride + c] -> LDS [nrows][stride]
+template <bool COH>
+__device__ __forceinline__ void stage_f32(float* dst, int stride, const float* base, int64_t idx0, int src_stride, int ncols,
                                           int nrows, int tid, int nthreads) {
     const int vpr = ncols >> 2;
     for (int e = tid; e < nrows * vpr; e += nthreads) {
         const int b = e / vpr, c = (e - b * vpr) << 2;
-        *reinterpret_cast<f32x4*>(dst + b * stride + c) =
-            *reinterpret_cast<const f32x4*>(src + (int64_t)b * src_stride + c);
+        *reinterpret_cast<f32x4*>(dst + b * stride + c) = ldc4<COH>(base, idx0 + (int64_t)b * src_stride + c);
     }
 }
 

@@ -24,6 +24,9 @@
 //   A[i = l&15][k = l>>4],  B[k = l>>4][j = l&15],  D[i = 4*(l>>4)+reg][j = l&15].
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+// No implicit FMA contraction anywhere in this translation unit (see __graft_entry__.build): every schedule (k_chain / k_step /
+// k_persist instantiations) must round identically.  MFMA instructions are unaffected.
+#pragma clang fp contract(off)
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -54,11 +57,11 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bid = (int)blockIdx.x;
     if (bid < a.nchain) {
-        if constexpr (LEAN) chain_lean<MB>(a.ca, bid, lds);
-        else chain_body<MB, false>(a.ca, bid, lds);
+        if constexpr (LEAN) chain_lean<MB>(a.ca, chain_step_of(a.ca), bid, lds);
+        else chain_body<MB, false>(a.ca, chain_step_of(a.ca), bid, lds);
     }
     else if (bid < a.nchain + a.sa.ntap) sweep_tap_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain, lds);
-    else sweep_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain - a.sa.ntap, lds);
+    else sweep_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, sweep_step_of(a.sa), bid - a.nchain - a.sa.ntap, lds);
 }
 
 // Standalone chain launch (small populations: chain and sweep run back to back, so the chain's latency is on the
@@ -66,10 +69,11 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
 template <int MB, bool LEAN>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_chain(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if constexpr (LEAN) chain_lean<MB>(a, (int)blockIdx.x, lds);
-    else chain_body<MB, true>(a, (int)blockIdx.x, lds);
+    if constexpr (LEAN) chain_lean<MB>(a, chain_step_of(a), (int)blockIdx.x, lds);
+    else chain_body<MB, true>(a, chain_step_of(a), (int)blockIdx.x, lds);
 }
 
+#include "persist.hip.h"
 #include "eval.hip.h"
 #include "pack.hip.h"
 
@@ -117,6 +121,15 @@ struct mfas_population {
     double prof_ms = 0.0, bytes_per_launch = 0.0, prof_bytes = 0.0;
     double alg_state_bytes = 0.0, alg_feat_elems = 0.0;
     double best_threshold = 0.0;    // snapshot_best: a dev metric must exceed this to count (init_f1, mmimdb.py:18; 0 for NTU)
+    // persistent step loop (persist.hip.h): one launch per epoch, per-candidate dependencies
+    bool persist = false;
+    int n_cus = 0;
+    size_t lds_persist = 0;
+    uint32_t* d_sync = nullptr;     // [K] flags | [K] counters | abort word (zeroed before every launch)
+    int32_t* d_need = nullptr;      // [K] sweep units per candidate
+    float* d_scal = nullptr;        // device copy of the step scalars
+    size_t scal_cap = 0;
+    unsigned long long* d_trace = nullptr;
 };
 
 static inline int ceil16(int x) { return (x + 15) & ~15; }
@@ -271,6 +284,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
                     d.rows = hp->R; d.cols = true_w[j];
                     d.src_off = c.f_W[i]; d.src_ld = Kin; d.src_col0 = col0[j];
                     d.init_seed = 2 * i; d.init_bound = bound;
+                    d.rb0 = 0; d.seg_nrb = g.nrb;
                     p->descs.push_back(d);
                 }
                 if (j < 2) pslot += nch;
@@ -294,6 +308,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             d.rows = hp->C; d.cols = hp->R;
             d.src_off = c.f_Wc; d.src_ld = hp->R; d.src_col0 = 0;
             d.init_seed = 10; d.init_bound = (float)(1.0 / sqrt((double)hp->R));
+            d.rb0 = 0; d.seg_nrb = g.ncb;
             p->descs.push_back(d);
             plane_off += (int64_t)g.Cp * g.Rp;
             wt_off += (int64_t)g.Cp * g.Rp;
@@ -393,6 +408,17 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         // 50: 430 vs 475, 100: 582 vs 677, 200: 566 vs 600, 256: 630 vs 619, 512: 685 vs 641 -> fused only for 40 <= K < 224.
         int ngroups = p->lean_chain ? ((K >= 40 && K < 224) ? 2 : 1) : (K >= 20 ? 2 : 1);
         if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
+        {   // persistent step loop: small populations (one workgroup per CU must hold every chain + a useful number of sweep workgroups)
+            hipDeviceProp_t prop;
+            CREATE_CHK(hipGetDeviceProperties(&prop, device));
+            p->n_cus = prop.multiProcessorCount;
+            bool want = false;   // default decided by measurement; MFAS_PERSIST=1/0 overrides
+            if (const char* e = getenv("MFAS_PERSIST")) want = atoi(e) != 0;
+            const bool fits = K <= p->n_cus / 4 && g.MB != 4 && (int64_t)p->descs.size() <= (int64_t)PERSIST_MAX_UNITS * (p->n_cus - K) &&
+                              (double)p->plane_stride * 4.0 < 3.9e9 && (double)step_off * 4.0 < 3.9e9 && (double)wt_off * 4.0 < 3.9e9;
+            p->persist = want && fits;
+            if (p->persist) ngroups = 1;
+        }
         int split = K;
         if (ngroups == 2) {
             double tot = 0, run = 0;
@@ -416,7 +442,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             // small R (1, 2 or 4 row blocks): feature segments are regrouped tap-major (sweep_tap_body)
             std::vector<SegDesc> sorted;
             std::vector<TapDesc> taps;
-            const bool tap_major = (g.nrb == 1 || g.nrb == 2 || g.nrb == 4) && !getenv("MFAS_NO_TAP_MAJOR");
+            const bool tap_major = (g.nrb == 1 || g.nrb == 2 || g.nrb == 4) && !getenv("MFAS_NO_TAP_MAJOR") && !p->persist;
             if (tap_major) {
                 const int per_wg = STEP_NW / g.nrb;
                 std::vector<const SegDesc*> feat;
@@ -476,6 +502,22 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(set_lds((k_chain<4, false>), p->lds_chain));
     CREATE_CHK(set_lds((k_chain<1, true>), p->lds_chain));
     CREATE_CHK(set_lds((k_chain<2, true>), p->lds_chain));
+    if (p->persist) {
+        p->lds_persist = ((std::max(p->lds_step, p->lds_chain) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
+        std::vector<int32_t> need(K, 0);
+        for (const SegDesc& d : p->descs) need[d.cand]++;
+        CREATE_CHK(hipMalloc(&p->d_need, sizeof(int32_t) * K));
+        CREATE_CHK(hipMemcpy(p->d_need, need.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice));
+        CREATE_CHK(hipMalloc(&p->d_sync, sizeof(uint32_t) * (2 * K + 16)));
+        if (getenv("MFAS_PERSIST_TRACE")) {
+            CREATE_CHK(hipMalloc(&p->d_trace, sizeof(unsigned long long) * 64));
+            CREATE_CHK(hipMemset(p->d_trace, 0, sizeof(unsigned long long) * 64));
+        }
+        CREATE_CHK(set_lds((k_persist<1, false, 2>), p->lds_persist));
+        CREATE_CHK(set_lds((k_persist<2, false, 2>), p->lds_persist));
+        CREATE_CHK(set_lds((k_persist<1, true, 2>), p->lds_persist));
+        CREATE_CHK(set_lds((k_persist<2, true, 2>), p->lds_persist));
+    }
     // W/m/v beyond what the 256 MiB Infinity Cache can keep between steps are streamed nontemporally
     p->nontemporal = (double)p->plane_stride * 12.0 > 200.0 * 1024 * 1024;
     if (const char* e = getenv("MFAS_NT")) p->nontemporal = atoi(e) != 0;
@@ -493,6 +535,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     for (auto& gr : p->groups) { hipFree(gr.d_descs); hipFree(gr.d_taps); }
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
     hipFree(p->d_seeds); hipFree(p->d_corr); hipFree(p->d_posw);
+    hipFree(p->d_sync); hipFree(p->d_need); hipFree(p->d_scal); hipFree(p->d_trace);
     delete p;
 }
 
@@ -700,11 +743,67 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         }
     };
 
+    std::vector<uint32_t> aborts(epochs, 0u);
+    if (p->persist) {   // the step scalars live on the device: the kernel walks the steps itself
+        const size_t nsc = (size_t)epochs * nb * 2;
+        if (p->scal_cap < nsc) {
+            hipFree(p->d_scal); p->d_scal = nullptr;
+            HIPCHK(hipMalloc(&p->d_scal, sizeof(float) * nsc));
+            p->scal_cap = nsc;
+        }
+        const size_t have = (size_t)(max_steps >= 0 ? std::min<int64_t>(max_steps, (int64_t)epochs * nb) : (int64_t)epochs * nb) * 2;
+        HIPCHK(hipMemcpyAsync(p->d_scal, step_scalars, sizeof(float) * have, hipMemcpyHostToDevice, p->stream));
+    }
+    // one persistent launch = all train steps of one epoch (persist.hip.h)
+    auto persist_epoch = [&](int ep, int64_t T) -> hipError_t {
+        hipError_t e = hipMemsetAsync(p->d_sync, 0, sizeof(uint32_t) * (2 * K + 16), p->stream);
+        if (e != hipSuccess) return e;
+        PersistArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.sa = st.sa; pa.ca = st.ca;
+        pa.sa.desc = p->groups[0].d_descs; pa.sa.tdesc = nullptr; pa.sa.ntap = 0;
+        pa.ca.cands = p->d_cands;
+        pa.nchain = K; pa.nitems = p->groups[0].ndesc;
+        pa.T = (int)T; pa.epoch = ep;
+        pa.N = N; pa.pos0 = (int64_t)ep * N;
+        pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);
+        pa.scal = p->d_scal; pa.sync = p->d_sync; pa.need = p->d_need; pa.trace = p->d_trace;
+        const unsigned grid = (unsigned)(K + std::min(pa.nitems, p->n_cus - K));
+        const int ldsw = (int)(p->lds_persist / 4) - PERSIST_LDS_WORDS;
+        if (pa.nitems > PERSIST_MAX_UNITS * (int)(grid - K)) return hipErrorInvalidConfiguration;
+        const bool prof = p->profiling;
+        if (prof) {
+            if (p->ev.size() < ev_used + 2) {
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                p->ev.push_back(e0); p->ev.push_back(e1);
+            }
+            hipEventRecord(p->ev[ev_used], p->stream);
+        }
+#define PERSIST_LAUNCH(M, F) hipLaunchKernelGGL((k_persist<M, F, 2>), dim3(grid), dim3(STEP_THREADS), p->lds_persist, p->stream, pa, ldsw)
+        if (p->lean_chain) { if (g.MB == 1) PERSIST_LAUNCH(1, true); else PERSIST_LAUNCH(2, true); }
+        else if (g.MB == 1) PERSIST_LAUNCH(1, false);
+        else PERSIST_LAUNCH(2, false);
+#undef PERSIST_LAUNCH
+        if (prof) {
+            hipEventRecord(p->ev[ev_used + 1], p->stream);
+            ev_used += 2;
+            // algorithmic bytes of the launch: T update+forward sweeps of every candidate
+            ev_bytes.push_back((double)T * (p->groups[0].alg_state + p->groups[0].alg_feat * elt + 8.0 * B * K));
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(&aborts[ep], p->d_sync + 2 * K, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
+    };
+
     int64_t done = 0;   // train steps completed (max_steps bookkeeping)
     for (int ep = 0; ep < epochs; ++ep) {
         int64_t T = nb;
         if (max_steps >= 0) T = std::min<int64_t>(nb, max_steps - done);
         if (T <= 0) break;
+        if (p->persist) {
+            HIPCHK(persist_epoch(ep, T));
+        } else {
         for (int gi = 0; gi < NG; ++gi) step(gi, 0, 1, ep, 0, -1, 0);   // prologue: forward sums of batch 0
         if (NG == 1) {
             for (int64_t t = 0; t < T; ++t) {
@@ -718,6 +817,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
                 step(0, 1, fwd, ep, t, 1, t);                       // sweep(A, t)  ||  chain(B, t)
                 step(1, 1, fwd, ep, t, fwd ? 0 : -1, t + 1);        // sweep(B, t)  ||  chain(A, t+1)
             }
+        }
         }
         done += T;
         HIPCHK(hipGetLastError());
@@ -753,6 +853,19 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     HIPCHK(hipMemcpyAsync(hstatus.data(), p->d_status, sizeof(int32_t) * K, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipGetLastError());
+    for (uint32_t ab : aborts)
+        if (ab) return fail(MFAS_EHIP, "persistent step loop: a workgroup timed out waiting for its dependency (launch aborted)");
+    if (p->d_trace && p->persist) {
+        unsigned long long tr[64];
+        if (hipMemcpy(tr, p->d_trace, sizeof(tr), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[persist trace, 10 ns ticks; per step: chain wait0 ready done published | sweep-unit-0 wait0 ready done arrived]\n");
+            for (int t = 0; t < 8; ++t) {
+                fprintf(stderr, "  step %2d:", t + 8);
+                for (int j = 0; j < 8; ++j) fprintf(stderr, " %lld", (long long)(tr[t * 8 + j] - tr[0]));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
     for (size_t i = 0; i < hstats.size(); ++i) {
         stats[i].train_loss_sum = hstats[i].train_loss;
         stats[i].dev_loss_sum = hstats[i].dev_loss;

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) k_pack(const PackArgs a) {
     for (int e = threadIdx.x; e < d.rows_p * d.cc; e += 256) {
         const int tile = e >> 8, within = e & 255, lane = within >> 2, q = within & 3;
         const int rb = tile / nkb, kb = tile - rb * nkb;
-        const int r = rb * 16 + (lane & 15);
+        const int r = (d.rb0 + rb) * 16 + (lane & 15);   // row inside the segment (row-split units start at row block rb0)
         const int k = d.k0 + kb * 16 + 4 * (lane >> 4) + q;   // column inside the segment
         const bool ok = r < d.rows && k < d.cols;
         const int64_t fidx = (int64_t)r * d.src_ld + d.src_col0 + k;
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_pack(const PackArgs a) {
         }
         if (d.wt_off >= 0) {
             const int l15 = lane & 15, lg = lane >> 4;
-            float* T = a.wt + d.wt_off + ((int64_t)((d.k0 >> 4) + kb) * nrb + rb) * 256;
+            float* T = a.wt + d.wt_off + ((int64_t)((d.k0 >> 4) + kb) * d.seg_nrb + d.rb0 + rb) * 256;
             T[((((l15 >> 2) * 16 + 4 * lg) + q) << 2) + (l15 & 3)] = val;
         }
     }

@@ -7,7 +7,7 @@
 //   dW^T = x_t^T dy (4*MB f32 MFMAs; D image == the tile image)  ->  Adam(+L2) on 4 elements/lane in registers  ->
 //   store W, m, v (+ transposed copy T for OUT/HEAD)  ->  y_{t+1} += x_{t+1} W_new^T (4*MB f32 MFMAs) into yacc.
 // ------------------------------------------------------------------------------------------------
-template <int MB, bool NT, int SWEEP_U>
+template <int MB, bool NT, int SWEEP_U, bool COH = false>
 __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const int rb, const int nkb, const int kb0,
                                          const int kbs, const float* xt, const int ST, const float* xn, const int SN,
                                          const float (&dyf)[MB * 4], const float gsc, const AdamC& ac, const bool upd,
@@ -55,7 +55,10 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
                         __builtin_nontemporal_store(m4[u], reinterpret_cast<f32x4*>(Mp + off));
                         __builtin_nontemporal_store(v4[u], reinterpret_cast<f32x4*>(Vp + off));
                     } else {
-                        *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
+                        // COH (persistent schedule): OUT / HEAD weights are read by the chain workgroup on another CU in the
+                        // same launch -> write-through; feature segments (T == nullptr) are private to this workgroup
+                        if (COH && T) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w4[u]), mk_rsrc(Wp), (int)(uint32_t)(off << 2), 0, MFAS_AUX_SC1);
+                        else *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
                         *reinterpret_cast<f32x4*>(Mp + off) = m4[u];
                         *reinterpret_cast<f32x4*>(Vp + off) = v4[u];
                     }
@@ -63,7 +66,7 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
                         float* Tt = T + ((int64_t)kb * tstride_rb + rb) * 256;
                         const int base = (((l15 >> 2) * 16 + 4 * lg) << 2) + (l15 & 3);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) Tt[base + 4 * q] = w4[u][q];
+                        for (int q = 0; q < 4; ++q) stc1<COH>(Tt + base + 4 * q, w4[u][q]);
                     }
                 }
                 if (fwd) {
@@ -102,11 +105,26 @@ struct SweepArgs {
     Geo g;
 };
 
+// what changes from one train step to the next (k_step takes it from the launch arguments, the persistent loop computes it)
+struct SweepStep {
+    int64_t pos_t, pos_n;
+    int32_t base_t, base_n, nvalid_t, nvalid_n;
+    int32_t upd, fwd;
+    float ss, bc2s;
+};
+__device__ __forceinline__ SweepStep sweep_step_of(const SweepArgs& a) {
+    SweepStep s;
+    s.pos_t = a.pos_t; s.pos_n = a.pos_n; s.base_t = a.base_t; s.base_n = a.base_n;
+    s.nvalid_t = a.nvalid_t; s.nvalid_n = a.nvalid_n; s.upd = a.do_update; s.fwd = a.do_forward;
+    s.ss = a.ac.ss; s.bc2s = a.ac.bc2s;
+    return s;
+}
+
 #define STEP_NW 8
 #define STEP_THREADS (STEP_NW * 64)
 
-template <int MB, bool NT, int U>
-__device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, float* lds) {
+template <int MB, bool NT, int U, bool COH = false>
+__device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& st, const int bid, float* lds) {
     const SegDesc d = a.desc[bid];
     const CandDev& cd = a.cands[d.cand];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,43 +139,48 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, fl
     float* dyl = xn + Bp * SN;
     float* wred = dyl + Bp * SD;   // [8 waves][nrb][MB][256], only when the chunk is k-split over waves
     const bool feat = d.kind <= KIND_V;
-    const bool upd = a.do_update != 0;
-    const bool fwd = (a.do_forward != 0) && feat;
+    const bool upd = st.upd != 0;
+    const bool fwd = (st.fwd != 0) && feat;
     if (!upd && !fwd) return;
-    float* sb = a.stepbuf + cd.step_off;
+    const int64_t sbo = cd.step_off;   // this candidate's step buffers inside a.stepbuf
 
     if (upd) {
         if (feat) {
             const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
-            stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_t, a.base_t, a.nvalid_t, Bp, tid, STEP_THREADS);
+            stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, st.pos_t, st.base_t, st.nvalid_t, Bp, tid, STEP_THREADS);
         } else {
             const int xcell = d.kind == KIND_OUT ? d.cell - 1 : cd.L - 1;
-            stage_f32(xt, ST, sb + a.g.sb_xo + (int64_t)xcell * Bp * a.g.Rp + d.k0, a.g.Rp, cc, Bp, tid, STEP_THREADS);
+            stage_f32<COH>(xt, ST, a.stepbuf, sbo + a.g.sb_xo + (int64_t)xcell * Bp * a.g.Rp + d.k0, a.g.Rp, cc, Bp, tid, STEP_THREADS);
         }
-        const float* dsrc = d.kind == KIND_HEAD ? sb + a.g.sb_dlog : sb + a.g.sb_dy + (int64_t)d.cell * Bp * a.g.Rp;
-        stage_f32(dyl, SD, dsrc, rows_p, rows_p, Bp, tid, STEP_THREADS);
+        // dy of this unit's rows: columns [16*rb0, 16*rb0 + rows_p) of the segment's dy (row stride = the segment's padded rows)
+        const int64_t dsrc = d.kind == KIND_HEAD ? sbo + a.g.sb_dlog : sbo + a.g.sb_dy + (int64_t)d.cell * Bp * a.g.Rp;
+        stage_f32<COH>(dyl, SD, a.stepbuf, dsrc + d.rb0 * 16, d.seg_nrb * 16, rows_p, Bp, tid, STEP_THREADS);
     }
     if (fwd) {
         const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
-        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_n, a.base_n, a.nvalid_n, Bp, tid, STEP_THREADS);
+        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, st.pos_n, st.base_n, st.nvalid_n, Bp, tid, STEP_THREADS);
     }
     __syncthreads();
 
     float* Wp = a.plane + d.w_off;
     float* Mp = Wp + a.plane_stride;
     float* Vp = Mp + a.plane_stride;
-    const AdamC ac = a.ac;
+    AdamC ac = a.ac;
+    ac.ss = upd ? st.ss : 0.f;
+    ac.bc2s = upd ? st.bc2s : 1.f;
     // alpha scaling of the gradient of S / V columns (aux_models.py:103-111): sigma(alpha_t) as used by this
     // step's forward, published by k_chain (alpha itself has already been stepped); 1.0 when alphas are off
     float gsc = 1.0f;
-    if (a.g.alphas && feat && upd) gsc = sb[a.g.sb_gsc + d.cell * 2 + d.kind];
+    if (a.g.alphas && feat && upd) gsc = ldc1<COH>(a.stepbuf + sbo + a.g.sb_gsc + d.cell * 2 + d.kind);
 
     // Work split: with >= 8 row blocks every wave owns whole row blocks (streams contiguous tiles, no
-    // reduction); with fewer (R < 128) the waves split the k blocks and reduce through LDS.
+    // reduction); with fewer (R < 128, or a row-split unit) the waves split the k blocks and reduce through LDS.
     const bool split_k = nrb < STEP_NW;
     const int rb0 = split_k ? 0 : wave, rbs = split_k ? 1 : STEP_NW;
     const int kb0 = split_k ? wave : 0, kbs = split_k ? STEP_NW : 1;
-    float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * nrb * MB) << 8);
+    // partial slot of this chunk: [seg_nrb][MB][256] in MFMA D layout; this unit owns row blocks rb0 .. rb0 + nrb
+    const int64_t part = sbo + a.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * d.seg_nrb * MB) << 8) +
+                         (((int64_t)d.rb0 * MB) << 8);
 
     for (int rb = rb0; rb < nrb; rb += rbs) {
         float dyf[MB * 4];
@@ -166,15 +189,15 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, fl
         f32x4 yacc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        tile_run<MB, NT, U>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
-                         d.wt_off >= 0 ? a.wt + d.wt_off + (int64_t)(d.k0 >> 4) * nrb * 256 : nullptr, nrb, lane);
+        tile_run<MB, NT, U, COH>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
+                                 d.wt_off >= 0 ? a.wt + d.wt_off + ((int64_t)(d.k0 >> 4) * d.seg_nrb + d.rb0) * 256 : nullptr, d.seg_nrb, lane);
         if (fwd) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 if (split_k)
                     *reinterpret_cast<f32x4*>(wred + (((wave * nrb + rb) * MB + mb) << 8) + lane * 4) = yacc[mb];
                 else   // partial slot in MFMA D layout [chunk][rb][mb][lane][4]
-                    *reinterpret_cast<f32x4*>(part + ((rb * MB + mb) << 8) + lane * 4) = yacc[mb];
+                    stc4<COH>(a.stepbuf, part + ((rb * MB + mb) << 8) + lane * 4, yacc[mb]);
             }
         }
     }
@@ -187,7 +210,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bid, fl
 #pragma unroll
         for (int w = 1; w < STEP_NW; ++w)
             s += *reinterpret_cast<const f32x4*>(wred + ((w * nrb * MB + slot) << 8) + ln * 4);
-        *reinterpret_cast<f32x4*>(part + (slot << 8) + ln * 4) = s;
+        stc4<COH>(a.stepbuf, part + (slot << 8) + ln * 4, s);
     }
 }
 

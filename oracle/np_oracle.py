@@ -486,6 +486,7 @@ def train_candidate(conf, hp: Hyper, params, train, dev, order=None, seed=0, eta
             loss, dlog, preds = ce_loss(logits, labels)
             if hp.multitask:    # train_searchable/ntu.py:60-61; unimodal CE terms carry no grad
                 preds = predict(logits + feats["vlogit"] + feats["slogit"])
+                loss = (loss + ce_loss(feats["vlogit"], labels)[0]) + ce_loss(feats["slogit"], labels)[0]
             grads = backward(params, hp, cache, dlog)
             bn_update_running(params, hp, cache)
             adam_step(params, grads, st, float(etas[gstep]), hp, keys)
@@ -505,6 +506,7 @@ def train_candidate(conf, hp: Hyper, params, train, dev, order=None, seed=0, eta
             loss, _, preds = ce_loss(logits, labels)
             if hp.multitask:
                 preds = predict(logits + feats["vlogit"] + feats["slogit"])
+                loss = (loss + ce_loss(feats["vlogit"], labels)[0]) + ce_loss(feats["slogit"], labels)[0]
             run_loss += float(loss) * len(idx)
             run_corr += int((preds == labels).sum())
         dev_acc = run_corr / N_dev

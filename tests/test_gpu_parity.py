@@ -226,6 +226,9 @@ def test_multitask_and_alphas_vs_reference(dev):
     assert abs(best_dev_accuracy(stats[0], 128) - float(g["mt_acc"])) <= 1.0 / 128 + 1e-9
     for e in range(3):
         assert abs(stats["dev_corrects"][0, e] / 128 - g["mt_hist"][2 * e + 1][2]) <= 1.0 / 128 + 1e-4
+        # 3-term multitask loss as the reference prints it (train_searchable/ntu.py:60-61,72-75)
+        assert abs(stats["train_loss_sum"][0, e] / 256 - g["mt_hist"][2 * e][1]) < 2e-3
+        assert abs(stats["dev_loss_sum"][0, e] / 128 - g["mt_hist"][2 * e + 1][1]) < 2e-3
     pop.close()
     ohp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=3, alphas=True)
     conf = np.array(CONFS["l3"])

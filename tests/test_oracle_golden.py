@@ -156,6 +156,9 @@ def test_multitask_and_alphas_runs(golden_dir):
     for ep, h in enumerate(hist):       # printed accuracies use the summed-logit argmax
         assert abs(h["train_acc"] - g["mt_hist"][2 * ep][2]) < 1e-4
         assert abs(h["dev_acc"] - g["mt_hist"][2 * ep + 1][2]) < 1e-4
+        # the printed Loss is the 3-term multitask loss CE(central) + CE(visual) + CE(skeleton) (train_searchable/ntu.py:60-61)
+        assert abs(h["train_loss"] - g["mt_hist"][2 * ep][1]) < 2e-4
+        assert abs(h["dev_loss"] - g["mt_hist"][2 * ep + 1][1]) < 2e-4
     hp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=3, alphas=True)
     conf = np.array(CONFS["l3"])
     params = O.init_params(conf, hp, 21)
