@@ -6,7 +6,14 @@ One "step" = one ``train_sampled_models`` call (the reference's plug-in boundary
 eval over N_dev}, gather the best dev accuracies.  Workload at N=1 = BASELINE configs[1]: NTU found conf 4
 (``--inner_representation_size 128 --batchnorm``), precomputed (synthetic, planted-signal) NTU-shaped taps
 stored bf16, B=16, drpt 0.5, E=10, N_train=10,000, N_dev=5,600.  Feature tables are
-resident in HBM before the timed region.  Weak scaling: every rank trains --pop candidates.
+resident in HBM before the timed region.  Weak scaling (default): every rank trains --pop candidates.
+
+Strong scaling of a SMALL population — what the search actually issues (models/searchable.py:90,120: sequential calls of
+<= num_samples configurations) — is `--total-pop K`: K candidates in total, sharded over the ranks.  Named workloads:
+  --workload c1   BASELINE configs[1] (default): conf 4, R=128, --batchnorm, B=16 (weak scaling, --pop per GPU)
+  --workload c2   BASELINE configs[2]: 16 sampled L=4 confs (np.random.seed(0)), search-script defaults R=16, B=20, no BN,
+                  drpt 0.5, E=10, total population 16 (strong scaling)
+  --workload c3   one call of BASELINE configs[3]: 50 sampled confs, same defaults, total population 50 (strong scaling)
 
 Launch: ``python bench.py --gpus 1`` or
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
@@ -30,7 +37,7 @@ CONF4 = [[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]]      # main_found_ntu.py:18
 HBM_PEAK_GBS = 8000.0                                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def synth_tables(n_train, n_dev, device, dtype, snr=0.15, C=60):
+def synth_tables(n_train, n_dev, device, dtype, snr=0.12, C=60):
     """Planted-signal NTU-shaped taps x = relu(snr*mu[label] + eps) generated on the GPU (same on every rank)."""
     import mfas_amd as M
     g = torch.Generator(device=device)
@@ -106,11 +113,36 @@ def cpu_baseline(train, dev, args, budget_s=24.0):
         if best is None or t_cand < best[0]:
             best = (t_cand, nt, t_step, t_row, steps, rows)
     t_cand, nt, t_step, t_row, steps, rows = best
-    return {"value": 1.0 / t_cand, "unit": "candidates/s", "cores": nt, "kind": "port",
-            "sample": f"{steps} train steps + {rows} dev rows of conf-4 R={args.R} B={args.batch} f32 (numpy oracle, "
-                      f"BLAS threads tried {tried}, best {nt}; host has {os.cpu_count()} logical cores), extrapolated to "
-                      f"E={args.epochs} x ({nb} steps + {len(dev)} dev rows): {t_step * 1e3:.2f} ms/step, "
-                      f"{t_row * 1e6:.1f} us/dev-row"}
+    out = {"value": 1.0 / t_cand, "unit": "candidates/s", "cores": nt, "kind": "port",
+           "sample": f"{steps} train steps + {rows} dev rows of conf-4 R={args.R} B={args.batch} f32 (numpy oracle, "
+                     f"BLAS threads tried {tried}, best {nt}; host has {os.cpu_count()} logical cores), extrapolated to "
+                     f"E={args.epochs} x ({nb} steps + {len(dev)} dev rows): {t_step * 1e3:.2f} ms/step, "
+                     f"{t_row * 1e6:.1f} us/dev-row"}
+    # the PyTorch-CPU eager restatement of the reference step sequence (oracle/torch_restatement.py),
+    # ONE FULL epoch (all train batches + the whole dev table) on all host cores and, for comparison, on 8 threads
+    try:
+        import torch as _t
+        from oracle import torch_restatement as TR
+        full_tr = {k: v.float().cpu() for k, v in train.taps.items()}
+        full_tr = {k: v[:, :train.widths[k]].contiguous() for k, v in full_tr.items()}
+        full_tr["label"] = train.label.cpu().long()
+        full_dv = {k: v.float().cpu()[:, :dev.widths[k]].contiguous() for k, v in dev.taps.items()}
+        full_dv["label"] = dev.label.cpu().long()
+        runs = []
+        for nt_t in sorted({min(8, os.cpu_count() or 1), os.cpu_count() or 1}):
+            sec, acc, used = TR.time_candidate(full_tr, full_dv, CONF4, args.R, args.batch, not args.no_bn, args.drpt,
+                                               epochs_timed=1, threads=nt_t)
+            runs.append({"threads": used, "s_per_epoch": sec, "cand_per_s": 1.0 / (sec * args.epochs)})
+        bestt = max(runs, key=lambda r: r["cand_per_s"])
+        out["torch_eager"] = {"value": bestt["cand_per_s"], "unit": "candidates/s", "cores": bestt["threads"], "kind": "port",
+                              "runs": runs,
+                              "sample": f"1 full epoch ({nb} train steps of B={args.batch} + {len(dev)} dev rows) of conf-4 R={args.R} in "
+                                        f"PyTorch-CPU eager (restatement of the reference loop incl. its per-step optimizer "
+                                        f"state_dict round trip), x E={args.epochs}; host has {os.cpu_count()} logical cores"}
+        _t.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    except Exception as e:   # the baseline is a report, never a reason to lose the bench line
+        out["torch_eager"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -132,7 +164,13 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="no HIP-event sampling of the dominant kernel (roofline fields become null)")
     ap.add_argument("--no-bn", action="store_true", help="search-script defaults: no BatchNorm")
     ap.add_argument("--mixed-confs", action="store_true", help="population of sampled L=1..4 confs instead of conf 4")
+    ap.add_argument("--total-pop", type=int, default=0, help="strong scaling: this many candidates IN TOTAL, sharded over the ranks")
+    ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c3"], help="named BASELINE workloads (see the module docstring)")
+    ap.add_argument("--snr", type=float, default=0.12, help="planted-signal strength of the synthetic taps (BASELINE.md section 2: 0.12)")
     a = ap.parse_args()
+    if a.workload in ("c2", "c3"):      # search-script defaults (main_searchable_ntu.py:26-47)
+        a.R, a.batch, a.no_bn = 16, 20, True
+        a.total_pop = a.total_pop or (16 if a.workload == "c2" else 50)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,18 +190,23 @@ def main():
     from mfas_amd import ntu_searchable as NS
 
     dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
-    train, dev = synth_tables(a.n_train, a.n_dev, device, dtype)
+    train, dev = synth_tables(a.n_train, a.n_dev, device, dtype, snr=a.snr)
     loaders = {"train": M.FeatureLoader(train, a.batch, shuffle=True), "dev": M.FeatureLoader(dev, a.batch, shuffle=False)}
     args = SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=a.drpt, inner_representation_size=a.R,
                            batchnorm=not a.no_bn, alphas=False, multitask=False, weightsharing=False, batchsize=a.batch,
                            eta_max=1e-3, eta_min=1e-6, Ti=1, Tm=2, use_dataparallel=False, verbose=False,
                            epochs=a.epochs, engine_init="device", engine_profile=not a.no_profile,
                            engine_chunk_cols=a.chunk_cols)
-    confs = [np.array(CONF4) for _ in range(a.pop * world)]
+    total = a.total_pop if a.total_pop > 0 else a.pop * world
+    confs = [np.array(CONF4) for _ in range(total)]
     if a.mixed_confs:
         rng = np.random.default_rng(0)
         confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1)
-                 for L in rng.integers(1, 5, a.pop * world)]
+                 for L in rng.integers(1, 5, total)]
+    if a.workload in ("c2", "c3"):      # L=4 configurations sampled like the controller does at progression level 3
+        np.random.seed(0)
+        layer = NS.get_possible_layer_configurations(0)
+        confs = [np.array([layer[i] for i in np.random.choice(len(layer), 4)]) for _ in range(total)]
     torch.manual_seed(0)
 
     def barrier():
@@ -181,31 +224,39 @@ def main():
         accs = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, loaders, args, device)
     barrier()
     dt = time.perf_counter() - t0
+    rank_dt = [dt]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device if a.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_dt = [float(x.item()) for x in allt]      # per-rank seconds around the same K timed steps
+        dt = max(rank_dt)
 
     if rank == 0:
         n_launch = sum(p[0] for p in NS.PROFILE)
         ms = sum(p[1] for p in NS.PROFILE)
         bytes_per_launch = NS.PROFILE[-1][2] if NS.PROFILE else 0.0
         achieved = bytes_per_launch / (ms / n_launch * 1e-3) / 1e9 if n_launch else None
-        total = a.pop * world * a.steps
-        traffic = None      # HBM bytes per launch from the committed PMC passes of this same workload (profiles/)
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tp) and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1:
-            try:
-                traffic = json.load(open(tp))["per_launch"]["total_bytes"]
-            except Exception:
-                traffic = None
-        mfma = None         # MfmaUtil (%) of the same kernel from the committed PMC pass (tools/pmc_mfma.py)
-        mp = os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")
-        if os.path.exists(mp) and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1:
-            try:
-                mfma = json.load(open(mp))["k_step"]["MfmaUtil"]["mean"]
-            except Exception:
-                mfma = None
+        total_trained = total * a.steps
+        # HBM traffic / MfmaUtil need rocprofv3 --pmc passes (separate runs, MI355X_MICROARCH.md): they are NOT measured in this
+        # process.  When the committed passes of exactly this workload exist they are quoted WITH their source; else null.
+        traffic = mfma = traffic_src = mfma_src = None
+        headline = a.total_pop == 0 and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1 and not a.mixed_confs
+        for tag in ("r02", "r01"):
+            tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+            if headline and traffic is None and os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp))["per_launch"]["total_bytes"]
+                    traffic_src = f"profiles/{tag}_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
+                except Exception:
+                    traffic = None
+            mp = os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma.json")
+            if headline and mfma is None and os.path.exists(mp):
+                try:
+                    mfma = json.load(open(mp))["k_step"]["MfmaUtil"]["mean"]
+                    mfma_src = f"profiles/{tag}_pmc_mfma.json (separate rocprofv3 --pmc pass; not measured in this run)"
+                except Exception:
+                    mfma = None
         stream = None       # live ceiling of THIS box for the sweep's access pattern (no compute), same units as `achieved`
         if world == 1:
             import ctypes
@@ -215,21 +266,28 @@ def main():
                 if _lib.lib().mfas_stream_probe(400 << 20, 10, ctypes.byref(gb)) == 0:
                     stream = gb.value
         line = {
-            "metric": "candidate-archs trained/sec (NTU inner loop)", "value": total / dt, "unit": "candidates/s",
+            "metric": "candidate-archs trained/sec (NTU inner loop)", "value": total_trained / dt, "unit": "candidates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if a.total_pop > 0 else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"NTU found conf 4, R={a.R}, batchnorm, drpt {a.drpt}, B={a.batch}, E={a.epochs}, "
-                                   f"N_train={a.n_train}, N_dev={a.n_dev}, {a.dtype} precomputed taps, f32 state/compute",
-                       "candidates_per_gpu_per_step": a.pop, "parallelism": f"population-sharded x{world}",
+            "config": {"workload": (f"BASELINE configs[{ {'c1': 1, 'c2': 2, 'c3': 3}[a.workload] }]: "
+                                    + ("NTU found conf 4" if a.workload == "c1" and not a.mixed_confs else
+                                       "sampled L=1..4 confs" if a.workload == "c1" else f"{total} sampled L=4 confs (np.random.seed(0))")
+                                    + f", R={a.R}, {'no batchnorm' if a.no_bn else 'batchnorm'}, drpt {a.drpt}, B={a.batch}, E={a.epochs}, "
+                                      f"N_train={a.n_train}, N_dev={a.n_dev}, snr {a.snr}, {a.dtype} precomputed taps, f32 state/compute"),
+                       "candidates_total_per_step": total,
+                       "candidates_per_gpu_per_step": (a.pop if a.total_pop == 0 else f"{total // world}..{-(-total // world)}"),
+                       "parallelism": f"population-sharded x{world}",
+                       "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (a.backend if world > 1 else None),
+                       "rank_seconds": rank_dt,
                        "mean_best_dev_acc": float(np.mean(accs))},
             "roofline": {"bound": "hbm", "kernel": "k_step (chain blocks of one group + sweep blocks of the other: dW, Adam, next-step forward)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": n_launch, "avg_launch_us": (ms / n_launch * 1e3) if n_launch else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "stream_ceiling": stream, "frac_of_stream": (achieved / stream) if (achieved and stream) else None,
-                         "mfma_util_pct": mfma},
+                         "mfma_util_pct_from_profile": mfma, "mfma_util_source": mfma_src},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(train, dev, a)

@@ -407,8 +407,17 @@ def _train_weightsharing(confs, wanted, searchable_type, train_l, dev_l, args, d
         pop.set_params(0, m.flat_params())
         sched = LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, N_tr / B)
         order = make_order(N_tr, E, train_l.shuffle, seed_base + 1 + 1000 * i, device)
+        if getattr(args, "verbose", False):
+            print("Now training: ")
+            print(confs[i])
         stats, _ = pop.train(train_l.table, dev_l.table, E, sched.eta_table(E * nb), order=order,
                              snapshot_best=True)
+        if getattr(args, "verbose", False):
+            for e in range(E):
+                print("train Loss: {:.4f} Acc: {:.4f}".format(stats["train_loss_sum"][0, e] / N_tr,
+                                                              stats["train_corrects"][0, e] / N_tr))
+                print("dev Loss: {:.4f} Acc: {:.4f}".format(stats["dev_loss_sum"][0, e] / N_dev,
+                                                            stats["dev_corrects"][0, e] / N_dev))
         m.load_flat(pop.get_params(0))
         _bump_bn_counters(m, E * nb)
         pop.close()

@@ -498,21 +498,30 @@ def train_candidate(conf, hp: Hyper, params, train, dev, order=None, seed=0, eta
         tr_loss, tr_acc = run_loss / N_tr, run_corr / N_tr
         # ---- dev phase
         run_loss, run_corr = 0.0, 0
+        margins = []
         for bi in range(nb_dev):
             idx = np.arange(bi * B, min((bi + 1) * B, N_dev))
             feats = _batch(dev, idx)
             labels = dev["label"][idx]
             logits, _ = forward(params, conf, hp, feats, False)
             loss, _, preds = ce_loss(logits, labels)
+            dec = logits
             if hp.multitask:
-                preds = predict(logits + feats["vlogit"] + feats["slogit"])
+                dec = logits + feats["vlogit"] + feats["slogit"]
+                preds = predict(dec)
                 loss = (loss + ce_loss(feats["vlogit"], labels)[0]) + ce_loss(feats["slogit"], labels)[0]
             run_loss += float(loss) * len(idx)
             run_corr += int((preds == labels).sum())
+            if history is not None:      # decision margins: |score of the true class - best other score| per dev sample
+                d = np.array(dec, np.float64)
+                own = d[np.arange(len(idx)), labels].copy()
+                d[np.arange(len(idx)), labels] = -np.inf
+                margins.append(np.abs(own - d.max(1)))
         dev_acc = run_corr / N_dev
         if history is not None:
             history.append(dict(train_loss=tr_loss, train_acc=tr_acc,
-                                dev_loss=run_loss / N_dev, dev_acc=dev_acc, dev_corrects=run_corr))
+                                dev_loss=run_loss / N_dev, dev_acc=dev_acc, dev_corrects=run_corr,
+                                dev_margins=np.sort(np.concatenate(margins))[:8]))
         if dev_acc > best:
             best = dev_acc
     return best

@@ -4,9 +4,13 @@ deterministic mode, 3 epochs) against the unchanged reference (goldens G13, G14)
 At this size the reference is not reproducible against ITSELF: changing only the BLAS thread count moves its best dev
 accuracy over 0.9830..0.9861 (G13: per-step losses differ by 1e-4 after ONE Adam step, whose update is sign-like, and by
 1e-2 after ten), and a 1e-7 relative perturbation of the initial weight matrices moves its epoch-0 train loss over
-1.94..2.08 and dev accuracy over 0.940..0.956 (G14, 16 starts).  A single trajectory can only be gated on that envelope;
+1.94..2.08 and dev accuracy over 0.940..0.956 (G14).  A single trajectory can only be gated on that envelope;
 the sharp statement is distributional: the reference, the oracle and the engine, run from the SAME perturbed starts, must
-agree in the MEAN of every epoch statistic within the standard error (accuracies: + the north_star's 0.1 %)."""
+agree in the MEAN of every epoch statistic within the standard error (accuracies: + the north_star's 0.1 %).
+The remedy for chaos is samples, not a wider gate: G14 holds 64 starts of the reference and the engine runs all 64
+(3 s.e. = 0.05 % on the best dev accuracy, so the gate is +-0.15 %); G14m repeats the experiment in the SENSITIVE regime
+(snr 0.10: dev accuracy 0.69 instead of a saturated 0.98), and G15 is the bench workload itself (dropout 0.5, shuffled,
+E=10) gated on the mean best dev accuracy over 64 engine seeds vs 16 reference seeds."""
 import numpy as np
 import pytest
 
@@ -19,13 +23,20 @@ HP = O.Hyper(R=128, B=16, bn=True, drpt=0.0, epochs=3)
 NAMES = [f"{ph} {q} e{e}" for e in range(3) for ph in ("train", "dev") for q in ("loss", "acc")] + ["best dev acc"]
 
 
-@pytest.fixture(scope="module")
-def tables():
-    return O.synth_table(10000, 1, snr=0.15, quant="bf16"), O.synth_table(5600, 2, snr=0.15, quant="bf16")
+VARIANTS = {"saturated": ("g14_fullsize_envelope.npz", 0.15), "midrange": ("g14m_fullsize_midrange.npz", 0.10)}
+_TABLES = {}
 
 
-def g14_stats():
-    g = golden("g14_fullsize_envelope.npz")
+def tables_for(variant):
+    snr = VARIANTS[variant][1]
+    if snr not in _TABLES:
+        _TABLES[snr] = (O.synth_table(10000, 1, snr=snr, quant="bf16"), O.synth_table(5600, 2, snr=snr, quant="bf16"))
+    return _TABLES[snr]
+
+
+def g14_stats(variant="saturated"):
+    g = golden(VARIANTS[variant][0])
+    assert float(g["snr"][0]) == VARIANTS[variant][1]
     H = g["hist"]                                   # [trial][2*epoch + phase] = (phase, loss, acc)
     return np.concatenate([H[:, :, 1:].reshape(len(H), -1), g["best_acc"][:, None]], 1)   # [trial][13], order = NAMES
 
@@ -38,12 +49,12 @@ def row_of(train_loss, train_acc, dev_loss, dev_acc, best):
 
 
 def check_ensemble(mine, ref):
-    """mine, ref: [trial][13].  Means within 3.5 standard errors (+0.1 % on accuracies), spreads within x3, every sample
+    """mine, ref: [trial][13].  Means within 3 standard errors (+0.1 % on accuracies), spreads within x3, every sample
     inside the reference's range widened by its own width."""
     for j, nm in enumerate(NAMES):
         sr, sm = ref[:, j].std(ddof=1), mine[:, j].std(ddof=1)
         se = np.sqrt(sr ** 2 / len(ref) + sm ** 2 / len(mine))
-        budget = 3.5 * se + (TOL if "acc" in nm else 0.0)
+        budget = 3.0 * se + (TOL if "acc" in nm else 0.0)
         assert abs(mine[:, j].mean() - ref[:, j].mean()) <= budget, (nm, mine[:, j].mean(), ref[:, j].mean(), se)
         assert sm <= 3.0 * sr + 1e-4, (nm, "spread", sm, sr)
         lo, hi = ref[:, j].min(), ref[:, j].max()
@@ -56,30 +67,36 @@ def test_reference_is_not_reproducible_against_itself():
     g13 = golden("g13_fullsize.npz")
     assert np.ptp(g13["best_acc"]) > 0.002                      # 4 thread counts: 0.9830 .. 0.9861
     r = g14_stats()
-    assert r.shape == (16, 13)
+    assert r.shape == (64, 13)
     assert np.ptp(r[:, 3]) > 0.005 and np.ptp(r[:, 12]) > 0.002  # epoch-0 dev acc, best dev acc
     np.testing.assert_allclose(r[0, :12].reshape(6, 2), g13["hist"][2][:, 1:], atol=2e-3)   # trial 0 == G13's 4-thread run
+    # with 64 + 64 samples the gate on the best dev accuracy is 3 s.e. + 0.1 % < 0.2 %
+    assert 3.0 * r[:, 12].std(ddof=1) * np.sqrt(2.0 / 64) + TOL < 0.002
+    m = g14_stats("midrange")
+    assert m.shape == (64, 13) and 0.5 < m[:, 12].mean() < 0.8    # the sensitive regime
 
 
-def test_oracle_fullsize_vs_reference(tables):
-    ttr, tdv = tables
+@pytest.mark.parametrize("variant,ntrial", [("saturated", 4), ("midrange", 3)])
+def test_oracle_fullsize_vs_reference(variant, ntrial):
+    ttr, tdv = tables_for(variant)
     rows = []
-    for trial in range(6):
+    for trial in range(ntrial):
         hist = []
         best = O.train_candidate(CONF, HP, O.perturb_params(O.init_params(CONF, HP, 77), trial), ttr, tdv, history=hist)
         rows.append(row_of([h["train_loss"] for h in hist], [h["train_acc"] for h in hist],
                            [h["dev_loss"] for h in hist], [h["dev_acc"] for h in hist], best))
-    check_ensemble(np.array(rows), g14_stats())
+    check_ensemble(np.array(rows), g14_stats(variant))
 
 
 @pytest.mark.gpu
-def test_engine_fullsize_vs_reference(tables):
+@pytest.mark.parametrize("variant", ["saturated", "midrange"])
+def test_engine_fullsize_vs_reference(variant):
     torch = pytest.importorskip("torch")
     import mfas_amd as M
-    ttr, tdv = tables
+    ttr, tdv = tables_for(variant)
     dev = torch.device("cuda:0")
     ta, tb = M.FeatureTable.from_numpy(ttr, dev, torch.bfloat16), M.FeatureTable.from_numpy(tdv, dev, torch.bfloat16)
-    NT = 16
+    NT = 64
     # all starts train as ONE lock-step population (each candidate is independent of its neighbours)
     pop = M.Population(engine_hyper(HP), [CONF] * NT, dev)
     for trial in range(NT):
@@ -89,4 +106,46 @@ def test_engine_fullsize_vs_reference(tables):
     rows = [row_of(s["train_loss_sum"] / 10000, s["train_corrects"] / 10000, s["dev_loss_sum"] / 5600,
                    s["dev_corrects"] / 5600, M.best_dev_accuracy(s, 5600)) for s in stats]
     pop.close()
-    check_ensemble(np.array(rows), g14_stats())
+    check_ensemble(np.array(rows), g14_stats(variant))
+
+
+@pytest.mark.gpu
+def test_engine_bench_workload_vs_reference():
+    """G15: BASELINE configs[1] exactly as bench.py runs it (conf 4, R=128, BN, drpt 0.5, shuffled, B=16, E=10,
+    N=10,000/5,600, bf16-rounded taps; snr 0.10 so that the best dev accuracy sits at 0.66) through the unchanged reference
+    for 16 seeds (train_searchable/ntu.py:14-89).  The engine's dropout and shuffle streams are its own, so the gate is
+    statistical: mean best dev accuracy over 64 engine seeds (4 populations of 16, each with its own epoch orders; the
+    first 16 initial states are the reference's own) within 3 s.e. + 0.1 %; the per-epoch dev accuracies likewise."""
+    torch = pytest.importorskip("torch")
+    import mfas_amd as M
+    g = golden("g15_bench_workload.npz")
+    N, Nd, snr, R, B, E, bn, drpt = g["meta"]
+    N, Nd, R, B, E = int(N), int(Nd), int(R), int(B), int(E)
+    hp = O.Hyper(R=R, B=B, bn=bool(bn), drpt=float(drpt), epochs=E)
+    ttr, tdv = O.synth_table(N, 1, snr=float(snr), quant="bf16"), O.synth_table(Nd, 2, snr=float(snr), quant="bf16")
+    dev = torch.device("cuda:0")
+    ta, tb = M.FeatureTable.from_numpy(ttr, dev, torch.bfloat16), M.FeatureTable.from_numpy(tdv, dev, torch.bfloat16)
+    best, per_epoch = [], []
+    for grp in range(4):
+        seeds = list(range(16 * grp, 16 * grp + 16))
+        pop = M.Population(engine_hyper(hp), [CONF] * 16, dev, drop_seeds=[7000 + s for s in seeds])
+        pop.init([3000 + 10 * s for s in seeds])          # == O.init_params(conf, hp, 3000 + 10 * seed): the reference's starts
+        order = M.ntu_searchable.make_order(N, E, True, 900 + grp, dev)
+        stats, status = pop.train(ta, tb, E, etas_for(hp, N), order=order)
+        assert not status.any()
+        best += [M.best_dev_accuracy(s, Nd) for s in stats]
+        per_epoch += [s["dev_corrects"] / Nd for s in stats]
+        pop.close()
+    best, per_epoch = np.array(best), np.array(per_epoch)
+    ref_best = g["best_acc"]
+    ref_epoch = g["hist"][:, 1::2, 2]                      # [seed][epoch] dev accuracy as printed (4 decimals)
+    assert 0.5 < ref_best.mean() < 0.8                     # mid-range: the regime where accuracy is sensitive
+
+    def gate(mine, ref, what):
+        se = np.sqrt(ref.std(ddof=1) ** 2 / len(ref) + mine.std(ddof=1) ** 2 / len(mine))
+        assert abs(mine.mean() - ref.mean()) <= 3.0 * se + TOL, (what, mine.mean(), ref.mean(), se)
+        assert mine.std(ddof=1) <= 2.5 * ref.std(ddof=1) + 1e-3, (what, "spread", mine.std(ddof=1), ref.std(ddof=1))
+
+    gate(best, ref_best, "best dev acc")
+    for e in range(E):
+        gate(per_epoch[:, e], ref_epoch[:, e], f"dev acc epoch {e}")

@@ -90,10 +90,27 @@ def test_eval_forward_vs_reference_golden(dev):
 
 
 # ---------------------------------------------------------------------------------------- k train steps vs oracle AND reference golden
+def _row_block_fracs(a, v, rtol, atol):
+    """Fraction of out-of-tolerance elements per 16-row block of a weight matrix (the engine's tile rows)."""
+    bad = np.abs(a - v) > atol + rtol * np.abs(v)
+    nrb = -(-a.shape[0] // 16)
+    return np.array([bad[16 * rb:16 * rb + 16].mean() for rb in range(nrb)])
+
+
 def check_state(pop, k, params, st, steps, lr=1e-3, tag=""):
+    """Parameters / Adam moments after `steps` train steps vs the oracle.  Adam's first steps are sign-like (dw = +-lr for every
+    element whatever the size of its gradient), so elements whose gradient is round-off sized may legitimately land up to
+    lr * steps apart; everything else has to agree to 1e-4.  Three layers of bounds:
+      * bulk:       >= 97 % of the elements (94 % for small vectors) within rtol 1e-4;
+      * tail:       >= 99.7 % within rtol 1e-2 (+ the same atol) — the sign-flip elements are few AND the rest is tight;
+      * max:        every element within lr * steps;
+      * structure:  no 16-row tile block of a weight matrix may hold more than 4x its share of the out-of-tolerance elements
+                    (an indexing error confined to one tile row cannot hide inside the global allowance)."""
+    import os
     got = pop.get_state_dict(k, 0)
     gm = pop.get_state_dict(k, 1)
     gv = pop.get_state_dict(k, 2)
+    log = os.environ.get("MFAS_CHECK_STATS")
     for key, v in params.items():
         if key.startswith("alphas") and key not in st.m:
             continue
@@ -101,7 +118,19 @@ def check_state(pop, k, params, st, steps, lr=1e-3, tag=""):
         lim = 0.03 if a.size >= 1000 else 0.06          # small vectors: a handful of round-off-level elements
         # BN running statistics are an EMA of batch moments: they inherit the weights' allowed 1e-4 deviations of every step
         rtol = 1e-3 if key.endswith(("running_mean", "running_var")) else 1e-4
-        assert frac_bad(a, v, rtol, 2e-6 * steps) <= lim, (tag, key, frac_bad(a, v, rtol, 2e-6 * steps))
+        atol = 2e-6 * steps
+        fb = frac_bad(a, v, rtol, atol)
+        ft = frac_bad(a, v, 1e-2, atol)
+        rbmax = 0.0
+        if a.ndim == 2 and a.shape[0] >= 32 and a.size >= 4096:
+            rbf = _row_block_fracs(a, v, rtol, atol)
+            rbmax = float(rbf.max())
+            assert rbmax <= max(4.0 * lim, 4.0 * fb + 0.02), (tag, key, "row-block", rbf.round(3).tolist())
+        if log:
+            with open(log, "a") as f:
+                f.write(f"{tag} {key} n={a.size} bulk={fb:.5f} tail={ft:.5f} rbmax={rbmax:.5f} max={np.abs(a - v).max():.3g}\n")
+        assert fb <= lim, (tag, key, fb)
+        assert ft <= (0.003 if a.size >= 1000 else 0.03), (tag, key, "tail", ft)
         assert np.abs(a - v).max() <= lr * steps, (tag, key)
     for key in st.m:
         # small vectors: a ReLU/dropout kink flipped by round-off moves one sample's share of a column sum (1/B), so a
@@ -208,9 +237,23 @@ def test_population_vs_reference(dev, B):
     stats, _ = pop.train(table(ttr, dev), table(tdv, dev), 3, etas_for(ohp, 256))
     from mfas_amd import best_dev_accuracy
     accs = [best_dev_accuracy(stats[k], 128) for k in range(4)]
-    np.testing.assert_allclose(accs, g[f"B{B}/accs"], atol=1.0 / 128 + 1e-9)   # <= 1 sample of 128
-    assert sum(a == w for a, w in zip(accs, g[f"B{B}/accs"])) >= 3
     pop.close()
+    # Per-epoch dev correct counts must equal the reference's (the oracle reproduces the reference's accuracies exactly,
+    # tests/test_oracle_golden.py) EXCEPT where a dev sample is a numerical tie: the engine's weights agree with the
+    # oracle's to ~1e-4 relative after 48 Adam steps, which moves logits by ~1e-3, so a sample whose decision margin
+    # |logit[label] - best other logit| in the ORACLE run is below 5e-3 may fall on either side.  A count may differ by at
+    # most the number of such near-tie samples of that epoch — and that number is asserted to be small.
+    for k, c in enumerate(confs):
+        hist = []
+        want = O.train_candidate(c, ohp, O.init_params(c, ohp, 9 + k), ttr, tdv, history=hist)
+        assert want == pytest.approx(float(g[f"B{B}/accs"][k]), abs=1e-12)          # oracle == reference
+        for e, h in enumerate(hist):
+            ties = int((h["dev_margins"] < 5e-3).sum())
+            assert ties <= 2, (k, e, h["dev_margins"])
+            assert abs(int(stats["dev_corrects"][k, e]) - h["dev_corrects"]) <= ties, (k, e, int(stats["dev_corrects"][k, e]), h["dev_corrects"], h["dev_margins"][:3])
+        if all(int((h["dev_margins"] < 5e-3).sum()) == 0 for h in hist):
+            assert accs[k] == float(g[f"B{B}/accs"][k]), (k, accs[k])
+    np.testing.assert_allclose(accs, g[f"B{B}/accs"], atol=1.0 / 128 + 1e-9)   # in any case <= 1 sample of 128
 
 
 def test_multitask_and_alphas_vs_reference(dev):

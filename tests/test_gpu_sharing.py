@@ -1,0 +1,143 @@
+"""SURVEY §8(f) next#4 against the UNCHANGED reference: --weightsharing (golden G16: train_sampled_models with
+get/set_central_states, ntu_searchable.py:74-75,91-92,123-174) and main_found_ntu.train_model's two-phase schedule
+(golden G17: main_found_ntu.py:94-157, multitask and single-task).  Deterministic mode (drpt = 0 + BN, unshuffled), so
+accuracies are compared sample-exact (up to numerical ties) and parameters element-wise."""
+import contextlib
+import io
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from oracle import np_oracle as O
+from tests.helpers import CONFS, frac_bad, golden
+
+pytestmark = pytest.mark.gpu
+HIST_RE = r"(train|dev) Loss: ([0-9.eE+naninf-]+) Acc: ([0-9.eE+naninf-]+)"
+
+
+def mkargs(**kw):
+    a = dict(vid_len=(8, 32), num_outputs=60, drpt=0.0, inner_representation_size=16, batchnorm=True,
+             alphas=False, multitask=False, weightsharing=False, batchsize=16, eta_max=1e-3, eta_min=1e-6,
+             Ti=1, Tm=2, use_dataparallel=False, verbose=True, epochs=3, test_cp="", checkpointdir="")
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def parse_hist(text):
+    return np.array([(0 if m.group(1) == "train" else 1, float(m.group(2)), float(m.group(3)))
+                     for m in re.finditer(HIST_RE, text)], np.float64)
+
+
+def want_of(g, key):
+    """Fixture tensors are stored whole (<= 4096 elements) or as a strided sample + float64 sum (tests/golden/make_golden.put)."""
+    if key in g:
+        return g[key], None
+    return g[key + "#s"], float(g[key + "#sum"])
+
+
+def close(got, want, wsum, steps, what, lr=1e-3):
+    got = np.asarray(got, np.float64)
+    if wsum is not None:          # sampled fixture: compare the same strided sample and the sum
+        assert abs(got.sum() - wsum) <= 1e-3 * max(1.0, np.abs(got).sum() * 1e-2), (what, got.sum(), wsum)
+        got = O.sample_view(got.astype(np.float32)).astype(np.float64)
+    want = np.asarray(want, np.float64).reshape(got.shape)
+    assert frac_bad(got, want, 2e-3, 1e-5 * steps) <= 0.04, (what, frac_bad(got, want, 2e-3, 1e-5 * steps))
+    assert np.abs(got - want).max() <= lr * steps + 1e-6, (what, np.abs(got - want).max())
+
+
+class Factory:
+    """searchable_type stand-in (a plain callable in the reference, ntu_searchable.py:44): builds the module and loads the
+    hash-generated parameters the golden run used (seed0 + index)."""
+
+    def __init__(self, seed0):
+        self.seed0, self.n = seed0, 0
+
+    def __call__(self, args, conf):
+        import mfas_amd as M
+        m = M.Searchable_Skeleton_Image_Net(args, conf)
+        hp = O.Hyper(R=args.inner_representation_size, C=args.num_outputs, B=args.batchsize, bn=args.batchnorm,
+                     drpt=args.drpt, multitask=args.multitask)
+        sd = m.state_dict()
+        for k, v in O.init_params(conf, hp, self.seed0 + self.n).items():
+            sd[k].copy_(torch.from_numpy(v))
+        self.n += 1
+        return m
+
+
+def loaders(tabs, dev, B):
+    import mfas_amd as M
+    return {k: M.FeatureLoader(M.FeatureTable.from_numpy(t, dev, torch.float32), B, shuffle=False) for k, t in tabs.items()}
+
+
+def test_weightsharing_vs_reference():
+    import mfas_amd as M
+    dev = torch.device("cuda:0")
+    g = golden("g16_weightsharing.npz")
+    confs = [g[f"conf{i}"] for i in range(4)]
+    ld = loaders({"train": O.synth_table(256, 41, snr=1.5), "dev": O.synth_table(128, 42, snr=1.5)}, dev, 16)
+    args = mkargs(weightsharing=True, epochs=3, verbose=True)
+    shared = {}
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        accs, models = M.train_sampled_models(confs, Factory(50), ld, args, dev, state_dict=shared, return_model=[0, 1, 2, 3])
+    # which cells were published, in the reference's key format "{idx}.L_{in}_{out}.A_{act}"
+    ref_keys = sorted({str(e[1]) for e in g["events"]})
+    assert sorted(shared) == ref_keys, (sorted(shared), ref_keys)
+    # accuracies: candidates 1 and 3 START from cells candidate 0 / 1 trained — a wrong sharing rule changes them grossly
+    np.testing.assert_allclose(accs, g["accs"], atol=2.0 / 128 + 1e-9)
+    hist = parse_hist(buf.getvalue())
+    assert hist.shape == g["hist"].shape
+    np.testing.assert_allclose(hist[:, 1], g["hist"][:, 1], atol=5e-3)          # losses as printed
+    np.testing.assert_allclose(hist[:, 2], g["hist"][:, 2], atol=2.0 / 128 + 1e-4)   # accuracies as printed
+    steps = 3 * 16
+    for name in ref_keys:                # the published state_dict after the last candidate
+        for sub in ("0.weight", "0.bias", "2.weight", "2.bias", "2.running_mean", "2.running_var"):
+            want, wsum = want_of(g, f"shared/{name}/{sub}")
+            close(shared[name][sub].cpu().numpy(), want, wsum, 4 * steps, f"shared/{name}/{sub}")
+    for i, m in enumerate(models):       # every candidate's final (best-epoch) central parameters
+        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        for k in sd:
+            if "num_batches" in k or k.startswith("alphas") or f"final{i}/{k}" not in g and f"final{i}/{k}#s" not in g:
+                continue
+            want, wsum = want_of(g, f"final{i}/{k}")
+            close(sd[k], want, wsum, 4 * steps, f"final{i}/{k}")
+
+
+@pytest.mark.parametrize("mt", [True, False])
+def test_found_two_phase_vs_reference(mt):
+    import mfas_amd as M
+    import main_found_ntu as F
+    dev = torch.device("cuda:0")
+    g = golden("g17_found_twophase.npz")
+    pre = "mt/" if mt else "st/"
+    conf = np.array(CONFS["c0"])
+    tabs = {"train": O.synth_table(256, 61, snr=1.0, with_logits=True), "dev": O.synth_table(128, 62, snr=1.0, with_logits=True),
+            "test": O.synth_table(96, 63, snr=1.0, with_logits=True)}
+    ld = loaders(tabs, dev, 16)
+    args = mkargs(multitask=mt, epochs=3, verbose=True)
+    rmode = Factory(70)(args, conf)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        acc = F.train_model(rmode, conf, ld, args, dev)
+    text = buf.getvalue()
+    hist = parse_hist(text)
+    want = g[pre + "hist"]               # phase 1 (1 epoch) then phase 2 (3 epochs): rows (phase, loss, acc)
+    assert hist.shape == want.shape == (8, 3)
+    np.testing.assert_allclose(hist[:, 1], want[:, 1], atol=6e-3)                 # 3-term loss when multitask
+    tr, dv = hist[:, 0] == 0, hist[:, 0] == 1
+    np.testing.assert_allclose(hist[tr, 2], want[tr, 2], atol=2.0 / 256 + 1e-4)
+    np.testing.assert_allclose(hist[dv, 2], want[dv, 2], atol=2.0 / 128 + 1e-4)
+    interm = float(re.search(r"Intermediate val accuracy: (?:tensor\()?([0-9.]+)", text).group(1))
+    final = float(re.search(r"Final val accuracy: (?:tensor\()?([0-9.]+)", text).group(1))
+    assert abs(interm - float(g[pre + "interm"])) <= 2.0 / 128 + 1e-4
+    assert abs(final - float(g[pre + "final"])) <= 2.0 / 128 + 1e-4
+    assert abs(float(acc) - float(g[pre + "test_acc"])) <= 2.0 / 96 + 1e-9
+    sd = {k: v.detach().cpu().numpy() for k, v in rmode.state_dict().items()}
+    for k in sd:
+        if "num_batches" in k or k.startswith("alphas"):
+            continue
+        w, wsum = want_of(g, pre + "final/" + k)
+        close(sd[k], w, wsum, 4 * 16, pre + k)
