@@ -101,11 +101,13 @@ def check_state(pop, k, params, st, steps, lr=1e-3, tag=""):
     """Parameters / Adam moments after `steps` train steps vs the oracle.  Adam's first steps are sign-like (dw = +-lr for every
     element whatever the size of its gradient), so elements whose gradient is round-off sized may legitimately land up to
     lr * steps apart; everything else has to agree to 1e-4.  Three layers of bounds:
-      * bulk:       >= 97 % of the elements (94 % for small vectors) within rtol 1e-4;
-      * tail:       >= 99.7 % within rtol 1e-2 (+ the same atol) — the sign-flip elements are few AND the rest is tight;
+      * bulk:       >= 99 % of the elements (94 % for vectors under 1000 elements) within rtol 1e-4;
+      * tail:       >= 99.9 % within rtol 1e-2 (+ the same atol) — the sign-flip elements are few AND the rest is tight;
       * max:        every element within lr * steps;
       * structure:  no 16-row tile block of a weight matrix may hold more than 4x its share of the out-of-tolerance elements
-                    (an indexing error confined to one tile row cannot hide inside the global allowance)."""
+                    (an indexing error confined to one tile row cannot hide inside the global allowance).
+    Observed over the 2,300 tensors the GPU suite checks (MFAS_CHECK_STATS=<file> logs them): bulk <= 0.29 %, tail <= 0.03 %,
+    worst row block <= 1.8 % for tensors of >= 1000 elements; the limits sit ~3x above that."""
     import os
     got = pop.get_state_dict(k, 0)
     gm = pop.get_state_dict(k, 1)
@@ -115,7 +117,7 @@ def check_state(pop, k, params, st, steps, lr=1e-3, tag=""):
         if key.startswith("alphas") and key not in st.m:
             continue
         a = got[key].numpy()
-        lim = 0.03 if a.size >= 1000 else 0.06          # small vectors: a handful of round-off-level elements
+        lim = 0.01 if a.size >= 1000 else 0.06          # small vectors: a handful of round-off-level elements
         # BN running statistics are an EMA of batch moments: they inherit the weights' allowed 1e-4 deviations of every step
         rtol = 1e-3 if key.endswith(("running_mean", "running_var")) else 1e-4
         atol = 2e-6 * steps
@@ -125,12 +127,12 @@ def check_state(pop, k, params, st, steps, lr=1e-3, tag=""):
         if a.ndim == 2 and a.shape[0] >= 32 and a.size >= 4096:
             rbf = _row_block_fracs(a, v, rtol, atol)
             rbmax = float(rbf.max())
-            assert rbmax <= max(4.0 * lim, 4.0 * fb + 0.02), (tag, key, "row-block", rbf.round(3).tolist())
+            assert rbmax <= max(0.03, 4.0 * fb + 0.01), (tag, key, "row-block", rbf.round(3).tolist())
         if log:
             with open(log, "a") as f:
                 f.write(f"{tag} {key} n={a.size} bulk={fb:.5f} tail={ft:.5f} rbmax={rbmax:.5f} max={np.abs(a - v).max():.3g}\n")
         assert fb <= lim, (tag, key, fb)
-        assert ft <= (0.003 if a.size >= 1000 else 0.03), (tag, key, "tail", ft)
+        assert ft <= (0.001 if a.size >= 1000 else 0.03), (tag, key, "tail", ft)
         assert np.abs(a - v).max() <= lr * steps, (tag, key)
     for key in st.m:
         # small vectors: a ReLU/dropout kink flipped by round-off moves one sample's share of a column sum (1/B), so a
