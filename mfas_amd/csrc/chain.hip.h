@@ -687,8 +687,49 @@ __device__ __forceinline__ f32x4 pick4(const f32x4 (&t)[MFAS_MAX_CELLS], int i) 
     switch (i) { case 0: return t[0]; case 1: return t[1]; case 2: return t[2]; default: return t[3]; }
 }
 
-template <int MB, bool COH = false>
-__device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds) {
+// Per-launch state of a RESIDENT lean chain (persistent schedule, persist.hip.h): the chain workgroup of a candidate keeps its
+// vector block (+ Adam moments) and the weights it owns — the prev-out tiles OUT_1..OUT_{L-1} and the head tiles, with their
+// moments and transposed images — in LDS for the whole epoch, and its statistics in registers.
+struct LeanRes {
+    double loss;        // running train loss of the epoch (thread CHAIN_THREADS - 64)
+    long long corr;     // running correct count
+    int bad;            // non-finite loss seen
+};
+#define LEAN_OWN_TILES 7   // slots 0..2: OUT_1..OUT_3, slots 3..6: head class blocks 0..3
+
+// LDS layout shared by chain_lean and the resident helpers
+template <int MB>
+struct LeanLds {
+    static constexpr int Bp = MB * 16, Rp = 16, SX = Rp + 4, sav_plane = MFAS_MAX_CELLS * MB * 256;
+    float *xo_l, *dy_l, *lg_l, *rstd_l, *red_l, *yf_l, *vec_l, *sav_a, *sav_x, *sav_d, *own;
+    int* lab_l;
+    int nvec, SC;
+    __device__ __forceinline__ LeanLds(float* lds, const Geo& g) {
+        SC = g.Cp + 4;
+        nvec = MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp;
+        xo_l = lds;                                          // [L][Bp][SX] out_i of every cell
+        dy_l = xo_l + MFAS_MAX_CELLS * Bp * SX;              // [L][Bp][SX] dy_i of every cell
+        lg_l = dy_l + MFAS_MAX_CELLS * Bp * SX;              // [Bp][SC] logits -> dlogits
+        rstd_l = lg_l + Bp * SC;                             // [L][Rp]
+        red_l = rstd_l + MFAS_MAX_CELLS * Rp;                // [2*Bp + 16]
+        lab_l = reinterpret_cast<int*>(red_l + 2 * Bp + 16); // [Bp]
+        yf_l = reinterpret_cast<float*>(lab_l + Bp);         // [1 or 2][L][MB][256] reduced feature sums
+        vec_l = yf_l + (g.alphas ? 2 : 1) * sav_plane;       // [3][nvec] vector block + Adam state
+        sav_a = vec_l + 3 * nvec;                            // [L][MB][256] activations
+        sav_x = sav_a + sav_plane;                           // xhat (batchnorm only)
+        sav_d = sav_a + (g.bn ? 2 : 1) * sav_plane;          // yS - yV (alphas only)
+        own = sav_a + (((1 + (g.bn ? 1 : 0) + (g.alphas ? 1 : 0)) * sav_plane + 3) & ~3);   // resident: [W|M|V|T][7 tiles][256]
+    }
+    static __host__ __device__ constexpr int own_floats() { return 4 * LEAN_OWN_TILES * 256; }
+};
+
+// MODE 0: launch-per-phase schedule; 1: persistent, everything exchanged through memory (write-through / sc1);
+// 2: persistent AND resident (LeanRes): vector block, OUT / HEAD weights and statistics live on chip, the chain's only
+// global traffic per step is the sweep's partial sums in and dy (+ alpha scales) out.
+template <int MB, int MODE = 0>
+__device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds, LeanRes* rs = nullptr) {
+    constexpr bool COH = MODE >= 1;
+    constexpr bool RES = MODE == 2;
 #ifdef MFAS_CHAIN_TIMING
     const unsigned long long ct0 = __builtin_readcyclecounter();
 #endif
@@ -701,18 +742,24 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     constexpr int Rp = 16, SX = Rp + 4;
     const int Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L, SC = Cp + 4;
     constexpr int sav_plane = MFAS_MAX_CELLS * MB * 256;
-    const int nvec = MFAS_MAX_CELLS * g.vec_cell_stride + Cp;
-    float* xo_l = lds;                                          // [L][Bp][SX] out_i of every cell
-    float* dy_l = xo_l + MFAS_MAX_CELLS * Bp * SX;              // [L][Bp][SX] dy_i of every cell
-    float* lg_l = dy_l + MFAS_MAX_CELLS * Bp * SX;              // [Bp][SC] logits -> dlogits
-    float* rstd_l = lg_l + Bp * SC;                             // [L][Rp]
-    float* red_l = rstd_l + MFAS_MAX_CELLS * Rp;                // [2*Bp + 16]
-    int* lab_l = reinterpret_cast<int*>(red_l + 2 * Bp + 16);   // [Bp]
-    float* yf_l = reinterpret_cast<float*>(lab_l + Bp);         // [1 or 2][L][MB][256] reduced feature sums
-    float* vec_l = yf_l + (g.alphas ? 2 : 1) * sav_plane;       // [3][nvec] vector block + Adam state
-    float* sav_a = vec_l + 3 * nvec;                            // [L][MB][256] activations
-    float* sav_x = sav_a + sav_plane;                           // xhat (batchnorm only)
-    float* sav_d = sav_a + (g.bn ? 2 : 1) * sav_plane;          // yS - yV (alphas only)
+    const LeanLds<MB> ll(lds, g);
+    const int nvec = ll.nvec;
+    float* xo_l = ll.xo_l;
+    float* dy_l = ll.dy_l;
+    float* lg_l = ll.lg_l;
+    float* rstd_l = ll.rstd_l;
+    float* red_l = ll.red_l;
+    int* lab_l = ll.lab_l;
+    float* yf_l = ll.yf_l;
+    float* vec_l = ll.vec_l;
+    float* sav_a = ll.sav_a;
+    float* sav_x = ll.sav_x;
+    float* sav_d = ll.sav_d;
+    // vector-parameter updates: memory (MODE 0 / 1) or the resident LDS copy (MODE 2; flushed at the end of the launch)
+    auto put_vec = [&](int64_t o, float w, float m, float v) {
+        if constexpr (RES) { const int e = (int)(o - cd.vec_off); vec_l[e] = w; vec_l[nvec + e] = m; vec_l[2 * nvec + e] = v; }
+        else { a.plane[o] = w; a.plane[a.plane_stride + o] = m; a.plane[2 * a.plane_stride + o] = v; }
+    };
 
     float* W = a.plane;
     float* Mv = a.plane + a.plane_stride;
@@ -752,20 +799,34 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
         p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)uu * MB) << 8));
     }
     const int vi = tid < nvec ? tid : 0;   // nvec = 4 * 96 + Cp <= 448: one element of the vector block per thread
-    const float vw = W[cvec_off + vi], vm = Mv[cvec_off + vi], vv = Vv[cvec_off + vi];
+    float vw = 0.f, vm = 0.f, vv = 0.f;
+    if constexpr (!RES) { vw = W[cvec_off + vi]; vm = Mv[cvec_off + vi]; vv = Vv[cvec_off + vi]; }
     // weight tiles of every product (all waves fetch them — 11 KiB, uniform control flow; wave 0 / waves < ncb use them)
     f32x4 tP[MFAS_MAX_CELLS], tT[MFAS_MAX_CELLS], tHT[4], tH;   // prev-out tile of cell i, its transpose, head^T, head
     tP[0] = z4; tT[0] = z4;
+    if constexpr (RES) {   // the chain owns these weights: LDS-resident images (slot i-1: OUT_i, slot 3+u: head block u)
+        const float* ownW = ll.own;
+        const float* ownT = ll.own + 3 * LEAN_OWN_TILES * 256;
 #pragma unroll
-    for (int i = 1; i < MFAS_MAX_CELLS; ++i) {
-        // (cells beyond L: any valid address — the loads stay unconditional, their values are never used)
-        tP[i] = ldc4<COH>(W, (i < L ? cd.seg_off[i][2] : cvec_off) + lane * 4);
-        tT[i] = ldc4<COH>(a.wt, (i < L ? cd.outT_off[i] : cd.headT_off) + lane * 4);
+        for (int i = 1; i < MFAS_MAX_CELLS; ++i) {
+            tP[i] = *reinterpret_cast<const f32x4*>(ownW + ((i - 1) << 8) + lane * 4);
+            tT[i] = *reinterpret_cast<const f32x4*>(ownT + ((i - 1) << 8) + lane * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tHT[u] = *reinterpret_cast<const f32x4*>(ownT + ((3 + u) << 8) + lane * 4);
+        tH = *reinterpret_cast<const f32x4*>(ownW + ((3 + (wave < ncb ? wave : 0)) << 8) + lane * 4);
+    } else {
+#pragma unroll
+        for (int i = 1; i < MFAS_MAX_CELLS; ++i) {
+            // (cells beyond L: any valid address — the loads stay unconditional, their values are never used)
+            tP[i] = ldc4<COH>(W, (i < L ? cd.seg_off[i][2] : cvec_off) + lane * 4);
+            tT[i] = ldc4<COH>(a.wt, (i < L ? cd.outT_off[i] : cd.headT_off) + lane * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            tHT[u] = ldc4<COH>(a.wt, cd.headT_off + ((int64_t)(u < ncb ? u : 0) << 8) + lane * 4);
+        tH = ldc4<COH>(W, cd.head_off + ((int64_t)(wave < ncb ? wave : 0) << 8) + lane * 4);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        tHT[u] = ldc4<COH>(a.wt, cd.headT_off + ((int64_t)(u < ncb ? u : 0) << 8) + lane * 4);
-    tH = ldc4<COH>(W, cd.head_off + ((int64_t)(wave < ncb ? wave : 0) << 8) + lane * 4);
     // dropout keep bits of this lane's elements (wave 0 owns the row block): bit (i*MB + mb)*4 + q — computed while the
     // loads above are in flight, used by the forward AND the backward pass
     const int r = l15;
@@ -805,7 +866,9 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS + accV;
         }
     }
-    if (tid < nvec) { vec_l[tid] = vw; vec_l[nvec + tid] = vm; vec_l[2 * nvec + tid] = vv; }
+    if constexpr (!RES) {
+        if (tid < nvec) { vec_l[tid] = vw; vec_l[nvec + tid] = vm; vec_l[2 * nvec + tid] = vv; }
+    }
     // labels: a dependent pair of loads that nothing needs before the loss; requested last, by wave 1, consumed after the
     // forward pass
     int lab = 0;
@@ -901,8 +964,8 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                         const float unb = var * (nf / (nf - 1.0f));
                         rm += g.bn_mom * (mu - rm);
                         rv += g.bn_mom * (unb - rv);
-                        W[vb + VEC_RM * Rp + r] = rm;
-                        W[vb + VEC_RV * Rp + r] = rv;
+                        if constexpr (RES) { vec_l[vbl + VEC_RM * Rp + r] = rm; vec_l[vbl + VEC_RV * Rp + r] = rv; }
+                        else { W[vb + VEC_RM * Rp + r] = rm; W[vb + VEC_RV * Rp + r] = rv; }
                     }
                 }
 #pragma unroll
@@ -941,8 +1004,10 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     // ------------------------------------------------------------------ out_i -> step buffer (x operand of the sweep's
     // OUT / HEAD segments), coalesced, by everyone; head on waves < ncb
     {
-        float* xo_g = sb + g.sb_xo;   // [L][Bp][Rp]
-        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(xo_g + e, xo_l[(e >> 4) * SX + (e & 15)]);
+        if constexpr (!RES) {   // (the resident chain updates OUT / HEAD itself: no sweep reads out_i)
+            float* xo_g = sb + g.sb_xo;   // [L][Bp][Rp]
+            for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(xo_g + e, xo_l[(e >> 4) * SX + (e & 15)]);
+        }
         const float* xl = xo_l + (L - 1) * Bp * SX;
         if (wave < ncb) {
             const int c = wave * 16 + l15;
@@ -970,16 +1035,24 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     if (tid == CHAIN_THREADS - 64) {
         float ls = 0.f, ncor = 0.f;
         for (int b = 0; b < Bp; ++b) { ls += red_l[b]; ncor += red_l[Bp + b]; }
-        DevStats& st = a.stats[(int64_t)cgidx * a.E + cs.epoch];
-        st.train_loss += (double)ls;
-        st.train_corr += (long long)ncor;
-        if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
+        if constexpr (RES) {   // accumulated in registers for the epoch, flushed by lean_res_store
+            rs->loss += (double)ls;
+            rs->corr += (long long)ncor;
+            if (!(fabsf(ls) <= 3.0e38f)) rs->bad = 1;
+        } else {
+            DevStats& st = a.stats[(int64_t)cgidx * a.E + cs.epoch];
+            st.train_loss += (double)ls;
+            st.train_corr += (long long)ncor;
+            if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
+        }
     }
     if (wave != 0) {   // dlogits -> step buffer (dy operand of the HEAD segment); head-bias Adam
-        float* dlg = sb + g.sb_dlog;
-        for (int e = tid - 64; e < Bp * Cp; e += CHAIN_THREADS - 64) {
-            const int b = e / Cp, c = e - b * Cp;
-            stc1<COH>(dlg + e, lg_l[b * SC + c]);
+        if constexpr (!RES) {
+            float* dlg = sb + g.sb_dlog;
+            for (int e = tid - 64; e < Bp * Cp; e += CHAIN_THREADS - 64) {
+                const int b = e / Cp, c = e - b * Cp;
+                stc1<COH>(dlg + e, lg_l[b * SC + c]);
+            }
         }
         const int hc = tid - (CHAIN_THREADS - 256);
         if (hc >= 0 && hc < C) {
@@ -988,7 +1061,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             const int64_t o = cvec_off + g.vec_head + hc;
             float w = vecW[g.vec_head + hc], m = vecM[g.vec_head + hc], v = vecV[g.vec_head + hc];
             adam1(w, m, v, gsum, ac);
-            W[o] = w; Mv[o] = m; Vv[o] = v;
+            put_vec(o, w, m, v);
         }
     } else {
         // -------------------------------------------------------------- backward: wave 0, all cells, no barrier
@@ -1094,12 +1167,12 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             const float db = colsum(sdy);
             if (lg == 0 && colok) {   // Adam on the column's vector parameters (one owner lane per column)
                 adam1(pw[0], pm[0], pv[0], db, ac);
-                W[ob] = pw[0]; Mv[ob] = pm[0]; Vv[ob] = pv[0];
+                put_vec(ob, pw[0], pm[0], pv[0]);
                 if (g.bn) {
                     adam1(pw[1], pm[1], pv[1], dgam, ac);
-                    W[og] = pw[1]; Mv[og] = pm[1]; Vv[og] = pv[1];
+                    put_vec(og, pw[1], pm[1], pv[1]);
                     adam1(pw[2], pm[2], pv[2], dbet, ac);
-                    W[obe] = pw[2]; Mv[obe] = pm[2]; Vv[obe] = pv[2];
+                    put_vec(obe, pw[2], pm[2], pv[2]);
                 }
             }
             if (g.alphas) {   // d(alpha_i) = sigma'(alpha) * sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]
@@ -1110,7 +1183,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                     float w = vecW[vbl + 5 * Rp], m = vecM[vbl + 5 * Rp], v = vecV[vbl + 5 * Rp];
                     const float sg = 1.0f / (1.0f + expf(-w));
                     adam1(w, m, v, tot * sg * (1.0f - sg), ac);
-                    W[o] = w; Mv[o] = m; Vv[o] = v;
+                    put_vec(o, w, m, v);
                 }
             }
         }
@@ -1118,7 +1191,115 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     lds_barrier();
     CT_STAMP(12);
     {   // dy_i -> step buffer (dy operand of the sweep), coalesced
-        float* dy_g = sb + g.sb_dy;   // [L][Bp][Rp]
-        for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(dy_g + e, dy_l[(e >> 4) * SX + (e & 15)]);
+        if constexpr (RES) {   // 16 B write-through stores: [L][Bp][16] = one f32x4 per thread and cell pair
+            for (int e4 = tid; e4 < L * Bp * 4; e4 += CHAIN_THREADS)
+                stc4<true>(a.stepbuf, sbo + g.sb_dy + (int64_t)e4 * 4, *reinterpret_cast<const f32x4*>(dy_l + (e4 >> 2) * SX + (e4 & 3) * 4));
+        } else {
+            float* dy_g = sb + g.sb_dy;   // [L][Bp][Rp]
+            for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(dy_g + e, dy_l[(e >> 4) * SX + (e & 15)]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resident lean chain, launch prologue / per-step weight update / launch epilogue (persist.hip.h, MODE 2)
+// ------------------------------------------------------------------------------------------------
+// own-tile plane offsets of slot s: OUT_{s+1} (s < 3), head class block s-3
+__device__ __forceinline__ int64_t lean_own_off(const CandDev& cd, int s) { return s < 3 ? cd.seg_off[s + 1][2] : cd.head_off + ((int64_t)(s - 3) << 8); }
+__device__ __forceinline__ int64_t lean_own_toff(const CandDev& cd, int s) { return s < 3 ? cd.outT_off[s + 1] : cd.headT_off + ((int64_t)(s - 3) << 8); }
+__device__ __forceinline__ bool lean_own_live(const CandDev& cd, const Geo& g, int s) { return s < 3 ? (s + 1 < cd.L) : (s - 3 < g.ncb); }
+
+template <int MB>
+__device__ __forceinline__ void lean_res_load(const ChainArgs& a, const int bid, float* lds, LeanRes& rs) {
+    const CandDev& cd = a.cands[bid];
+    const LeanLds<MB> ll(lds, a.g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < ll.nvec; e += CHAIN_THREADS)
+        for (int pl = 0; pl < 3; ++pl) ll.vec_l[pl * ll.nvec + e] = a.plane[pl * a.plane_stride + cd.vec_off + e];
+    if (wave < LEAN_OWN_TILES) {
+        const int s = wave;
+        const bool live = lean_own_live(cd, a.g, s);
+        for (int pl = 0; pl < 3; ++pl) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (live) v = *reinterpret_cast<const f32x4*>(a.plane + pl * a.plane_stride + lean_own_off(cd, s) + lane * 4);
+            *reinterpret_cast<f32x4*>(ll.own + (pl * LEAN_OWN_TILES + s) * 256 + lane * 4) = v;
+        }
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (live) t = *reinterpret_cast<const f32x4*>(a.wt + lean_own_toff(cd, s) + lane * 4);
+        *reinterpret_cast<f32x4*>(ll.own + (3 * LEAN_OWN_TILES + s) * 256 + lane * 4) = t;
+    }
+    rs.loss = 0.0; rs.corr = 0; rs.bad = 0;
+    __syncthreads();
+}
+
+// dW + Adam of the weights the chain owns, after dy has been published (off the sweep's critical path).  Wave i (1 <= i < L)
+// updates OUT_i with x = out_{i-1}, dy = dy_i; wave 4 + u updates head class block u with x = out_{L-1}, dy = dlogits.
+// Arithmetic = tile_run's for these segments (MB*4 MFMAs in batch order, gradient scale 1, adam1) — bit-identical.
+template <int MB>
+__device__ __forceinline__ void lean_res_update(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds) {
+    const CandDev& cd = a.cands[bid];
+    const Geo& g = a.g;
+    const LeanLds<MB> ll(lds, g);
+    constexpr int Bp = MB * 16, SX = 20;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int L = cd.L;
+    int s = -1;
+    const float* x = nullptr;
+    const float* dy = nullptr;
+    int sx = SX, sd = SX, dcol = 0;
+    if (wave >= 1 && wave < L) { s = wave - 1; x = ll.xo_l + (wave - 1) * Bp * SX; dy = ll.dy_l + wave * Bp * SX; }
+    else if (wave >= 4 && wave - 4 < g.ncb) { s = 3 + (wave - 4); x = ll.xo_l + (L - 1) * Bp * SX; dy = ll.lg_l; sd = ll.SC; dcol = (wave - 4) * 16; }
+    if (s >= 0) {
+        AdamC ac = a.ac;
+        ac.ss = cs.ss;
+        ac.bc2s = cs.bc2s;
+        float* oW = ll.own + s * 256 + lane * 4;
+        float* oM = oW + LEAN_OWN_TILES * 256;
+        float* oV = oM + LEAN_OWN_TILES * 256;
+        f32x4 w4 = *reinterpret_cast<const f32x4*>(oW), m4 = *reinterpret_cast<const f32x4*>(oM), v4 = *reinterpret_cast<const f32x4*>(oV);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < MB * 4; ++j)
+            acc = MFMA16(x[(4 * j + lg) * sx + l15], dy[(4 * j + lg) * sd + dcol + l15], acc);
+        const float gsc = 1.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float w = w4[q], m = m4[q], v = v4[q];
+            adam1(w, m, v, acc[q] * gsc, ac);
+            w4[q] = w; m4[q] = m; v4[q] = v;
+        }
+        *reinterpret_cast<f32x4*>(oW) = w4;
+        *reinterpret_cast<f32x4*>(oM) = m4;
+        *reinterpret_cast<f32x4*>(oV) = v4;
+        float* oT = ll.own + (3 * LEAN_OWN_TILES + s) * 256;        // transposed image for the backward chain
+        const int base = (((l15 >> 2) * 16 + 4 * lg) << 2) + (l15 & 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) oT[base + 4 * q] = w4[q];
+    }
+    lds_barrier();
+}
+
+template <int MB>
+__device__ __forceinline__ void lean_res_store(const ChainArgs& a, const int bid, const int epoch, float* lds, const LeanRes& rs) {
+    const CandDev& cd = a.cands[bid];
+    const LeanLds<MB> ll(lds, a.g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    for (int e = tid; e < ll.nvec; e += CHAIN_THREADS)
+        for (int pl = 0; pl < 3; ++pl) a.plane[pl * a.plane_stride + cd.vec_off + e] = ll.vec_l[pl * ll.nvec + e];
+    if (wave < LEAN_OWN_TILES && lean_own_live(cd, a.g, wave)) {
+        const int s = wave;
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<f32x4*>(a.plane + pl * a.plane_stride + lean_own_off(cd, s) + lane * 4) =
+                *reinterpret_cast<const f32x4*>(ll.own + (pl * LEAN_OWN_TILES + s) * 256 + lane * 4);
+        *reinterpret_cast<f32x4*>(const_cast<float*>(a.wt) + lean_own_toff(cd, s) + lane * 4) =
+            *reinterpret_cast<const f32x4*>(ll.own + (3 * LEAN_OWN_TILES + s) * 256 + lane * 4);
+    }
+    if (tid == CHAIN_THREADS - 64) {
+        DevStats& st = a.stats[(int64_t)cd.gidx * a.E + epoch];
+        st.train_loss += rs.loss;
+        st.train_corr += rs.corr;
+        if (rs.bad) a.status[cd.gidx] = 1;
     }
 }

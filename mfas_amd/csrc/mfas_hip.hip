@@ -124,6 +124,10 @@ struct mfas_population {
     // persistent step loop (persist.hip.h): one launch per epoch, per-candidate dependencies
     bool persist = false;
     int n_cus = 0;
+    bool res_chain = false;         // resident lean chain: owns OUT / HEAD + vector block on chip; persistent units = feature units only
+    int nres = 0;                   // resident feature units (one workgroup each, W/m/v in registers): the first nres persistent units
+    SegDesc* d_pdescs = nullptr;    // persistent schedule's unit list: [resident feature units | streamed units]
+    int n_pdescs = 0;
     size_t lds_persist = 0;
     uint32_t* d_sync = nullptr;     // [K] flags | [K] counters | abort word (zeroed before every launch)
     int32_t* d_need = nullptr;      // [K] sweep units per candidate
@@ -201,7 +205,34 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     // ---- column chunk per workgroup.  A workgroup should stream >= ~64 tiles (amortises staging / reduction and
     // keeps the number of partial-sum chunks the chain has to reduce small), the launch should still have a few
     // hundred workgroups, and x_t / x_{t+1} for the chunk must fit the LDS budget.
+    // ---- persistent step loop (persist.hip.h): wanted?  With one row block (R <= 16) the feature units become RESIDENT
+    // (one workgroup per unit, W/m/v in registers): the column chunk is then the smallest of 128 / 256 / 512 columns with
+    // which every chain, every unit and one streaming workgroup per candidate (OUT / HEAD) get a CU of their own.
+    bool want_persist = false;   // default decided by measurement; MFAS_PERSIST=1/0 overrides
+    if (const char* e = getenv("MFAS_PERSIST")) want_persist = atoi(e) != 0;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+        p->n_cus = ncu;
+    }
+    bool plan_res = want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT");
+    auto count_feat_units = [&](int cc_target) {
+        int64_t n = 0;
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < n_cells[k] && i < MFAS_MAX_CELLS; ++i) {
+                const int sw = ceil16(hp->s_sizes[confs[(k * 4 + i) * 3] & 7]), vw = ceil16(hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 7]);
+                n += sw / pick_chunk(sw, cc_target) + vw / pick_chunk(vw, cc_target);
+            }
+        return n;
+    };
     int target = chunk_cols;
+    if (plan_res && target <= 0) {
+        int pick = 0;
+        for (int cct : {128, 256, 512})
+            if (!pick && K + count_feat_units(cct) + K <= p->n_cus) pick = cct;
+        if (pick) target = pick;
+        else plan_res = false;
+    }
     if (target <= 0) {
         double tot_cols = 0;
         for (int k = 0; k < K; ++k)
@@ -343,8 +374,16 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
 
     // ---- LDS budgets
     {
+        // resident feature units (persistent schedule) do not go through sweep_body: their LDS need is separate
+        int nfeat = 0, max_fcc = 0;
+        for (const SegDesc& d : p->descs)
+            if (d.kind <= KIND_V) { ++nfeat; max_fcc = std::max(max_fcc, d.cc); }
+        const size_t lds_res = ((size_t)2 * g.Bp * (max_fcc + 4) + (size_t)STEP_NW * g.MB * 256) * 4;
+        const bool res_ok = plan_res && max_fcc <= 128 * PERSIST_NTR && K + nfeat + 1 <= p->n_cus && lds_res + 4 * PERSIST_LDS_WORDS <= 160 * 1024;
+        p->nres = res_ok ? nfeat : 0;
         size_t ls = 0;
         for (const SegDesc& d : p->descs) {
+            if (res_ok && d.kind <= KIND_V) continue;
             const int nrb = d.rows_p / 16;
             size_t fl = (size_t)g.Bp * (d.cc + 16) + (size_t)g.Bp * (d.cc + 4) + (size_t)g.Bp * (d.rows_p + 16);
             if (nrb < STEP_NW && d.kind <= KIND_V) fl += (size_t)STEP_NW * nrb * g.MB * 256;   // k-split reduction (forward only)
@@ -364,6 +403,9 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
                              + (g.alphas ? 2 : 1) * plane + vec / 4 + (1 + (g.bn ? 1 : 0) + (g.alphas ? 1 : 0)) * plane) * 4;
         p->lean_chain = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && std::max(ls, lean) <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
         if (p->lean_chain) { p->lds_chain = lean; p->lds_step = std::max(p->lds_step, lean); }
+        p->res_chain = res_ok && p->lean_chain && !getenv("MFAS_PERSIST_NO_RES_CHAIN");
+        const size_t lds_rchain = p->res_chain ? p->lds_chain + 16 + 4 * (size_t)LeanLds<1>::own_floats() : 0;
+        p->lds_persist = ((std::max(std::max(std::max(p->lds_step, p->lds_chain), res_ok ? lds_res : (size_t)0), lds_rchain) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
     }
     p->nrbw = (g.nrb + 3) / 4;
     if (p->nrbw == 3) p->nrbw = 4;
@@ -409,15 +451,14 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         int ngroups = p->lean_chain ? ((K >= 40 && K < 224) ? 2 : 1) : (K >= 20 ? 2 : 1);
         if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
         {   // persistent step loop: small populations (one workgroup per CU must hold every chain + a useful number of sweep workgroups)
-            hipDeviceProp_t prop;
-            CREATE_CHK(hipGetDeviceProperties(&prop, device));
-            p->n_cus = prop.multiProcessorCount;
-            bool want = false;   // default decided by measurement; MFAS_PERSIST=1/0 overrides
-            if (const char* e = getenv("MFAS_PERSIST")) want = atoi(e) != 0;
-            const bool fits = K <= p->n_cus / 4 && g.MB != 4 && (int64_t)p->descs.size() <= (int64_t)PERSIST_MAX_UNITS * (p->n_cus - K) &&
+            const bool want = want_persist;
+            const int64_t n_stream = (int64_t)p->descs.size() - p->nres;
+            const bool fits = K <= p->n_cus / 4 && g.MB != 4 && K + p->nres < p->n_cus &&
+                              n_stream <= (int64_t)PERSIST_MAX_UNITS * (p->n_cus - K - p->nres) &&
                               (double)p->plane_stride * 4.0 < 3.9e9 && (double)step_off * 4.0 < 3.9e9 && (double)wt_off * 4.0 < 3.9e9;
             p->persist = want && fits;
             if (p->persist) ngroups = 1;
+            else { p->nres = 0; p->res_chain = false; }
         }
         int split = K;
         if (ngroups == 2) {
@@ -503,9 +544,21 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     CREATE_CHK(set_lds((k_chain<1, true>), p->lds_chain));
     CREATE_CHK(set_lds((k_chain<2, true>), p->lds_chain));
     if (p->persist) {
-        p->lds_persist = ((std::max(p->lds_step, p->lds_chain) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
+        {   // unit list of the persistent schedule: resident feature units first, then the streamed units (largest first)
+            std::vector<SegDesc> res, rest;
+            for (const SegDesc& d : p->descs) {
+                if (p->nres > 0 && d.kind <= KIND_V) res.push_back(d);
+                else if (!p->res_chain) rest.push_back(d);     // (a resident lean chain updates OUT / HEAD itself)
+            }
+            std::stable_sort(rest.begin(), rest.end(), [](const SegDesc& x, const SegDesc& y) { return x.cc * x.rows_p > y.cc * y.rows_p; });
+            res.insert(res.end(), rest.begin(), rest.end());
+            p->n_pdescs = (int)res.size();
+            CREATE_CHK(hipMalloc(&p->d_pdescs, sizeof(SegDesc) * res.size()));
+            CREATE_CHK(hipMemcpy(p->d_pdescs, res.data(), sizeof(SegDesc) * res.size(), hipMemcpyHostToDevice));
+        }
         std::vector<int32_t> need(K, 0);
-        for (const SegDesc& d : p->descs) need[d.cand]++;
+        for (const SegDesc& d : p->descs)
+            if (!(p->res_chain && d.kind > KIND_V)) need[d.cand]++;
         CREATE_CHK(hipMalloc(&p->d_need, sizeof(int32_t) * K));
         CREATE_CHK(hipMemcpy(p->d_need, need.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice));
         CREATE_CHK(hipMalloc(&p->d_sync, sizeof(uint32_t) * (2 * K + 16)));
@@ -535,7 +588,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     for (auto& gr : p->groups) { hipFree(gr.d_descs); hipFree(gr.d_taps); }
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
     hipFree(p->d_seeds); hipFree(p->d_corr); hipFree(p->d_posw);
-    hipFree(p->d_sync); hipFree(p->d_need); hipFree(p->d_scal); hipFree(p->d_trace);
+    hipFree(p->d_sync); hipFree(p->d_need); hipFree(p->d_scal); hipFree(p->d_trace); hipFree(p->d_pdescs);
     delete p;
 }
 
@@ -761,16 +814,17 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         PersistArgs pa;
         memset(&pa, 0, sizeof(pa));
         pa.sa = st.sa; pa.ca = st.ca;
-        pa.sa.desc = p->groups[0].d_descs; pa.sa.tdesc = nullptr; pa.sa.ntap = 0;
+        pa.sa.desc = p->d_pdescs; pa.sa.tdesc = nullptr; pa.sa.ntap = 0;
         pa.ca.cands = p->d_cands;
-        pa.nchain = K; pa.nitems = p->groups[0].ndesc;
+        pa.nchain = K; pa.nitems = p->n_pdescs; pa.nres = p->nres; pa.res_chain = p->res_chain ? 1 : 0;
         pa.T = (int)T; pa.epoch = ep;
         pa.N = N; pa.pos0 = (int64_t)ep * N;
         pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);
         pa.scal = p->d_scal; pa.sync = p->d_sync; pa.need = p->d_need; pa.trace = p->d_trace;
-        const unsigned grid = (unsigned)(K + std::min(pa.nitems, p->n_cus - K));
+        const int n_stream = pa.nitems - pa.nres;
+        const unsigned grid = (unsigned)(K + pa.nres + (n_stream > 0 ? std::max(1, std::min(n_stream, p->n_cus - K - pa.nres)) : 0));
         const int ldsw = (int)(p->lds_persist / 4) - PERSIST_LDS_WORDS;
-        if (pa.nitems > PERSIST_MAX_UNITS * (int)(grid - K)) return hipErrorInvalidConfiguration;
+        if ((n_stream > 0 && n_stream > PERSIST_MAX_UNITS * (int)(grid - K - pa.nres)) || (int)grid > p->n_cus) return hipErrorInvalidConfiguration;
         const bool prof = p->profiling;
         if (prof) {
             if (p->ev.size() < ev_used + 2) {

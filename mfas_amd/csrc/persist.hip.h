@@ -24,6 +24,8 @@ struct PersistArgs {
     SweepArgs sa;              // desc = the population's sweep units (per-segment), cands = all candidates
     ChainArgs ca;              // cands = all candidates
     int32_t nchain, nitems;    // K, number of sweep units
+    int32_t nres, res_chain;   // units [0, nres) are RESIDENT feature units: one workgroup each (blocks K .. K + nres);
+                               // res_chain: the (lean) chain owns OUT / HEAD and keeps them + its vector block on chip
     int32_t T, epoch;          // train steps of this launch, epoch index (statistics slot)
     int64_t N, pos0;           // N_train, epoch * N_train (position in the sample-order table)
     int32_t B, gstep0;         // batch size, epoch * batches-per-epoch (Adam / dropout step counter base)
@@ -35,6 +37,7 @@ struct PersistArgs {
 
 #define PERSIST_MAX_UNITS 8             // sweep units one workgroup may own
 #define PERSIST_LDS_WORDS 32            // LDS words the loop itself uses (behind the bodies' LDS)
+#define PTRACE(slot) do { if (a.trace && tr_on) a.trace[tr_base + (slot)] = wall_clock64(); } while (0)
 #define PERSIST_SPIN_LIMIT (1u << 22)   // a few seconds of s_sleep polls: only a lost workgroup or a bug gets here
 
 __device__ __forceinline__ uint32_t ld_u32_relaxed(const uint32_t* p) {
@@ -69,7 +72,169 @@ __device__ __forceinline__ void wg_publish_barrier() {
     __syncthreads();
 }
 
-#define PTRACE(slot) do { if (a.trace && tr_on) a.trace[tr_base + (slot)] = wall_clock64(); } while (0)
+// ------------------------------------------------------------------------------------------------
+// sweep_resident — ONE feature unit (a column chunk of one S / V segment, R <= 16: one row block) owned by ONE workgroup
+// for the whole launch, with its W / m / v tiles held IN REGISTERS across the epoch's steps: the 128 MB register file of
+// the chip is the parameter store of a small population (the search trains 6-16 candidates of ~125 K parameters per GPU:
+// 1.5 MB of state each).  Per step the unit reads dy (2 KB, from the chain) and the batch's table rows and writes its 2 KB
+// forward partial — no W/m/v traffic at all; the state is loaded at launch start and stored back at its end (the dev
+// evaluation and the next epoch's launch read it from memory).  The rows of batch t+1 are staged into LDS BEFORE the
+// workgroup waits for the chain of step t (the sample order is known), and batch t's rows are still there from the previous
+// step, so no table access sits on the critical path: wait -> dy -> dW (MFMA) -> Adam -> forward (MFMA) -> partial.
+// Tile -> wave mapping, MFMA order, Adam arithmetic and the cross-wave reduction are those of sweep_body's k-split path:
+// bit-identical to the launch-per-phase schedule run on the same units.
+// ------------------------------------------------------------------------------------------------
+template <int MB, int NTR>
+__device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int unit, float* lds, int* ldsw) {
+    const SweepArgs& sa = a.sa;
+    const SegDesc d = sa.desc[unit];
+    const CandDev& cd = sa.cands[d.cand];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int Bp = MB * 16;
+    const int cc = d.cc, nkb = cc >> 4;
+    const int S = cc + 4;                         // row stride of both staged batches (16 B aligned rows)
+    float* xbuf[2] = {lds, lds + Bp * S};
+    float* wred = lds + 2 * Bp * S;               // [8 waves][MB][256] cross-wave reduction of the forward partial
+    const int K = a.nchain;
+    uint32_t* flag = a.sync + d.cand;
+    uint32_t* cnt = a.sync + K + d.cand;
+    uint32_t* abortw = a.sync + 2 * K;
+    const void* tp = d.kind == KIND_S ? sa.tab.s[d.tap] : sa.tab.v[d.tap];
+    const int64_t sbo = cd.step_off;
+    const int64_t part = sbo + sa.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * MB) << 8);
+    const int64_t dyo = sbo + sa.g.sb_dy + (int64_t)d.cell * Bp * sa.g.Rp;      // dy_i [Bp][Rp = 16]
+    float* Wp = sa.plane + d.w_off;
+    float* Mp = Wp + sa.plane_stride;
+    float* Vp = Mp + sa.plane_stride;
+
+    // ---- the unit's state: wave w owns k-blocks w, w + 8, ... (as sweep_body's k-split)
+    f32x4 w4[NTR], m4[NTR], v4[NTR];
+#pragma unroll
+    for (int s = 0; s < NTR; ++s) {
+        const int kb = wave + STEP_NW * s;
+        const int64_t off = (int64_t)(kb < nkb ? kb : 0) * 256 + lane * 4;
+        w4[s] = *reinterpret_cast<const f32x4*>(Wp + off);
+        m4[s] = *reinterpret_cast<const f32x4*>(Mp + off);
+        v4[s] = *reinterpret_cast<const f32x4*>(Vp + off);
+    }
+    AdamC ac = sa.ac;
+
+    auto stage = [&](float* dst, int t) {     // rows of batch t -> LDS (f32)
+        const int nv = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
+        stage_table(dst, S, tp, sa.tab.dtype, d.width, d.k0, cc, sa.order, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
+    };
+    // forward partial of the staged batch `xn` with the current weights -> partial slot (write-through) -> arrive
+    auto reduce_publish = [&](const f32x4 (&yacc)[MB]) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            *reinterpret_cast<f32x4*>(wred + ((wave * MB + mb) << 8) + lane * 4) = yacc[mb];
+        __syncthreads();
+        for (int e = tid; e < MB * 64; e += STEP_THREADS) {    // fixed order 0..7, as sweep_body
+            const int slot = e >> 6, ln = e & 63;
+            f32x4 sum = *reinterpret_cast<const f32x4*>(wred + (slot << 8) + ln * 4);
+#pragma unroll
+            for (int w = 1; w < STEP_NW; ++w)
+                sum += *reinterpret_cast<const f32x4*>(wred + ((w * MB + slot) << 8) + ln * 4);
+            stc4<true>(sa.stepbuf, part + (slot << 8) + ln * 4, sum);
+        }
+        wg_publish_barrier();
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    // ---- prologue: forward partial sums of batch 0 (no update)
+    int cur = 0;
+    stage(xbuf[cur], 0);
+    __syncthreads();
+    {
+        f32x4 yacc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NTR; ++s) {
+            const int kb = wave + STEP_NW * s;
+            if (kb < nkb) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xbuf[cur] + (mb * 16 + l15) * S + kb * 16 + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[s][q], yacc[mb]);
+                }
+            }
+        }
+        reduce_publish(yacc);
+    }
+    // ---- the epoch's train steps
+    for (int t = 0; t < a.T; ++t) {
+        const bool fwd = t + 1 < a.T;
+        float* xt = xbuf[cur];
+        float* xn = xbuf[cur ^ 1];
+        if (fwd) stage(xn, t + 1);               // batch t+1 lands while the chain of step t is still running
+        const bool tr_on = unit == 0 && tid == 0 && t >= 8 && t < 16;
+        const int tr_base = (t - 8) * 8 + 4;
+        PTRACE(0);
+        if (!wg_wait_ge(flag, (uint32_t)(t + 1), abortw, ldsw)) return;    // (its barriers also publish the staging)
+        PTRACE(1);
+        float dyf[MB * 4];
+#pragma unroll
+        for (int j = 0; j < MB * 4; ++j) dyf[j] = ldc1<true>(sa.stepbuf + dyo + (4 * j + lg) * 16 + l15);
+        float gsc = 1.0f;
+        if (sa.g.alphas) gsc = ldc1<true>(sa.stepbuf + sbo + sa.g.sb_gsc + d.cell * 2 + d.kind);
+        ac.ss = a.scal[2 * (int64_t)(a.gstep0 + t)];
+        ac.bc2s = a.scal[2 * (int64_t)(a.gstep0 + t) + 1];
+        f32x4 yacc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NTR; ++s) {
+            const int kb = wave + STEP_NW * s;
+            if (kb < nkb) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < MB * 4; ++j)
+                    acc = MFMA16(xt[(4 * j + lg) * S + kb * 16 + l15], dyf[j], acc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float w = w4[s][q], m = m4[s][q], v = v4[s][q];
+                    adam1(w, m, v, acc[q] * gsc, ac);
+                    w4[s][q] = w;
+                    m4[s][q] = m;
+                    v4[s][q] = v;
+                }
+                if (fwd) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * S + kb * 16 + 4 * lg);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[s][q], yacc[mb]);
+                    }
+                }
+            }
+        }
+        PTRACE(2);
+        if (fwd) {
+            reduce_publish(yacc);
+        } else {
+            wg_publish_barrier();
+            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        PTRACE(3);
+        cur ^= 1;
+    }
+    // ---- state back to memory (dev evaluation, parameter export and the next epoch's launch read it there)
+#pragma unroll
+    for (int s = 0; s < NTR; ++s) {
+        const int kb = wave + STEP_NW * s;
+        if (kb < nkb) {
+            const int64_t off = (int64_t)kb * 256 + lane * 4;
+            *reinterpret_cast<f32x4*>(Wp + off) = w4[s];
+            *reinterpret_cast<f32x4*>(Mp + off) = m4[s];
+            *reinterpret_cast<f32x4*>(Vp + off) = v4[s];
+        }
+    }
+}
+
+#define PERSIST_NTR 4                   // resident units: tiles per wave (cc <= 128 * PERSIST_NTR columns)
 
 template <int MB, bool LEAN, int U>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a, const int lds_word) {
@@ -84,6 +249,35 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
     if (bid < K) {
         // ------------------------------------------------------------------ chain workgroup of candidate `bid`
         const uint32_t need = (uint32_t)a.need[bid];
+        if constexpr (LEAN) {
+            if (a.res_chain) {   // resident lean chain: see chain.hip.h (MODE 2)
+                LeanRes rs;
+                lean_res_load<MB>(a.ca, bid, lds, rs);
+                for (int t = 0; t < a.T; ++t) {
+                    const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
+                    const int tr_base = (t - 8) * 8;
+                    PTRACE(0);
+                    if (!wg_wait_ge(cnt + bid, need * (uint32_t)(t + 1), abortw, ldsw)) return;
+                    PTRACE(1);
+                    ChainStep cs;
+                    cs.pos_t = a.pos0 + (int64_t)t * a.B;
+                    cs.base_t = t * a.B;
+                    cs.nvalid = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
+                    cs.gstep = a.gstep0 + t;
+                    cs.epoch = a.epoch;
+                    cs.ss = a.scal[2 * (int64_t)cs.gstep];
+                    cs.bc2s = a.scal[2 * (int64_t)cs.gstep + 1];
+                    chain_lean<MB, 2>(a.ca, cs, bid, lds, &rs);
+                    PTRACE(2);
+                    wg_publish_barrier();
+                    if (tid == 0) __hip_atomic_store(flag + bid, (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    PTRACE(3);
+                    lean_res_update<MB>(a.ca, cs, bid, lds);   // OUT / HEAD dW + Adam while the sweep units run
+                }
+                lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs);
+                return;
+            }
+        }
         for (int t = 0; t < a.T; ++t) {
             const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
             const int tr_base = (t - 8) * 8;
@@ -98,7 +292,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
             cs.epoch = a.epoch;
             cs.ss = a.scal[2 * (int64_t)cs.gstep];
             cs.bc2s = a.scal[2 * (int64_t)cs.gstep + 1];
-            if constexpr (LEAN) chain_lean<MB, true>(a.ca, cs, bid, lds);
+            if constexpr (LEAN) chain_lean<MB, 1>(a.ca, cs, bid, lds);
             else chain_body<MB, true, true>(a.ca, cs, bid, lds);
             PTRACE(2);
             wg_publish_barrier();
@@ -112,13 +306,18 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
     // ever re-read by the same CU, so they stay coherent without any fence.  A workgroup that owns several units serves
     // whichever of them is ready (its candidate's chain has published the step the unit is waiting for): units of different
     // candidates never block each other (in-order service convoys all candidates behind the slowest chain).
-    const int G = (int)gridDim.x - K, wg = bid - K;
-    const int n_my = wg < a.nitems ? (a.nitems - wg + G - 1) / G : 0;   // <= PERSIST_MAX_UNITS (host)
+    if (bid < K + a.nres) {
+        sweep_resident<MB, PERSIST_NTR>(a, bid - K, lds, ldsw);
+        return;
+    }
+    const int G = (int)gridDim.x - K - a.nres, wg = bid - K - a.nres;
+    const int n_gen = a.nitems - a.nres;      // units served by the generic (streaming) workgroups: [nres, nitems)
+    const int n_my = wg < n_gen ? (n_gen - wg + G - 1) / G : 0;   // <= PERSIST_MAX_UNITS (host)
     int* nxt = ldsw + 8;                     // next step of my j-th unit (-1 = the epoch's prologue: forward of batch 0, no update)
     int* cnd = ldsw + 8 + PERSIST_MAX_UNITS; // its candidate
     if (tid < n_my) {
         nxt[tid] = -1;
-        cnd[tid] = a.sa.desc[wg + tid * G].cand;
+        cnd[tid] = a.sa.desc[a.nres + wg + tid * G].cand;
     }
     __syncthreads();
     int last = n_my - 1;
@@ -148,7 +347,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
         __syncthreads();
         const int pick = ldsw[0];
         if (pick < 0) return;
-        const int t = nxt[pick], cand = cnd[pick], it = wg + pick * G;
+        const int t = nxt[pick], cand = cnd[pick], it = a.nres + wg + pick * G;
         __syncthreads();   // everyone has read the pick before lane 0 can overwrite it
         last = pick;
         SweepStep st;

@@ -1,6 +1,6 @@
 """Persistent step loop (MFAS_PERSIST=1) vs the launch-per-phase schedule on the same small population: results must be
 bit-identical (statistics and every parameter / Adam moment); prints cand/s of both.
-usage: persist_check.py R B bn K E [N_train N_dev] [mixed]"""
+usage: persist_check.py R B bn K E [N_train N_dev] [mixed] [cc=COLS] [steps=N]"""
 import os
 import sys
 import time
@@ -15,11 +15,13 @@ from oracle import np_oracle as O
 R, B, bn, K, E = (int(x) for x in sys.argv[1:6])
 N, Nd = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (10000, 5600)
 mixed = "mixed" in sys.argv
+cc = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("cc=")), 0)   # feature-column chunk (same units in both schedules)
+os.environ["MFAS_NO_TAP_MAJOR"] = "1"      # the persistent schedule runs per-segment units: compare like with like
 steps = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("steps=")), -1)   # debug: stop after N train steps
 dev = torch.device("cuda:0")
 tr = M.FeatureTable.synthetic(N, 1, dev, torch.bfloat16, snr=0.12)
 dv = M.FeatureTable.synthetic(Nd, 2, dev, torch.bfloat16, snr=0.12)
-hp = M.Hyper(R=R, B=B, bn=bool(bn), drpt=0.5)
+hp = M.Hyper(R=R, B=B, bn=bool(bn), drpt=0.5, alphas="alphas" in sys.argv)
 conf4 = np.array([[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]])
 confs = [conf4] * K
 if mixed:
@@ -31,7 +33,7 @@ order = M.ntu_searchable.make_order(N, E, True, 5, dev)
 res = {}
 for mode in ("0", "1", "0", "1"):
     os.environ["MFAS_PERSIST"] = mode
-    pop = M.Population(hp, confs, dev, drop_seeds=list(range(100, 100 + K)))
+    pop = M.Population(hp, confs, dev, drop_seeds=list(range(100, 100 + K)), chunk_cols=cc)
     pop.init(list(range(1, K + 1)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
