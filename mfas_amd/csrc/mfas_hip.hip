@@ -208,14 +208,23 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     // ---- persistent step loop (persist.hip.h): wanted?  With one row block (R <= 16) the feature units become RESIDENT
     // (one workgroup per unit, W/m/v in registers): the column chunk is then the smallest of 128 / 256 / 512 columns with
     // which every chain, every unit and one streaming workgroup per candidate (OUT / HEAD) get a CU of their own.
-    bool want_persist = false;   // default decided by measurement; MFAS_PERSIST=1/0 overrides
-    if (const char* e = getenv("MFAS_PERSIST")) want_persist = atoi(e) != 0;
+    // Default (measured, profiles/r02_popsweep_*.log): ON where the resident form fits (R <= 16, every chain and feature unit on
+    // its own CU: x1.14-1.3 over the launch-per-phase schedule at 4..12 candidates per GPU); the streaming form (larger R, or
+    // units that do not fit) is slower than launch-per-phase (x0.8-0.9) and only runs when forced.  MFAS_PERSIST=1/0 overrides.
+    bool want_persist = true, force_persist = false;
+    if (const char* e = getenv("MFAS_PERSIST")) { want_persist = atoi(e) != 0; force_persist = want_persist; }
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
         p->n_cus = ncu;
     }
-    bool plan_res = want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT");
+    // (lean-chain feasibility, same formula as the LDS budget below: the resident form is only planned by default when the
+    // resident lean chain will run with it, otherwise the unit size chosen for it would be wrong for the fallback schedule)
+    const size_t lean_bytes_early = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
+                                     + (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.MB * 256 + (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp)
+                                     + (size_t)(1 + (g.bn ? 1 : 0) + (g.alphas ? 1 : 0)) * MFAS_MAX_CELLS * g.MB * 256) * 4;
+    const bool lean_ok_early = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean_bytes_early <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
+    bool plan_res = want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT") && (lean_ok_early || force_persist);
     auto count_feat_units = [&](int cc_target) {
         int64_t n = 0;
         for (int k = 0; k < K; ++k)
@@ -456,7 +465,7 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
             const bool fits = K <= p->n_cus / 4 && g.MB != 4 && K + p->nres < p->n_cus &&
                               n_stream <= (int64_t)PERSIST_MAX_UNITS * (p->n_cus - K - p->nres) &&
                               (double)p->plane_stride * 4.0 < 3.9e9 && (double)step_off * 4.0 < 3.9e9 && (double)wt_off * 4.0 < 3.9e9;
-            p->persist = want && fits;
+            p->persist = want && fits && (p->res_chain || force_persist);
             if (p->persist) ngroups = 1;
             else { p->nres = 0; p->res_chain = false; }
         }
