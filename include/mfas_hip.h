@@ -49,6 +49,11 @@ typedef struct mfas_hyper {
     int32_t allow_plain_cell; /* 1: [Linear, nl] cells (no BN, no Dropout) are legal (avmnist_searchable.py:276-285); the
                                * NTU searchable leaves that case undefined (ntu_searchable.py:274-284) */
     double f1_threshold; /* th_fscore, mmimdb.py:16 (0.3) */
+    int32_t tap_bits;    /* hint: element size of the feature tables this population will train on (16: bf16 / f16 taps, the
+                          * layout north_star prescribes; 32: f32; 0: unknown = any).  With 16 the engine may size resident
+                          * feature units for 16-bit staging (up to 1024 columns each); training such a population on f32
+                          * tables is refused with MFAS_EINVAL. */
+    int32_t _pad;
 } mfas_hyper;
 
 /* Pooled feature table = what Visual/Skeleton.forward + GlobalPooling2D hand to the fusion net

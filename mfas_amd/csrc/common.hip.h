@@ -256,4 +256,6 @@ __device__ __forceinline__ void stage_f32(float* dst, int stride, const float* b
 // MB == 2 has two builds: WPE = 2 (up to 256 VGPRs, one workgroup per CU, U = 2: nothing spills, best when the co-scheduled
 // chain's latency bounds the launch) and WPE = 4 (U = 1, the chain code spills a little, two workgroups per CU: +10..19 %
 // when the sweep bounds the launch).  Deeper batches (U = 4, 6 at WPE = 2) measured 8-12 % slower.
+// (MB == 1 with U = 4 in a one-workgroup-per-CU build for the sweep-only launches of small populations was measured SLOWER:
+// 90.6 vs 82.6 us/step at 6 candidates, R=128 — profiles/r02_popsweep_r128.log.)
 template <int MB, int WPE> struct SweepU { static constexpr int v = (MB == 2 && WPE == 4) ? 1 : 2; };

@@ -124,6 +124,7 @@ struct mfas_population {
     // persistent step loop (persist.hip.h): one launch per epoch, per-candidate dependencies
     bool persist = false;
     int n_cus = 0;
+    bool res_wide = false;          // resident units of more than 512 columns (16-bit staging): f32 tables cannot be trained
     bool res_chain = false;         // resident lean chain: owns OUT / HEAD + vector block on chip; persistent units = feature units only
     int nres = 0;                   // resident feature units (one workgroup each, W/m/v in registers): the first nres persistent units
     SegDesc* d_pdescs = nullptr;    // persistent schedule's unit list: [resident feature units | streamed units]
@@ -158,9 +159,11 @@ static hipError_t set_lds(KT kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells,
-                                      const uint32_t* drop_seeds, int32_t K, int32_t device, void* hip_stream,
-                                      int32_t chunk_cols, mfas_population** out) {
+#define MFAS_RETRY_NO_PERSIST 12345   // internal: the layout was planned for the resident persistent schedule, which then did not fit
+
+static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells,
+                       const uint32_t* drop_seeds, int32_t K, int32_t device, void* hip_stream,
+                       int32_t chunk_cols, mfas_population** out, const bool allow_persist) {
     if (!hp || !confs || !n_cells || !out || K <= 0) return fail(MFAS_EINVAL, "null argument or K <= 0");
     if (hp->R < 1 || hp->R > 512 || hp->C < 1 || hp->C > 256) return fail(MFAS_EINVAL, "R must be in [1,512], C in [1,256]");
     if (hp->B < 2 || hp->B > 64) return fail(MFAS_EINVAL, "batchsize must be in [2,64]");
@@ -211,8 +214,8 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     // Default (measured, profiles/r02_popsweep_*.log): ON where the resident form fits (R <= 16, every chain and feature unit on
     // its own CU: x1.14-1.3 over the launch-per-phase schedule at 4..12 candidates per GPU); the streaming form (larger R, or
     // units that do not fit) is slower than launch-per-phase (x0.8-0.9) and only runs when forced.  MFAS_PERSIST=1/0 overrides.
-    bool want_persist = true, force_persist = false;
-    if (const char* e = getenv("MFAS_PERSIST")) { want_persist = atoi(e) != 0; force_persist = want_persist; }
+    bool want_persist = allow_persist, force_persist = false;
+    if (const char* e = getenv("MFAS_PERSIST")) { want_persist = allow_persist && atoi(e) != 0; force_persist = want_persist; }
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
@@ -237,8 +240,8 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     int target = chunk_cols;
     if (plan_res && target <= 0) {
         int pick = 0;
-        for (int cct : {128, 256, 512})
-            if (!pick && K + count_feat_units(cct) + K <= p->n_cus) pick = cct;
+        for (int cct : {128, 256, 512, 1024})   // (1024 needs 16-bit staging: only when the caller promised 16-bit taps)
+            if (!pick && (cct <= 512 || hp->tap_bits == 16) && K + count_feat_units(cct) + 1 <= p->n_cus) pick = cct;
         if (pick) target = pick;
         else plan_res = false;
     }
@@ -387,8 +390,12 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
         int nfeat = 0, max_fcc = 0;
         for (const SegDesc& d : p->descs)
             if (d.kind <= KIND_V) { ++nfeat; max_fcc = std::max(max_fcc, d.cc); }
-        const size_t lds_res = ((size_t)2 * g.Bp * (max_fcc + 4) + (size_t)STEP_NW * g.MB * 256) * 4;
-        const bool res_ok = plan_res && max_fcc <= 128 * PERSIST_NTR && K + nfeat + 1 <= p->n_cus && lds_res + 4 * PERSIST_LDS_WORDS <= 160 * 1024;
+        const bool wide = max_fcc > 128 * PERSIST_NTR;      // 16-bit staging only
+        const size_t lds_res = wide ? ((size_t)2 * g.Bp * (max_fcc + 8) * 2 + (size_t)STEP_NW * g.MB * 256 * 4)
+                                    : ((size_t)2 * g.Bp * (max_fcc + 4) + (size_t)STEP_NW * g.MB * 256) * 4;
+        const bool res_ok = plan_res && max_fcc <= 128 * PERSIST_NTR16 && (!wide || hp->tap_bits == 16) && K + nfeat + 1 <= p->n_cus &&
+                            lds_res + 4 * PERSIST_LDS_WORDS <= 160 * 1024;
+        p->res_wide = res_ok && wide;
         p->nres = res_ok ? nfeat : 0;
         size_t ls = 0;
         for (const SegDesc& d : p->descs) {
@@ -467,7 +474,10 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
                               (double)p->plane_stride * 4.0 < 3.9e9 && (double)step_off * 4.0 < 3.9e9 && (double)wt_off * 4.0 < 3.9e9;
             p->persist = want && fits && (p->res_chain || force_persist);
             if (p->persist) ngroups = 1;
-            else { p->nres = 0; p->res_chain = false; }
+            else if (p->nres > 0) {   // units and LDS budgets were laid out for resident units: start over without them
+                mfas_population_destroy(p);
+                return MFAS_RETRY_NO_PERSIST;
+            }
         }
         int split = K;
         if (ngroups == 2) {
@@ -588,6 +598,14 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     return MFAS_OK;
 }
 
+extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells,
+                                      const uint32_t* drop_seeds, int32_t K, int32_t device, void* hip_stream,
+                                      int32_t chunk_cols, mfas_population** out) {
+    int rc = create_impl(hp, confs, n_cells, drop_seeds, K, device, hip_stream, chunk_cols, out, true);
+    if (rc == MFAS_RETRY_NO_PERSIST) rc = create_impl(hp, confs, n_cells, drop_seeds, K, device, hip_stream, chunk_cols, out, false);
+    return rc;
+}
+
 extern "C" void mfas_population_destroy(mfas_population* p) {
     if (!p) return;
     hipSetDevice(p->device);
@@ -696,6 +714,8 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     const int K = p->K, B = g.B;
     const int64_t N = train->N;
     const int64_t nb = (N + B - 1) / B;
+    if (p->persist && p->res_wide && train->dtype == MFAS_DT_F32)
+        return fail(MFAS_EINVAL, "this population was created for 16-bit feature tables (mfas_hyper.tap_bits = 16); f32 tables need tap_bits = 32 or 0");
     if (N - (nb - 1) * B == 1 && g.bn)   // torch BatchNorm1d raises on a size-1 train batch
         return fail(MFAS_EINVAL, "final train batch of size 1 with batchnorm (reference raises ValueError)");
 
@@ -825,7 +845,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         pa.sa = st.sa; pa.ca = st.ca;
         pa.sa.desc = p->d_pdescs; pa.sa.tdesc = nullptr; pa.sa.ntap = 0;
         pa.ca.cands = p->d_cands;
-        pa.nchain = K; pa.nitems = p->n_pdescs; pa.nres = p->nres; pa.res_chain = p->res_chain ? 1 : 0;
+        pa.nchain = K; pa.nitems = p->n_pdescs; pa.nres = p->nres; pa.res_chain = p->res_chain ? 1 : 0; pa.res_wide = p->res_wide ? 1 : 0;
         pa.T = (int)T; pa.epoch = ep;
         pa.N = N; pa.pos0 = (int64_t)ep * N;
         pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);

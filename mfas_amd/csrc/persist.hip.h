@@ -24,6 +24,7 @@ struct PersistArgs {
     SweepArgs sa;              // desc = the population's sweep units (per-segment), cands = all candidates
     ChainArgs ca;              // cands = all candidates
     int32_t nchain, nitems;    // K, number of sweep units
+    int32_t res_wide, _pad1;   // resident units wider than 512 columns exist (16-bit staging, 8 tiles per wave)
     int32_t nres, res_chain;   // units [0, nres) are RESIDENT feature units: one workgroup each (blocks K .. K + nres);
                                // res_chain: the (lean) chain owns OUT / HEAD and keeps them + its vector block on chip
     int32_t T, epoch;          // train steps of this launch, epoch index (statistics slot)
@@ -84,7 +85,27 @@ __device__ __forceinline__ void wg_publish_barrier() {
 // Tile -> wave mapping, MFMA order, Adam arithmetic and the cross-wave reduction are those of sweep_body's k-split path:
 // bit-identical to the launch-per-phase schedule run on the same units.
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NTR>
+// X16: bf16 / f16 tables are staged RAW (16-bit) and converted when read as MFMA operands (exact: the same f32 values as the
+// f32 staging) — half the LDS, so a unit may span 1024 columns and ~28 candidates of the search's size fit one GPU.
+__device__ __forceinline__ float cvt16(uint32_t u, int dtype) {
+    return dtype == MFAS_DT_BF16 ? __uint_as_float(u << 16) : __half2float(__ushort_as_half((unsigned short)u));
+}
+// table rows of one batch -> LDS, raw 16-bit elements, row stride S16 halves (16 B aligned rows)
+__device__ __forceinline__ void stage_table16(uint16_t* dst, int S16, const void* tab, int width, int col0, int ncols,
+                                              const int32_t* ord, int64_t pos, int base, int nvalid, int nrows, int tid, int nthreads) {
+    const int vpr = ncols >> 3;
+    for (int e = tid; e < nrows * vpr; e += nthreads) {
+        const int b = e / vpr, c = (e - b * vpr) << 3;
+        uint4 raw = {0u, 0u, 0u, 0u};
+        if (b < nvalid) {
+            const int64_t row = ord ? (int64_t)ord[pos + b] : (int64_t)(base + b);
+            raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(tab) + row * width + col0 + c);
+        }
+        *reinterpret_cast<uint4*>(dst + b * S16 + c) = raw;
+    }
+}
+
+template <int MB, int NTR, bool X16>
 __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int unit, float* lds, int* ldsw) {
     const SweepArgs& sa = a.sa;
     const SegDesc d = sa.desc[unit];
@@ -93,9 +114,24 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
     const int l15 = lane & 15, lg = lane >> 4;
     constexpr int Bp = MB * 16;
     const int cc = d.cc, nkb = cc >> 4;
-    const int S = cc + 4;                         // row stride of both staged batches (16 B aligned rows)
-    float* xbuf[2] = {lds, lds + Bp * S};
-    float* wred = lds + 2 * Bp * S;               // [8 waves][MB][256] cross-wave reduction of the forward partial
+    const int S = X16 ? cc + 8 : cc + 4;          // row stride (elements) of both staged batches (16 B aligned rows)
+    const int bufw = X16 ? (Bp * S) / 2 : Bp * S; // LDS words per staged batch
+    float* xbuf[2] = {lds, lds + bufw};
+    float* wred = lds + 2 * bufw;                 // [8 waves][MB][256] cross-wave reduction of the forward partial
+    const int dt = sa.tab.dtype;
+    // MFMA operand reads from a staged batch: one element (dW: A[i = column][k = batch row]) / four consecutive columns
+    auto x1 = [&](const float* xb, int row, int col) -> float {
+        if constexpr (X16) return cvt16(reinterpret_cast<const uint16_t*>(xb)[row * S + col], dt);
+        else return xb[row * S + col];
+    };
+    auto x4of = [&](const float* xb, int row, int col) -> f32x4 {
+        if constexpr (X16) {
+            const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(xb) + row * S + col);
+            return (f32x4){cvt16(r.x & 0xFFFFu, dt), cvt16(r.x >> 16, dt), cvt16(r.y & 0xFFFFu, dt), cvt16(r.y >> 16, dt)};
+        } else {
+            return *reinterpret_cast<const f32x4*>(xb + row * S + col);
+        }
+    };
     const int K = a.nchain;
     uint32_t* flag = a.sync + d.cand;
     uint32_t* cnt = a.sync + K + d.cand;
@@ -122,7 +158,10 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
 
     auto stage = [&](float* dst, int t) {     // rows of batch t -> LDS (f32)
         const int nv = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
-        stage_table(dst, S, tp, sa.tab.dtype, d.width, d.k0, cc, sa.order, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
+        if constexpr (X16)
+            stage_table16(reinterpret_cast<uint16_t*>(dst), S, tp, d.width, d.k0, cc, sa.order, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
+        else
+            stage_table(dst, S, tp, sa.tab.dtype, d.width, d.k0, cc, sa.order, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
     };
     // forward partial of the staged batch `xn` with the current weights -> partial slot (write-through) -> arrive
     auto reduce_publish = [&](const f32x4 (&yacc)[MB]) {
@@ -156,7 +195,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
             if (kb < nkb) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xbuf[cur] + (mb * 16 + l15) * S + kb * 16 + 4 * lg);
+                    const f32x4 x4 = x4of(xbuf[cur], mb * 16 + l15, kb * 16 + 4 * lg);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[s][q], yacc[mb]);
                 }
@@ -192,7 +231,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < MB * 4; ++j)
-                    acc = MFMA16(xt[(4 * j + lg) * S + kb * 16 + l15], dyf[j], acc);
+                    acc = MFMA16(x1(xt, 4 * j + lg, kb * 16 + l15), dyf[j], acc);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float w = w4[s][q], m = m4[s][q], v = v4[s][q];
@@ -204,7 +243,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
                 if (fwd) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
-                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xn + (mb * 16 + l15) * S + kb * 16 + 4 * lg);
+                        const f32x4 x4 = x4of(xn, mb * 16 + l15, kb * 16 + 4 * lg);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[s][q], yacc[mb]);
                     }
@@ -234,7 +273,8 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
     }
 }
 
-#define PERSIST_NTR 4                   // resident units: tiles per wave (cc <= 128 * PERSIST_NTR columns)
+#define PERSIST_NTR 4                   // resident units, f32 staging: tiles per wave (cc <= 512 columns)
+#define PERSIST_NTR16 8                 // resident units, 16-bit staging: cc <= 1024 columns
 
 template <int MB, bool LEAN, int U>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a, const int lds_word) {
@@ -307,7 +347,9 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
     // whichever of them is ready (its candidate's chain has published the step the unit is waiting for): units of different
     // candidates never block each other (in-order service convoys all candidates behind the slowest chain).
     if (bid < K + a.nres) {
-        sweep_resident<MB, PERSIST_NTR>(a, bid - K, lds, ldsw);
+        if (a.sa.tab.dtype == MFAS_DT_F32) sweep_resident<MB, PERSIST_NTR, false>(a, bid - K, lds, ldsw);
+        else if (a.res_wide) sweep_resident<MB, PERSIST_NTR16, true>(a, bid - K, lds, ldsw);
+        else sweep_resident<MB, PERSIST_NTR, true>(a, bid - K, lds, ldsw);
         return;
     }
     const int G = (int)gridDim.x - K - a.nres, wg = bid - K - a.nres;

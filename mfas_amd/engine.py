@@ -42,6 +42,7 @@ class Hyper:
     loss_mode: int = 0          # 0 CE + top-1 (NTU); 1 weighted BCE-with-logits + F1-samples (MM-IMDB)
     f1_threshold: float = 0.3   # th_fscore, train_searchable/mmimdb.py:16
     allow_plain_cell: bool = False   # [Linear, nl] cells are legal (AV-MNIST, avmnist_searchable.py:276-285)
+    tap_bits: int = 0           # element size of the feature tables to come (16 / 32; 0 = unknown): lets the engine size its units
 
     @classmethod
     def from_args(cls, args) -> "Hyper":
@@ -68,6 +69,7 @@ class Hyper:
         h.loss_mode = int(self.loss_mode)
         h.allow_plain_cell = int(self.allow_plain_cell)
         h.f1_threshold = float(self.f1_threshold)
+        h.tap_bits = int(self.tap_bits)
         return h
 
 

@@ -298,6 +298,7 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
     dev_l = _require_loader(dataloaders["dev"], "dev", device)
     hp = _hp if _hp is not None else Hyper.from_args(args)
     hp.multitask = False    # ntu_searchable.py:82-84 never forwards multitask to the train loop
+    hp.tap_bits = 8 * train_l.table.elem_size() if train_l.table.dtype == dev_l.table.dtype else 0
     if getattr(args, "multitask", False) and _hp is None:
         raise TypeError("max() received an invalid combination of arguments: the searchable returns a tuple "
                         "with --multitask in search mode (reference behaviour, train_searchable/ntu.py:54)")

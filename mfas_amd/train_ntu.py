@@ -34,6 +34,7 @@ def train_ntu_track_acc(model, criteria, optimizer, scheduler, dataloaders, data
     model = model.module if isinstance(model, torch.nn.DataParallel) else model
     hp = _adam_hyper(model.hyper(multitask), optimizer)
     hp.B = train_l.batch_size
+    hp.tap_bits = 8 * train_l.table.elem_size() if train_l.table.dtype == dev_l.table.dtype else 0
     N_tr, N_dev = len(train_l.table), len(dev_l.table)
     nb = -(-N_tr // hp.B)
     if isinstance(scheduler, LRCosineAnnealingScheduler):

@@ -21,7 +21,7 @@ steps = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("steps=")),
 dev = torch.device("cuda:0")
 tr = M.FeatureTable.synthetic(N, 1, dev, torch.bfloat16, snr=0.12)
 dv = M.FeatureTable.synthetic(Nd, 2, dev, torch.bfloat16, snr=0.12)
-hp = M.Hyper(R=R, B=B, bn=bool(bn), drpt=0.5, alphas="alphas" in sys.argv)
+hp = M.Hyper(R=R, B=B, bn=bool(bn), drpt=0.5, alphas="alphas" in sys.argv, tap_bits=16)
 conf4 = np.array([[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]])
 confs = [conf4] * K
 if mixed:

@@ -1,5 +1,5 @@
 """Small-population sweep: candidates/s of one train_sampled_models-sized job (E epochs over N_train / N_dev) for K candidates on
-one GPU, launch-per-phase schedule (MFAS_PERSIST=0) vs persistent step loop (MFAS_PERSIST=1), each with its own default unit
+one GPU, launch-per-phase schedule (MFAS_PERSIST=0) vs the default policy (persistent resident step loop where it fits), each with its own default unit
 decomposition.  usage: popsweep.py R B bn E K1,K2,... [mixed] [N_train N_dev]"""
 import os
 import sys
@@ -20,7 +20,7 @@ N, Nd = (nums + [10000, 5600])[:2] if len(nums) >= 2 else (10000, 5600)
 dev = torch.device("cuda:0")
 tr = M.FeatureTable.synthetic(N, 1, dev, torch.bfloat16, snr=0.12)
 dv = M.FeatureTable.synthetic(Nd, 2, dev, torch.bfloat16, snr=0.12)
-hp = M.Hyper(R=R, B=B, bn=bool(bn), drpt=0.5)
+hp = M.Hyper(R=R, B=B, bn=bool(bn), drpt=0.5, tap_bits=16)
 conf4 = np.array([[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]])
 nb = -(-N // B)
 etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, E * nb)
@@ -32,8 +32,11 @@ for K in Ks:
         rng = np.random.default_rng(0)
         confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in rng.integers(1, 5, K)]
     out = {}
-    for mode in ("0", "1"):
-        os.environ["MFAS_PERSIST"] = mode
+    for mode in ("0", "1"):          # "1" = the engine's default policy (persistent where the resident form fits), "0" = forced off
+        if mode == "0":
+            os.environ["MFAS_PERSIST"] = "0"
+        else:
+            os.environ.pop("MFAS_PERSIST", None)
         best = None
         for rep in range(2):
             torch.cuda.synchronize()
@@ -51,5 +54,5 @@ for K in Ks:
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         out[mode] = best
-    print(f"K={K:4d}  launch {K / out['0']:8.2f} cand/s ({out['0'] / (E * nb) * 1e6:6.1f} us/step)   persistent {K / out['1']:8.2f} cand/s "
+    print(f"K={K:4d}  launch {K / out['0']:8.2f} cand/s ({out['0'] / (E * nb) * 1e6:6.1f} us/step)   default {K / out['1']:8.2f} cand/s "
           f"({out['1'] / (E * nb) * 1e6:6.1f} us/step)   x{out['0'] / out['1']:.2f}", flush=True)
