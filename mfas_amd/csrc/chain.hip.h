@@ -23,6 +23,7 @@ struct ChainArgs {
     DevStats* stats;
     int32_t* status;
     const float* pos_w;   // loss_mode 1: per-class positive weights
+    int32_t yf_reduced, _padr;   // the sweep already reduced the partial sums into the step buffer's yf area (sweep.hip.h)
 };
 
 // what changes from one train step to the next (k_step / k_chain take it from the launch arguments, the persistent loop
@@ -318,7 +319,16 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
 
     // ------------------------------------------------------------------ phase 0: all 512 threads reduce the
     // sweep's column-chunk partial sums of EVERY cell (fixed order) into LDS, loads batched 8 deep
-    {
+    if (a.yf_reduced) {   // one reduced slab per cell (two with alphas): a straight copy, same values the loop below would produce
+        const int per_cell = nrb * MB * 64;
+        const f32x4* src = reinterpret_cast<const f32x4*>(sb + g.sb_yf);
+        if (yf_l != sb + g.sb_yf) {
+            for (int e = tid; e < L * per_cell; e += CHAIN_THREADS) {
+                *reinterpret_cast<f32x4*>(yf_l + (int64_t)e * 4) = src[e];
+                if (g.alphas) *reinterpret_cast<f32x4*>(yf_l + sav_plane + (int64_t)e * 4) = src[sav_plane / 4 + e];
+            }
+        }
+    } else {
         const int per_cell = nrb * MB * 64;   // float4 items per cell
         for (int e = tid; e < L * per_cell; e += CHAIN_THREADS) {
             const int i = e / per_cell, it = e - i * per_cell;

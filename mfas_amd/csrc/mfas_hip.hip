@@ -124,6 +124,8 @@ struct mfas_population {
     // persistent step loop (persist.hip.h): one launch per epoch, per-candidate dependencies
     bool persist = false;
     int n_cus = 0;
+    uint32_t* d_red_cnt = nullptr;  // reduce-in-sweep arrival counters [K][4] (small populations, general chain)
+    bool red_in_sweep = false;
     bool res_wide = false;          // resident units of more than 512 columns (16-bit staging): f32 tables cannot be trained
     bool res_chain = false;         // resident lean chain: owns OUT / HEAD + vector block on chip; persistent units = feature units only
     int nres = 0;                   // resident feature units (one workgroup each, W/m/v in registers): the first nres persistent units
@@ -546,6 +548,12 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             p->groups.push_back(gr);
         }
     }
+    // reduce-in-sweep: one group (the chain is on the critical path), general chain, per-segment units only
+    p->red_in_sweep = p->groups.size() == 1 && !p->lean_chain && !p->persist && p->groups[0].ntap == 0 && !getenv("MFAS_NO_RED_IN_SWEEP");
+    if (p->red_in_sweep) {
+        CREATE_CHK(hipMalloc(&p->d_red_cnt, sizeof(uint32_t) * K * MFAS_MAX_CELLS));
+        CREATE_CHK(hipMemset(p->d_red_cnt, 0, sizeof(uint32_t) * K * MFAS_MAX_CELLS));
+    }
     CREATE_CHK(hipMemsetAsync(p->plane, 0, sizeof(float) * 3 * (size_t)p->plane_stride, p->stream));
     CREATE_CHK(hipMemsetAsync(p->wt, 0, sizeof(float) * (size_t)std::max<int64_t>(p->wt_size, 64), p->stream));
     CREATE_CHK(hipMemsetAsync(p->stepbuf, 0, sizeof(float) * (size_t)p->step_total, p->stream));
@@ -615,6 +623,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     for (auto& gr : p->groups) { hipFree(gr.d_descs); hipFree(gr.d_taps); }
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
     hipFree(p->d_seeds); hipFree(p->d_corr); hipFree(p->d_posw);
+    hipFree(p->d_red_cnt);
     hipFree(p->d_sync); hipFree(p->d_need); hipFree(p->d_scal); hipFree(p->d_trace); hipFree(p->d_pdescs);
     delete p;
 }
@@ -752,6 +761,9 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     st.ca.tab = *train; st.ca.order = order; st.ca.E = epochs; st.ca.g = g; st.ca.stats = p->d_stats;
     st.ca.status = p->d_status; st.ca.ac = ac; st.ca.yf_in_lds = p->yf_in_lds ? 1 : 0; st.ca.pos_w = p->d_posw;
     st.ca.vec_in_lds = p->vec_in_lds ? 1 : 0;
+    st.sa.red_cnt = p->red_in_sweep ? p->d_red_cnt : nullptr;
+    st.ca.yf_reduced = p->red_in_sweep ? 1 : 0;
+    if (p->red_in_sweep) HIPCHK(hipMemsetAsync(p->d_red_cnt, 0, sizeof(uint32_t) * K * MFAS_MAX_CELLS, p->stream));
 
     const int elt = train->dtype == MFAS_DT_F32 ? 4 : 2;
     p->prof_launches = 0; p->prof_ms = 0.0; p->prof_bytes = 0.0;

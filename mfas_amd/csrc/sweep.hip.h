@@ -103,6 +103,10 @@ struct SweepArgs {
     int32_t do_update, do_forward;
     AdamC ac;
     Geo g;
+    // reduce-in-sweep (small populations, general chain): per (candidate, cell) arrival counters; the LAST feature workgroup of a
+    // cell to finish sums the cell's partial slabs (fixed order = the chain's phase 0) into the step buffer's yf area, so the
+    // next launch's chain reads 1 (or 2, alphas) reduced slab per cell instead of pulling every partial through its one CU
+    uint32_t* red_cnt;
 };
 
 // what changes from one train step to the next (k_step takes it from the launch arguments, the persistent loop computes it)
@@ -143,6 +147,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
     const bool fwd = (st.fwd != 0) && feat;
     if (!upd && !fwd) return;
     const int64_t sbo = cd.step_off;   // this candidate's step buffers inside a.stepbuf
+    const bool red = a.red_cnt != nullptr;
 
     if (upd) {
         if (feat) {
@@ -196,21 +201,69 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
             for (int mb = 0; mb < MB; ++mb) {
                 if (split_k)
                     *reinterpret_cast<f32x4*>(wred + (((wave * nrb + rb) * MB + mb) << 8) + lane * 4) = yacc[mb];
+                else if (red) stc4<true>(a.stepbuf, part + ((rb * MB + mb) << 8) + lane * 4, yacc[mb]);
                 else   // partial slot in MFMA D layout [chunk][rb][mb][lane][4]
                     stc4<COH>(a.stepbuf, part + ((rb * MB + mb) << 8) + lane * 4, yacc[mb]);
             }
         }
     }
-    if (!fwd || !split_k) return;
-    __syncthreads();
-    // deterministic cross-wave reduction (fixed order 0..7)
-    for (int e = tid; e < nrb * MB * 64; e += STEP_THREADS) {
-        const int slot = e >> 6, ln = e & 63;
-        f32x4 s = *reinterpret_cast<const f32x4*>(wred + (slot << 8) + ln * 4);
+    if (!fwd) return;
+    if (split_k) {
+        __syncthreads();
+        // deterministic cross-wave reduction (fixed order 0..7)
+        for (int e = tid; e < nrb * MB * 64; e += STEP_THREADS) {
+            const int slot = e >> 6, ln = e & 63;
+            f32x4 s = *reinterpret_cast<const f32x4*>(wred + (slot << 8) + ln * 4);
 #pragma unroll
-        for (int w = 1; w < STEP_NW; ++w)
-            s += *reinterpret_cast<const f32x4*>(wred + ((w * nrb * MB + slot) << 8) + ln * 4);
-        stc4<COH>(a.stepbuf, part + (slot << 8) + ln * 4, s);
+            for (int w = 1; w < STEP_NW; ++w)
+                s += *reinterpret_cast<const f32x4*>(wred + ((w * nrb * MB + slot) << 8) + ln * 4);
+            if (red) stc4<true>(a.stepbuf, part + (slot << 8) + ln * 4, s);
+            else stc4<COH>(a.stepbuf, part + (slot << 8) + ln * 4, s);
+        }
+    }
+    if (!red) return;
+    // ---- reduce-in-sweep: arrive on the cell's counter; the last arriver sums the cell's slabs (write-through stores + every
+    // wave's drain + barrier + relaxed agent-scope counter on the producer side, sc1 loads on the reader's: G16 R1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flagw = reinterpret_cast<int*>(lds);      // (the staging tiles are dead by now)
+    const int ns_c = cd.nch_s[d.cell], nch_c = ns_c + cd.nch_v[d.cell];
+    if (tid == 0) {
+        uint32_t* cnt = a.red_cnt + d.cand * MFAS_MAX_CELLS + d.cell;
+        const uint32_t old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (uint32_t)(nch_c - 1);
+        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        flagw[0] = last;
+    }
+    __syncthreads();
+    if (!flagw[0]) return;
+    {
+        const int snrb = d.seg_nrb;
+        const int per_cell = snrb * MB * 64;            // float4 items of the cell's [nrb][MB][256] slab
+        const int64_t part0 = sbo + a.g.sb_part + (((int64_t)cd.part_cell_off[d.cell] * snrb * MB) << 8);
+        const int64_t yf0 = sbo + a.g.sb_yf + (int64_t)d.cell * per_cell * 4;
+        const int64_t vplane = (int64_t)MFAS_MAX_CELLS * snrb * MB * 256;
+        for (int it = tid; it < per_cell; it += STEP_THREADS) {
+            f32x4 accS = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
+            constexpr int PB = 8;
+            for (int ch0 = 0; ch0 < nch_c; ch0 += PB) {
+                f32x4 p8[PB];
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+                    if (ch0 + u < nch_c) p8[u] = ldc4<true>(a.stepbuf, part0 + (((int64_t)(ch0 + u) * snrb * MB) << 8) + it * 4);
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+                    if (ch0 + u < nch_c) {
+                        if (ch0 + u < ns_c) accS += p8[u]; else accV += p8[u];
+                    }
+            }
+            if (a.g.alphas) {
+                *reinterpret_cast<f32x4*>(a.stepbuf + yf0 + it * 4) = accS;
+                *reinterpret_cast<f32x4*>(a.stepbuf + yf0 + vplane + it * 4) = accV;
+            } else {
+                *reinterpret_cast<f32x4*>(a.stepbuf + yf0 + it * 4) = accS + accV;
+            }
+        }
     }
 }
 

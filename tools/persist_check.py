@@ -30,9 +30,17 @@ if mixed:
 nb = -(-N // B)
 etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, E * nb)
 order = M.ntu_searchable.make_order(N, E, True, 5, dev)
+toggle = next((a.split("=")[1] for a in sys.argv if a.startswith("toggle=")), None)   # compare ENV=1 ("0") against unset ("1") instead
 res = {}
 for mode in ("0", "1", "0", "1"):
-    os.environ["MFAS_PERSIST"] = mode
+    if toggle:
+        os.environ["MFAS_PERSIST"] = "0"
+        if mode == "0":
+            os.environ[toggle] = "1"
+        else:
+            os.environ.pop(toggle, None)
+    else:
+        os.environ["MFAS_PERSIST"] = mode
     pop = M.Population(hp, confs, dev, drop_seeds=list(range(100, 100 + K)), chunk_cols=cc)
     pop.init(list(range(1, K + 1)))
     torch.cuda.synchronize()
