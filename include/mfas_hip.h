@@ -132,6 +132,13 @@ int mfas_population_train(mfas_population* pop, const mfas_table* train, const m
 int mfas_population_forward(mfas_population* pop, int32_t k, const mfas_table* tab, int64_t row0,
                             int64_t nrows, float* logits, int64_t* corrects);
 
+/* Replaces Searchable_Skeleton_Image_Net.forward in TRAIN mode (ntu_searchable.py:206-247 with model.train(True)) for
+ * candidate k on ONE batch = rows [row0, row0+nrows) of a table, nrows <= hyper.B: batch-statistics BatchNorm (the running
+ * statistics are updated, as any train-mode forward does), dropout from the candidate's stream at `step_index`; writes
+ * logits (nrows, C) (device).  No gradient is produced: the train loop (forward + backward + Adam) is mfas_population_train. */
+int mfas_population_forward_train(mfas_population* pop, int32_t k, const mfas_table* tab, int64_t row0, int32_t nrows,
+                                  int32_t step_index, float* logits);
+
 /* Timing of the dominant kernel (fused cell sweep) over the last train() call, measured with HIP
  * events on the population's stream: number of launches, summed milliseconds, and the algorithmic
  * HBM bytes of one update+forward launch (24*P_tiles + feature bytes). */

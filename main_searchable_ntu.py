@@ -52,6 +52,9 @@ def parse_args(argv=None):
     p.add_argument("--engine_init", default="torch", choices=["torch", "device"])
     p.add_argument("--surrogate_device", default="cpu", choices=["cpu", "gpu"],
                    help="where the 81k-parameter LSTM surrogate trains (the reference puts it on its training device)")
+    p.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
+                   help="torch.distributed backend under torchrun: nccl = RCCL over xGMI (one GPU per rank); gloo lets several ranks "
+                        "share one GPU (tests)")
     p.add_argument("--timing", action="store_true", help="print how the wall time splits into candidate training (GPU) and the controller / surrogate (CPU)")
     p.add_argument("--controller_threads", type=int, default=4,
                    help="torch CPU threads for the 81k-parameter surrogate (more threads only add overhead)")
@@ -64,10 +67,14 @@ def main(argv=None):
     args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group("gloo")
     torch.set_num_threads(max(1, args.controller_threads))
     torch.manual_seed(args.seed)          # every rank runs the same (seeded) controller
     np.random.seed(args.seed)

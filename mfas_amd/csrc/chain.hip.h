@@ -24,6 +24,8 @@ struct ChainArgs {
     int32_t* status;
     const float* pos_w;   // loss_mode 1: per-class positive weights
     int32_t yf_reduced, _padr;   // the sweep already reduced the partial sums into the step buffer's yf area (sweep.hip.h)
+    float* logits_out;           // train-mode FORWARD ONLY (mfas_population_forward_train): write the batch's logits (nvalid x C)
+                                 // after the head and stop — batch-statistics BN (running stats updated), dropout stream of `gstep`
 };
 
 // what changes from one train step to the next (k_step / k_chain take it from the launch arguments, the persistent loop
@@ -517,6 +519,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     }
     lds_barrier();
     CT_STAMP(6);
+    if (a.logits_out) {   // train-mode forward only
+        for (int e = tid; e < nvalid * C; e += CHAIN_THREADS) {
+            const int b = e / C, c = e - b * C;
+            a.logits_out[e] = lg_l[b * SC + c];
+        }
+        return;
+    }
     if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
     } else if (tid < LPR * Bp) {
@@ -1035,6 +1044,15 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     }
     lds_barrier();
     CT_STAMP(6);
+    if constexpr (MODE == 0) {
+        if (a.logits_out) {   // train-mode forward only
+            for (int e = tid; e < nvalid * C; e += CHAIN_THREADS) {
+                const int b = e / C, c = e - b * C;
+                a.logits_out[e] = lg_l[b * SC + c];
+            }
+            return;
+        }
+    }
     if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
     } else if (tid < LPR * Bp) {

@@ -259,7 +259,9 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         while (target > 64 && tot_cols / target < 320.0) target >>= 1;           // ... but keep >= ~320 workgroups
         // R >= 128, measured on MI355X: 64-column chunks (finer, better-balanced workgroups) win once
         // the chain is hidden under the other group's sweep (K >= 20); below that fewer partial chunks matter more
-        if (g.nrb >= 8) target = std::min(target, K >= 20 ? 64 : 256);   // (K >= 20 at R >= 128 <=> fused schedule)
+        // (round 2: with reduce-in-sweep the number of partial slabs no longer loads the chain; 256-column chunks stay best up
+        // to ~28 candidates, 64 beyond — profiles/r02_popsweep_r128.log)
+        if (g.nrb >= 8) target = std::min(target, K >= 28 ? 64 : 256);
     }
     target = std::max(16, (target / 16) * 16);
     p->cands.resize(K);
@@ -466,7 +468,9 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         // general chain, R=128: 16 candidates 104 vs 96, 20: 103 vs 110, 32: 119 vs 142 -> fused from 20;
         // lean chain, R=16 (18 us, cheap enough to run as its own launch over all CUs): 32: 348 vs 307, 40: 361 vs 364,
         // 50: 430 vs 475, 100: 582 vs 677, 200: 566 vs 600, 256: 630 vs 619, 512: 685 vs 641 -> fused only for 40 <= K < 224.
-        int ngroups = p->lean_chain ? ((K >= 40 && K < 224) ? 2 : 1) : (K >= 20 ? 2 : 1);
+        // round 2, general chain with reduce-in-sweep (chain 48 -> 38 us at R=128): fused from 8 candidates
+        // (R=128 cand/s unfused+reduce vs fused+reduce: 12 candidates 18.1 vs 20.2, 16: 21.0 vs 23.6, 24: 22.9 (old default) vs 26.6)
+        int ngroups = p->lean_chain ? ((K >= 40 && K < 224) ? 2 : 1) : (K >= 8 ? 2 : 1);
         if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
         {   // persistent step loop: small populations (one workgroup per CU must hold every chain + a useful number of sweep workgroups)
             const bool want = want_persist;
@@ -549,7 +553,9 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         }
     }
     // reduce-in-sweep: one group (the chain is on the critical path), general chain, per-segment units only
-    p->red_in_sweep = p->groups.size() == 1 && !p->lean_chain && !p->persist && p->groups[0].ntap == 0 && !getenv("MFAS_NO_RED_IN_SWEEP");
+    // (beyond ~28 candidates the co-scheduled chain is hidden anyway and the extra write-through traffic costs: 29.0 vs 26.7 cand/s at 32)
+    p->red_in_sweep = K < 28 && !p->lean_chain && !p->persist && !getenv("MFAS_NO_RED_IN_SWEEP");
+    for (const auto& gr : p->groups) if (gr.ntap != 0) p->red_in_sweep = false;     // (tap-major workgroups serve several candidates)
     if (p->red_in_sweep) {
         CREATE_CHK(hipMalloc(&p->d_red_cnt, sizeof(uint32_t) * K * MFAS_MAX_CELLS));
         CREATE_CHK(hipMemset(p->d_red_cnt, 0, sizeof(uint32_t) * K * MFAS_MAX_CELLS));
@@ -1012,6 +1018,62 @@ extern "C" int mfas_population_forward(mfas_population* p, int32_t k, const mfas
         HIPCHK(hipStreamSynchronize(p->stream));
         *corrects = (int64_t)h;
     }
+    return MFAS_OK;
+}
+
+extern "C" int mfas_population_forward_train(mfas_population* p, int32_t k, const mfas_table* tab, int64_t row0, int32_t nrows,
+                                             int32_t step_index, float* logits) {
+    if (!p || !logits || k < 0 || k >= p->K || row0 < 0) return fail(MFAS_EINVAL, "bad argument");
+    int rc = check_table(p, tab, false);
+    if (rc) return rc;
+    const Geo& g = p->g;
+    if (nrows < 1 || nrows > g.B) return fail(MFAS_EINVAL, "train-mode forward: 1 <= rows <= the population's batch size");
+    if (nrows == 1 && g.bn) return fail(MFAS_EINVAL, "train-mode BatchNorm needs more than 1 row (reference: ValueError)");
+    if (row0 + nrows > tab->N) return fail(MFAS_EINVAL, "row range outside the table");
+    HIPCHK(hipSetDevice(p->device));
+    StepArgs st;
+    memset(&st, 0, sizeof(st));
+    st.sa.cands = p->d_cands; st.sa.plane = p->plane; st.sa.plane_stride = p->plane_stride; st.sa.wt = p->wt;
+    st.sa.stepbuf = p->stepbuf; st.sa.tab = *tab; st.sa.order = nullptr; st.sa.g = g;
+    st.sa.desc = p->d_descs + p->desc_start[k]; st.sa.tdesc = nullptr; st.sa.ntap = 0;
+    st.sa.do_update = 0; st.sa.do_forward = 1;
+    st.sa.pos_n = row0; st.sa.base_n = (int)row0; st.sa.nvalid_n = nrows;
+    st.sa.pos_t = row0; st.sa.base_t = (int)row0; st.sa.nvalid_t = nrows;
+    st.sa.ac.ss = 0.f; st.sa.ac.bc2s = 1.f;
+    st.nchain = 0;
+    const unsigned nsw = (unsigned)(p->desc_start[k + 1] - p->desc_start[k]);
+    size_t lds_need = p->lds_step;   // (a population laid out for resident units budgets its streaming LDS without them)
+    for (int j = p->desc_start[k]; j < p->desc_start[k + 1]; ++j) {
+        const SegDesc& d = p->descs[j];
+        size_t fl = (size_t)g.Bp * (d.cc + 16) + (size_t)g.Bp * (d.cc + 4) + (size_t)g.Bp * (d.rows_p + 16);
+        if (d.rows_p / 16 < STEP_NW && d.kind <= KIND_V) fl += (size_t)STEP_NW * (d.rows_p / 16) * g.MB * 256;
+        lds_need = std::max(lds_need, fl * 4);
+    }
+    if (lds_need > 150 * 1024) return fail(MFAS_EINVAL, "train-mode forward: this population's units are too wide for the streaming kernels");
+    if (lds_need > p->lds_step) {
+        if (g.MB == 1) HIPCHK(set_lds((k_step<1, false, 4, false>), lds_need));
+        else if (g.MB == 2) HIPCHK(set_lds((k_step<2, false, 2, false>), lds_need));
+        else HIPCHK(set_lds((k_step<4, false, 2, false>), lds_need));
+    }
+    // 1. forward partial sums of the batch (no update): the sweep's forward half over this candidate's units
+    if (g.MB == 1) hipLaunchKernelGGL((k_step<1, false, 4, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
+    else if (g.MB == 2) hipLaunchKernelGGL((k_step<2, false, 2, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
+    else hipLaunchKernelGGL((k_step<4, false, 2, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
+    // 2. the chain up to the logits: batch-statistics BN (running statistics move like in any train-mode forward), dropout
+    ChainArgs& c = st.ca;
+    c.cands = p->d_cands + k; c.plane = p->plane; c.plane_stride = p->plane_stride; c.wt = p->wt; c.stepbuf = p->stepbuf;
+    c.tab = *tab; c.order = nullptr; c.pos_t = row0; c.base_t = (int)row0; c.nvalid = nrows;
+    c.gstep = step_index; c.epoch = 0; c.E = 1; c.g = g; c.stats = nullptr; c.status = p->d_status;
+    c.yf_in_lds = p->yf_in_lds ? 1 : 0; c.vec_in_lds = p->vec_in_lds ? 1 : 0; c.pos_w = p->d_posw;
+    c.yf_reduced = 0; c.logits_out = logits;
+#define CHAIN_LAUNCH(M, F) hipLaunchKernelGGL((k_chain<M, F>), dim3(1), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca)
+    if (p->lean_chain) { if (g.MB == 1) CHAIN_LAUNCH(1, true); else CHAIN_LAUNCH(2, true); }
+    else if (g.MB == 1) CHAIN_LAUNCH(1, false);
+    else if (g.MB == 2) CHAIN_LAUNCH(2, false);
+    else CHAIN_LAUNCH(4, false);
+#undef CHAIN_LAUNCH
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(p->stream));
     return MFAS_OK;
 }
 

@@ -388,6 +388,17 @@ class Population:
                                                         C.byref(corr) if count else None))
         return (logits, int(corr.value)) if count else logits
 
+    def forward_train(self, k: int, table: FeatureTable, row0: int = 0, nrows: Optional[int] = None, step: int = 0):
+        """Train-mode forward of ONE batch (<= hp.B rows): batch-statistics BN (running stats move), dropout stream at `step`."""
+        nrows = len(table) - row0 if nrows is None else nrows
+        self._check_table(table)
+        logits = torch.empty((nrows, self.hp.C), dtype=torch.float32, device=self.device)
+        tc = table.to_c()
+        with torch.cuda.device(self._idx):
+            _lib.check(self.lib.mfas_population_forward_train(self._h, k, C.byref(tc), row0, nrows, int(step),
+                                                              C.c_void_p(logits.data_ptr())))
+        return logits
+
     def set_pos_weight(self, w):
         w = np.ascontiguousarray(np.asarray(w, np.float32))
         assert w.size == self.hp.C

@@ -164,9 +164,6 @@ class Searchable_Skeleton_Image_Net(nn.Module):
         """tensor_tuple = (rgb, ske): dict-likes holding the pooled taps v0..v3 [+ 'vlogit'] and s0..s3
         [+ 'slogit'] on a HIP device.  Eval mode only: training runs inside the engine
         (train_sampled_models / train_ntu_track_acc)."""
-        if self.training:
-            raise NotImplementedError("training-mode forward lives in the HIP engine: use train_sampled_models / "
-                                      "train_ntu_track_acc; call .eval() for inference")
         image, skeleton = tensor_tuple[0], tensor_tuple[1]
         visual = self.rgbnet(image)
         skel = self.skenet(skeleton)
@@ -175,6 +172,27 @@ class Searchable_Skeleton_Image_Net(nn.Module):
         some = next(iter(taps.values()))
         n = some.shape[0]
         table = FeatureTable(taps, torch.zeros(n, dtype=torch.int32, device=some.device))
+        if self.training:
+            # train mode (ntu_searchable.py:206-247 under model.train(True)): batch-statistics BatchNorm — running statistics and
+            # num_batches_tracked move — and Dropout (the engine's counter-based stream, seeded from torch's RNG).  The logits
+            # carry no autograd graph: backward + Adam run inside the engine (train_ntu_track_acc / train_sampled_models).
+            if not 1 <= n <= 64:
+                raise NotImplementedError("train-mode forward handles one batch of 1..64 samples (the engine's batch range)")
+            if n == 1 and self.args.batchnorm:
+                raise ValueError("Expected more than 1 value per channel when training")     # torch BatchNorm1d's message
+            hp = self.hyper(False)
+            hp.B = max(n, 2)
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            pop = Population(hp, [self.conf], some.device, drop_seeds=[seed & 0xFFFFFFFF])
+            pop.set_params(0, self.flat_params())
+            out = pop.forward_train(0, table, 0, n, step=0)
+            if self.args.batchnorm:
+                self.load_flat(pop.get_params(0))      # the moved running statistics (nothing else changed)
+                _bump_bn_counters(self, 1)
+            pop.close()
+            if not self.args.multitask:
+                return out
+            return out, visual["vlogit"], skel["slogit"]
         pop = self._engine(some.device, False)
         pop.set_params(0, self.flat_params())
         out = pop.forward(0, table)

@@ -280,3 +280,76 @@ def test_generic_pooled_tap_loader_is_accepted(dev):
         M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net,
                                {"train": [{"rgb": torch.zeros(2, 3, 8, 32, 32), "ske": torch.zeros(2, 3, 8, 25, 2), "label": torch.zeros(2)}],
                                 "dev": fast["dev"]}, args, dev)
+
+
+@pytest.mark.parametrize("R,B,bn,drpt", [(16, 20, False, 0.5), (16, 16, True, 0.3), (128, 16, True, 0.5), (64, 11, True, 0.0)])
+def test_train_mode_forward_vs_oracle(dev, R, B, bn, drpt):
+    """mfas_population_forward_train == Searchable_Skeleton_Image_Net.forward under model.train(True)
+    (ntu_searchable.py:206-247): batch-statistics BN with running-stat update, dropout (the oracle shares the engine's
+    counter-based stream), logits of one batch; the module surface returns the same and bumps num_batches_tracked."""
+    import mfas_amd as M
+    from tests.helpers import engine_hyper, rel_err
+    ohp = O.Hyper(R=R, B=B, bn=bn, drpt=drpt)
+    conf = np.array(CONFS["c4"])
+    t = O.synth_table(B, 91, snr=0.4)
+    tab = M.FeatureTable.from_numpy(t, dev, torch.float32)
+    params = O.init_params(conf, ohp, 17, perturb_bn=True)
+    pop = M.Population(engine_hyper(ohp), [conf], dev, drop_seeds=[77])
+    pop.set_state_dict(0, params)
+    got = pop.forward_train(0, tab, 0, B, step=5).cpu().numpy()
+    feats = {k: v for k, v in t.items() if k != "label"}
+    want, cache = O.forward({k: v.copy() for k, v in params.items()}, conf, ohp, feats, True, seed=77, step=5)
+    assert rel_err(got, want) < 3e-4, rel_err(got, want)
+    if bn:      # the running statistics moved exactly like a train step's
+        p2 = {k: v.copy() for k, v in params.items()}
+        O.bn_update_running(p2, ohp, cache)
+        sd = pop.get_state_dict(0)
+        for i in range(4):
+            for nm in ("running_mean", "running_var"):
+                np.testing.assert_allclose(sd[f"fusion_layers.{i}.2.{nm}"].numpy(), p2[f"fusion_layers.{i}.2.{nm}"], rtol=2e-4, atol=1e-6)
+    # eval-mode forward of the same rows differs (dropout / batch statistics) unless there is neither
+    ev = pop.forward(0, tab).cpu().numpy()
+    assert (rel_err(ev, want) > 1e-3) or (not bn and drpt == 0.0)
+    pop.close()
+    # module surface: train() -> train-mode forward on the engine, eval() -> eval-mode forward
+    args = mkargs(inner_representation_size=R, batchnorm=bn, drpt=drpt, batchsize=B)
+    model = M.Searchable_Skeleton_Image_Net(args, conf)
+    model.train(True)
+    x = {k: torch.from_numpy(v).to(dev) for k, v in feats.items()}
+    rgb, ske = {k: v for k, v in x.items() if k[0] == "v"}, {k: v for k, v in x.items() if k[0] == "s"}
+    out = model((rgb, ske))
+    assert out.shape == (B, 60) and torch.isfinite(out).all()
+    if bn:
+        assert int(model.fusion_layers[0][2].num_batches_tracked) == 1
+        assert not torch.allclose(model.fusion_layers[0][2].running_mean, torch.zeros(R))
+    model.train(False)
+    out2 = model((rgb, ske))
+    assert out2.shape == (B, 60)
+
+
+def test_search_cli_two_ranks_matches_single(dev):
+    """main_searchable_ntu.py end to end under 2 processes (gloo, both on cuda:0): every rank runs the seeded controller, the
+    population of every call is sharded, accuracies are all-gathered — the search result equals the single-process run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "main_searchable_ntu.py"), "--synthetic", "600", "300", "--num_samples", "6",
+           "--search_iterations", "2", "--max_fusions", "2", "--epochs", "1", "--epochs_surrogate", "5", "--no-verbose",
+           "--dist_backend", "gloo", "--seed", "3", "--batchsize", "20"]
+
+    def run(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", WORLD_SIZE=str(world))
+        procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                 for r in range(world)]
+        outs = []
+        for p in procs:
+            out, _ = p.communicate(timeout=900)
+            assert p.returncode == 0, out.decode()[-3000:]
+            outs.append(out.decode())
+        text = outs[0]
+        listing = text[text.index("Now listing best architectures"):]
+        return [l for l in listing.splitlines()[1:] if l.startswith("[[")]
+
+    one, two = run(1), run(2)
+    assert len(one) == 5 and one == two, (one, two)

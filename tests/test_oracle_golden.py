@@ -186,3 +186,41 @@ def test_dropout_mask_rate():
     assert abs(keep.mean() - 0.5) < 0.03
     keep2 = O.dropout_keep(7, 4, 1, 64, 128, 0.5)
     assert (keep != keep2).mean() > 0.4
+
+
+def test_torch_restatement_matches_numpy_oracle():
+    """oracle/torch_restatement.py (the PyTorch-CPU eager baseline bench.py times) follows the same step sequence as the
+    reference-pinned numpy oracle: same network from the same parameters -> same logits, same loss, and after one Adam step
+    with the scheduler's eta the same parameters."""
+    torch = pytest.importorskip("torch")
+    from oracle import torch_restatement as TR
+    conf = np.array(CONFS["c4"])
+    hp = O.Hyper(R=16, B=16, bn=True, drpt=0.0, epochs=1)
+    t = O.synth_table(16, 5, snr=0.4)
+    params = O.init_params(conf, hp, 3)
+    net = TR.FusionNet(conf, 16, 60, True, 0.0)
+    sd = net.state_dict()
+    for k, v in params.items():
+        if k in sd:
+            sd[k].copy_(torch.from_numpy(v))
+    net.train(True)
+    feats = {k: torch.from_numpy(v) for k, v in t.items() if k != "label"}
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-4)
+    out = net(feats)
+    loss = torch.nn.CrossEntropyLoss()(out, torch.from_numpy(t["label"]))
+    want_logits, cache = O.forward({k: v.copy() for k, v in params.items()}, conf, hp, {k: v for k, v in t.items() if k != "label"}, True)
+    np.testing.assert_allclose(out.detach().numpy(), want_logits, rtol=2e-4, atol=2e-5)
+    want_loss, dlog, _ = O.ce_loss(want_logits, t["label"])
+    assert abs(float(loss) - float(want_loss)) < 1e-5
+    eta = float(O.eta_sequence(1e-3, 1e-6, 1, 2, 1.0, 1)[0])
+    TR.push_lr(opt, eta)
+    loss.backward()
+    opt.step()
+    p2 = {k: v.copy() for k, v in params.items()}
+    grads = O.backward(p2, hp, cache, dlog)
+    st = O.AdamState()
+    O.adam_step(p2, grads, st, eta, hp, O.trainable_keys(conf, hp))
+    got = net.state_dict()
+    for k in ("fusion_layers.0.0.weight", "fusion_layers.3.0.bias", "central_classifier.weight", "fusion_layers.1.2.weight"):
+        np.testing.assert_allclose(got[k].numpy(), p2[k], rtol=0, atol=2.1e-3)      # |dw| = lr at step 1: signs must agree
+        assert np.mean(np.abs(got[k].numpy() - p2[k]) > 1e-5) < 0.02, k

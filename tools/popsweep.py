@@ -15,6 +15,7 @@ from oracle import np_oracle as O
 R, B, bn, E = (int(x) for x in sys.argv[1:5])
 Ks = [int(x) for x in sys.argv[5].split(",")]
 mixed = "mixed" in sys.argv
+cc = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("cc=")), 0)
 nums = [int(a) for a in sys.argv[6:] if a.isdigit()]
 N, Nd = (nums + [10000, 5600])[:2] if len(nums) >= 2 else (10000, 5600)
 dev = torch.device("cuda:0")
@@ -42,7 +43,7 @@ for K in Ks:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             try:
-                pop = M.Population(hp, confs, dev, drop_seeds=list(range(100, 100 + K)))
+                pop = M.Population(hp, confs, dev, drop_seeds=list(range(100, 100 + K)), chunk_cols=cc)
                 pop.init(list(range(1, K + 1)))
                 stats, status = pop.train(tr, dv, E, etas, order=order)
                 pop.close()
