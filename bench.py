@@ -121,25 +121,32 @@ def cpu_baseline(train, dev, args, budget_s=24.0):
     # the PyTorch-CPU eager restatement of the reference step sequence (oracle/torch_restatement.py),
     # ONE FULL epoch (all train batches + the whole dev table) on all host cores and, for comparison, on 8 threads
     try:
-        import torch as _t
-        from oracle import torch_restatement as TR
-        full_tr = {k: v.float().cpu() for k, v in train.taps.items()}
-        full_tr = {k: v[:, :train.widths[k]].contiguous() for k, v in full_tr.items()}
-        full_tr["label"] = train.label.cpu().long()
-        full_dv = {k: v.float().cpu()[:, :dev.widths[k]].contiguous() for k, v in dev.taps.items()}
-        full_dv["label"] = dev.label.cpu().long()
+        import subprocess
         runs = []
-        for nt_t in sorted({min(8, os.cpu_count() or 1), os.cpu_count() or 1}):
-            sec, acc, used = TR.time_candidate(full_tr, full_dv, CONF4, args.R, args.batch, not args.no_bn, args.drpt,
-                                               epochs_timed=1, threads=nt_t)
-            runs.append({"threads": used, "s_per_epoch": sec, "cand_per_s": 1.0 / (sec * args.epochs)})
-        bestt = max(runs, key=lambda r: r["cand_per_s"])
+        ncpu = os.cpu_count() or 1
+        # 8 threads: a FULL epoch (about 6-10 s); all host cores: whatever fits 15 s (eager per-op dispatch does not scale to
+        # hundreds of threads — the survey measured 1.24x from 1 to 8).  Each run is a subprocess with a hard timeout.
+        for nt_t, budget in sorted({(min(8, ncpu), 60.0), (ncpu, 15.0)}):
+            cmd = [sys.executable, "-m", "oracle.torch_restatement", "--n-train", str(len(train)), "--n-dev", str(len(dev)),
+                   "--R", str(args.R), "--B", str(args.batch), "--bn", str(int(not args.no_bn)), "--drpt", str(args.drpt),
+                   "--threads", str(nt_t), "--budget", str(budget)]
+            try:
+                res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=budget + 120,
+                                     env=dict(os.environ, OMP_NUM_THREADS=str(nt_t), MKL_NUM_THREADS=str(nt_t)))
+                line = [l for l in res.stdout.splitlines() if l.startswith("TORCH_RESTATEMENT ")][-1]
+                r = json.loads(line[len("TORCH_RESTATEMENT "):])
+                runs.append({"threads": r["threads"], "s_per_epoch": r["s_per_epoch"], "cand_per_s": 1.0 / (r["s_per_epoch"] * args.epochs),
+                             "train_steps_timed": r["steps"], "dev_rows_timed": r["dev_rows"], "full_epoch": r["full_epoch"]})
+            except Exception as e:
+                runs.append({"threads": nt_t, "error": repr(e)[:200]})
+        good = [r for r in runs if "cand_per_s" in r]
+        bestt = max(good, key=lambda r: r["cand_per_s"])
         out["torch_eager"] = {"value": bestt["cand_per_s"], "unit": "candidates/s", "cores": bestt["threads"], "kind": "port",
                               "runs": runs,
-                              "sample": f"1 full epoch ({nb} train steps of B={args.batch} + {len(dev)} dev rows) of conf-4 R={args.R} in "
-                                        f"PyTorch-CPU eager (restatement of the reference loop incl. its per-step optimizer "
-                                        f"state_dict round trip), x E={args.epochs}; host has {os.cpu_count()} logical cores"}
-        _t.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+                              "sample": f"one epoch ({nb} train steps of B={args.batch} + {len(dev)} dev rows) of conf-4 R={args.R} in PyTorch-CPU "
+                                        f"eager (restatement of the reference loop incl. its per-step optimizer state_dict round trip) on "
+                                        f"same-shaped synthetic tables, per thread count: complete at {min(8, ncpu)} threads, time-boxed to 15 s "
+                                        f"at {ncpu} (runs[].full_epoch), x E={args.epochs}; host has {ncpu} logical cores"}
     except Exception as e:   # the baseline is a report, never a reason to lose the bench line
         out["torch_eager"] = {"error": repr(e)}
     return out
