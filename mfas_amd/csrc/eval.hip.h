@@ -62,14 +62,13 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
         for (int sv = 0; sv < 2; ++sv) {
             const int tap = cd.conf[i][sv];
             const void* tp = sv == 0 ? a.tab.s[tap] : a.tab.v[tap];
-            const int cols = cd.seg_cols[i][sv], cc = cd.seg_cc[i][sv];
+            const int cols = (vdead && sv == 1) ? 0 : cd.seg_cols[i][sv], cc = cd.seg_cc[i][sv];   // (sigma(alpha) == 1: no V columns)
             const int tw = sv == 0 ? g.sw[tap] : g.vw[tap];
             if (g.alphas && sv == 1) {   // switch modality: fold the S sum with its scale, restart for V
 #pragma unroll
                 for (int j = 0; j < NRBW; ++j)
 #pragma unroll
                     for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * (vdead ? sgS : sgS / sgV);
-                if (vdead) break;
             }
             for (int c0 = 0; c0 < cols; c0 += EVAL_CE) {
                 const int nc = min(EVAL_CE, cols - c0);
