@@ -152,6 +152,45 @@ __device__ __forceinline__ void bce_rows(float* lg_l, int SC, float* red, int Bp
     }
 }
 
+// Reductions over the LPR (<= 16) lanes that share a batch row, on the DPP cross-lane path (one VALU op per stage instead of
+// an LDS-crossbar ds_bpermute per __shfl_xor): stage 1 / 2 swap inside quads (quad_perm), stage 4 mirrors each half row
+// (lane i <-> 7 - i), stage 8 mirrors the row (i <-> 15 - i).  Every lane ends with the reduction over its 16 (8, 4, ...)
+// lanes; the operations are commutative, the pairing (hence the float summation order) is fixed.
+template <int STAGE>
+__device__ __forceinline__ int dpp_stage_i(int v) {
+    if constexpr (STAGE == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (STAGE == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (STAGE == 4) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    else return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);                            // row_mirror
+}
+template <int STAGE> __device__ __forceinline__ float dpp_stage_f(float v) { return __int_as_float(dpp_stage_i<STAGE>(__float_as_int(v))); }
+template <int LPR> __device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, dpp_stage_f<1>(v));
+    if constexpr (LPR > 2) v = fmaxf(v, dpp_stage_f<2>(v));
+    if constexpr (LPR > 4) v = fmaxf(v, dpp_stage_f<4>(v));
+    if constexpr (LPR > 8) v = fmaxf(v, dpp_stage_f<8>(v));
+    return v;
+}
+template <int LPR> __device__ __forceinline__ float row_sum(float v) {
+    v += dpp_stage_f<1>(v);
+    if constexpr (LPR > 2) v += dpp_stage_f<2>(v);
+    if constexpr (LPR > 4) v += dpp_stage_f<4>(v);
+    if constexpr (LPR > 8) v += dpp_stage_f<8>(v);
+    return v;
+}
+// first maximum (smallest class index on ties) over the row's lanes
+template <int STAGE> __device__ __forceinline__ void argmax_stage(float& bv, int& bi) {
+    const float pv = dpp_stage_f<STAGE>(bv);
+    const int pi = dpp_stage_i<STAGE>(bi);
+    if (pv > bv || (pv == bv && pi < bi)) { bv = pv; bi = pi; }
+}
+template <int LPR> __device__ __forceinline__ void row_argmax(float& bv, int& bi) {
+    argmax_stage<1>(bv, bi);
+    if constexpr (LPR > 2) argmax_stage<2>(bv, bi);
+    if constexpr (LPR > 4) argmax_stage<4>(bv, bi);
+    if constexpr (LPR > 8) argmax_stage<8>(bv, bi);
+}
+
 // Softmax cross-entropy on the LDS logits (train_searchable/ntu.py:53-61), LPR lanes per batch row: classes c = sub,
 // sub+LPR, ... (<= 8 classes per lane, exp kept).  Leaves dlogits = (softmax - onehot)/nvalid in place, the row's loss in
 // red[b] and its top-1 hit in red[Bp + b] (multitask: argmax of central + visual + skeleton logits).
@@ -176,8 +215,7 @@ __device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, const ChainS
         xv[j] = c < C ? row[c] : -3.0e38f;
         mx = fmaxf(mx, xv[j]);
     }
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = row_max<LPR>(mx);
     float se = 0.f;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -185,8 +223,7 @@ __device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, const ChainS
         ev[j] = c < C ? expf(xv[j] - mx) : 0.f;
         se += ev[j];
     }
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) se += __shfl_xor(se, o);
+    se = row_sum<LPR>(se);
     // argmax, first max on ties (torch.max(dim=1)); multitask: central + visual + skeleton logits
     float bv = -3.0e38f;
     int bi = 0x7FFFFFFF;
@@ -206,12 +243,7 @@ __device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, const ChainS
             if (t > bv) { bv = t; bi = c; }
         }
     }
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) {
-        const float pv = __shfl_xor(bv, o);
-        const int pi = __shfl_xor(bi, o);
-        if (pv > bv || (pv == bv && pi < bi)) { bv = pv; bi = pi; }
-    }
+    row_argmax<LPR>(bv, bi);
     const float lse = mx + logf(se);
     if (sub == 0) {
         float ls = ok ? -(row[lab] - lse) : 0.f;

@@ -594,10 +594,10 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             if (!(p->res_chain && d.kind > KIND_V)) need[d.cand]++;
         CREATE_CHK(hipMalloc(&p->d_need, sizeof(int32_t) * K));
         CREATE_CHK(hipMemcpy(p->d_need, need.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice));
-        CREATE_CHK(hipMalloc(&p->d_sync, sizeof(uint32_t) * (2 * K + 16)));
+        CREATE_CHK(hipMalloc(&p->d_sync, sizeof(uint32_t) * ((size_t)K * PERSIST_SYNC_STRIDE + 64)));
         if (getenv("MFAS_PERSIST_TRACE")) {
-            CREATE_CHK(hipMalloc(&p->d_trace, sizeof(unsigned long long) * 64));
-            CREATE_CHK(hipMemset(p->d_trace, 0, sizeof(unsigned long long) * 64));
+            CREATE_CHK(hipMalloc(&p->d_trace, sizeof(unsigned long long) * 256));
+            CREATE_CHK(hipMemset(p->d_trace, 0, sizeof(unsigned long long) * 256));
         }
         CREATE_CHK(set_lds((k_persist<1, false, 2>), p->lds_persist));
         CREATE_CHK(set_lds((k_persist<2, false, 2>), p->lds_persist));
@@ -856,7 +856,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     }
     // one persistent launch = all train steps of one epoch (persist.hip.h)
     auto persist_epoch = [&](int ep, int64_t T) -> hipError_t {
-        hipError_t e = hipMemsetAsync(p->d_sync, 0, sizeof(uint32_t) * (2 * K + 16), p->stream);
+        hipError_t e = hipMemsetAsync(p->d_sync, 0, sizeof(uint32_t) * ((size_t)K * PERSIST_SYNC_STRIDE + 64), p->stream);
         if (e != hipSuccess) return e;
         PersistArgs pa;
         memset(&pa, 0, sizeof(pa));
@@ -894,7 +894,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        return hipMemcpyAsync(&aborts[ep], p->d_sync + 2 * K, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
+        return hipMemcpyAsync(&aborts[ep], p->d_sync + (size_t)K * PERSIST_SYNC_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
     };
 
     int64_t done = 0;   // train steps completed (max_steps bookkeeping)
@@ -957,8 +957,14 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     for (uint32_t ab : aborts)
         if (ab) return fail(MFAS_EHIP, "persistent step loop: a workgroup timed out waiting for its dependency (launch aborted)");
     if (p->d_trace && p->persist) {
-        unsigned long long tr[64];
+        unsigned long long tr[256];
         if (hipMemcpy(tr, p->d_trace, sizeof(tr), hipMemcpyDeviceToHost) == hipSuccess) {
+            // step 12 of candidate 0: chain published at tr[4*8+3]; per resident unit: saw-flag / compute-done / arrived, relative to it
+            const long long pub = (long long)tr[4 * 8 + 3];
+            fprintf(stderr, "[persist trace step 12, candidate 0 units, ticks after the chain published: saw-flag done arrived]");
+            for (int u = 0; u < 64; ++u)
+                if (tr[64 + u]) fprintf(stderr, " u%d:%lld/%lld/%lld", u, (long long)tr[64 + u] - pub, (long long)tr[128 + u] - pub, (long long)tr[192 + u] - pub);
+            fprintf(stderr, "\n[chain ready for step 13 at +%lld]\n", (long long)tr[5 * 8 + 1] - pub);
             fprintf(stderr, "[persist trace, 10 ns ticks; per step: chain wait0 ready done published | sweep-unit-0 wait0 ready done arrived]\n");
             for (int t = 0; t < 8; ++t) {
                 fprintf(stderr, "  step %2d:", t + 8);

@@ -31,11 +31,16 @@ struct PersistArgs {
     int64_t N, pos0;           // N_train, epoch * N_train (position in the sample-order table)
     int32_t B, gstep0;         // batch size, epoch * batches-per-epoch (Adam / dropout step counter base)
     const float* scal;         // device [steps][2]: {lr_t/(1-beta1^t), sqrt(1-beta2^t)}
-    uint32_t* sync;            // [0,K) flag: steps whose dy is published; [K,2K) cnt: unit arrivals; [2K] abort word
+    uint32_t* sync;            // per candidate c one 256-byte record: sync[64c] = flag (steps whose dy is published), sync[64c + 32] =
+                               // unit arrivals (own 128-byte line: hundreds of pollers and the arrival atomics of different candidates
+                               // must not share a cache line / L2 channel); sync[64K] = abort word
     const int32_t* need;       // [K] sweep units of candidate c (= arrivals per step)
     unsigned long long* trace; // optional: 100 MHz timestamps of candidate 0's chain and of sweep unit 0 (steps 8..15)
 };
 
+#define PERSIST_SYNC_STRIDE 64          // uint32 words per candidate in the sync area
+#define PERSIST_FLAG(sync, c) ((sync) + (size_t)(c) * PERSIST_SYNC_STRIDE)
+#define PERSIST_CNT(sync, c) ((sync) + (size_t)(c) * PERSIST_SYNC_STRIDE + 32)
 #define PERSIST_MAX_UNITS 8             // sweep units one workgroup may own
 #define PERSIST_LDS_WORDS 32            // LDS words the loop itself uses (behind the bodies' LDS)
 #define PTRACE(slot) do { if (a.trace && tr_on) a.trace[tr_base + (slot)] = wall_clock64(); } while (0)
@@ -133,9 +138,9 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
         }
     };
     const int K = a.nchain;
-    uint32_t* flag = a.sync + d.cand;
-    uint32_t* cnt = a.sync + K + d.cand;
-    uint32_t* abortw = a.sync + 2 * K;
+    uint32_t* flag = PERSIST_FLAG(a.sync, d.cand);
+    uint32_t* cnt = PERSIST_CNT(a.sync, d.cand);
+    uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
     const void* tp = d.kind == KIND_S ? sa.tab.s[d.tap] : sa.tab.v[d.tap];
     const int64_t sbo = cd.step_off;
     const int64_t part = sbo + sa.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * MB) << 8);
@@ -214,6 +219,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
         PTRACE(0);
         if (!wg_wait_ge(flag, (uint32_t)(t + 1), abortw, ldsw)) return;    // (its barriers also publish the staging)
         PTRACE(1);
+        if (a.trace && d.cand == 0 && t == 12 && tid == 0 && unit < 64) a.trace[64 + unit] = wall_clock64();    // saw the flag
         float dyf[MB * 4];
 #pragma unroll
         for (int j = 0; j < MB * 4; ++j) dyf[j] = ldc1<true>(sa.stepbuf + dyo + (4 * j + lg) * 16 + l15);
@@ -251,6 +257,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
             }
         }
         PTRACE(2);
+        if (a.trace && d.cand == 0 && t == 12 && tid == 0 && unit < 64) a.trace[128 + unit] = wall_clock64();   // compute done
         if (fwd) {
             reduce_publish(yacc);
         } else {
@@ -258,6 +265,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
             if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PTRACE(3);
+        if (a.trace && d.cand == 0 && t == 12 && tid == 0 && unit < 64) a.trace[192 + unit] = wall_clock64();   // arrived
         cur ^= 1;
     }
     // ---- state back to memory (dev evaluation, parameter export and the next epoch's launch read it there)
@@ -282,9 +290,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
     int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
     const int bid = (int)blockIdx.x, tid = threadIdx.x;
     const int K = a.nchain;
-    uint32_t* flag = a.sync;
-    uint32_t* cnt = a.sync + K;
-    uint32_t* abortw = a.sync + 2 * K;
+    uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
 
     if (bid < K) {
         // ------------------------------------------------------------------ chain workgroup of candidate `bid`
@@ -297,7 +303,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
                     const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
                     const int tr_base = (t - 8) * 8;
                     PTRACE(0);
-                    if (!wg_wait_ge(cnt + bid, need * (uint32_t)(t + 1), abortw, ldsw)) return;
+                    if (!wg_wait_ge(PERSIST_CNT(a.sync, bid), need * (uint32_t)(t + 1), abortw, ldsw)) return;
                     PTRACE(1);
                     ChainStep cs;
                     cs.pos_t = a.pos0 + (int64_t)t * a.B;
@@ -310,7 +316,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
                     chain_lean<MB, 2>(a.ca, cs, bid, lds, &rs);
                     PTRACE(2);
                     wg_publish_barrier();
-                    if (tid == 0) __hip_atomic_store(flag + bid, (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     PTRACE(3);
                     lean_res_update<MB>(a.ca, cs, bid, lds);   // OUT / HEAD dW + Adam while the sweep units run
                 }
@@ -322,7 +328,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
             const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
             const int tr_base = (t - 8) * 8;
             PTRACE(0);
-            if (!wg_wait_ge(cnt + bid, need * (uint32_t)(t + 1), abortw, ldsw)) return;
+            if (!wg_wait_ge(PERSIST_CNT(a.sync, bid), need * (uint32_t)(t + 1), abortw, ldsw)) return;
             PTRACE(1);
             ChainStep cs;
             cs.pos_t = a.pos0 + (int64_t)t * a.B;
@@ -336,7 +342,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
             else chain_body<MB, true, true>(a.ca, cs, bid, lds);
             PTRACE(2);
             wg_publish_barrier();
-            if (tid == 0) __hip_atomic_store(flag + bid, (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             PTRACE(3);
         }
         return;
@@ -374,7 +380,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
                     const int tj = nxt[j];
                     if (tj >= a.T) continue;
                     pending = true;
-                    if (tj < 0 || ld_u32_relaxed(flag + cnd[j]) >= (uint32_t)(tj + 1)) { pick = j; break; }
+                    if (tj < 0 || ld_u32_relaxed(PERSIST_FLAG(a.sync, cnd[j])) >= (uint32_t)(tj + 1)) { pick = j; break; }
                 }
                 if (pick >= 0 || !pending) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -412,7 +418,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
         PTRACE(2);
         wg_publish_barrier();
         if (tid == 0) {
-            __hip_atomic_fetch_add(cnt + cand, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(PERSIST_CNT(a.sync, cand), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             nxt[pick] = t + 1;
         }
         PTRACE(3);
