@@ -169,6 +169,8 @@ class Searchable_Skeleton_Image_Net(nn.Module):
         skel = self.skenet(skeleton)
         taps = {k: v for k, v in visual.items() if k[0] == "v" and k[1:].isdigit()}
         taps.update({k: v for k, v in skel.items() if k[0] == "s" and k[1:].isdigit()})
+        if not taps:
+            raise ValueError("forward needs the pooled taps 'v0'.. / 's0'.. of the batch (there are no backbones in this engine)")
         some = next(iter(taps.values()))
         n = some.shape[0]
         table = FeatureTable(taps, torch.zeros(n, dtype=torch.int32, device=some.device))

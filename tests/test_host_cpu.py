@@ -131,9 +131,15 @@ def test_layer_configurations_and_module_surface():
             assert torch.equal(v, m2.state_dict()[k]), k
     with pytest.raises(ValueError):
         M.Searchable_Skeleton_Image_Net(mkargs(batchnorm=False, drpt=0.0), conf)
-    with pytest.raises(NotImplementedError):
-        m.train(True)
+    m.train(True)
+    with pytest.raises(ValueError):          # no taps, no forward
         m(({}, {}))
+    if not torch.cuda.is_available():        # train- and eval-mode forward both run on the HIP engine: CPU tensors fail loudly
+        x = {k: torch.zeros(4, w) for k, w in zip(("s0", "s1", "s2", "s3", "v0", "v1", "v2", "v3"), O.S_SIZES + O.V_SIZES)}
+        for mode in (True, False):
+            m.train(mode)
+            with pytest.raises(RuntimeError):
+                m(({k: v for k, v in x.items() if k[0] == "v"}, {k: v for k, v in x.items() if k[0] == "s"}))
 
 
 def test_weight_sharing_keys():
