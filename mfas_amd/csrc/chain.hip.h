@@ -327,10 +327,21 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     const float* vecV = Vv + cvec_off;
     if (PF && a.vec_in_lds) {
         float* vl = reinterpret_cast<float*>(lab_l + Bp) + (a.yf_in_lds ? (g.alphas ? 2 : 1) * sav_plane : 0);
-        for (int e = tid; e < nvec; e += CHAIN_THREADS) {
-            vl[e] = vecW[e];
-            vl[nvec + e] = vecM[e];
-            vl[2 * nvec + e] = vecV[e];
+        // (all loads of a batch of 4 strides are requested before the first LDS store: one memory round trip per batch, not
+        // one per stride — the entry of the R=128 chain was 6.2 us of round trips, profiles/r02_chain_phases.log)
+        for (int e0 = tid; e0 < nvec; e0 += 4 * CHAIN_THREADS) {
+            float tw[4], tm[4], tv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * CHAIN_THREADS;
+                const int ec = e < nvec ? e : 0;
+                tw[u] = vecW[ec]; tm[u] = vecM[ec]; tv[u] = vecV[ec];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * CHAIN_THREADS;
+                if (e < nvec) { vl[e] = tw[u]; vl[nvec + e] = tm[u]; vl[2 * nvec + e] = tv[u]; }
+            }
         }
         vecW = vl; vecM = vl + nvec; vecV = vl + 2 * nvec;   // visible after the phase-0 barrier below
     }
@@ -357,9 +368,24 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
         const int per_cell = nrb * MB * 64;
         const f32x4* src = reinterpret_cast<const f32x4*>(sb + g.sb_yf);
         if (yf_l != sb + g.sb_yf) {
-            for (int e = tid; e < L * per_cell; e += CHAIN_THREADS) {
-                *reinterpret_cast<f32x4*>(yf_l + (int64_t)e * 4) = src[e];
-                if (g.alphas) *reinterpret_cast<f32x4*>(yf_l + sav_plane + (int64_t)e * 4) = src[sav_plane / 4 + e];
+            const int n = L * per_cell;
+            for (int e0 = tid; e0 < n; e0 += 4 * CHAIN_THREADS) {      // 4 strides of loads in flight before the first LDS store
+                f32x4 ts[4], tvv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * CHAIN_THREADS;
+                    const int ec = e < n ? e : 0;
+                    ts[u] = src[ec];
+                    tvv[u] = g.alphas ? src[sav_plane / 4 + ec] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * CHAIN_THREADS;
+                    if (e < n) {
+                        *reinterpret_cast<f32x4*>(yf_l + (int64_t)e * 4) = ts[u];
+                        if (g.alphas) *reinterpret_cast<f32x4*>(yf_l + sav_plane + (int64_t)e * 4) = tvv[u];
+                    }
+                }
             }
         }
     } else {
