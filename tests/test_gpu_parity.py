@@ -453,12 +453,16 @@ def test_full_size_properties(dev):
     g.manual_seed(3)
     order = torch.stack([torch.randperm(10000, generator=g, device=dev) for _ in range(2)]).to(torch.int32)
 
-    def run(K, groups, seeds):
+    def run(K, groups, seeds, env=()):
         os.environ["MFAS_GROUPS"] = str(groups)
+        for k_, v_ in env:
+            os.environ[k_] = v_
         try:
             pop = Population(hp, [conf] * K, dev, drop_seeds=seeds, chunk_cols=128)   # same chunking = same summation order
         finally:
             del os.environ["MFAS_GROUPS"]
+            for k_, _ in env:
+                del os.environ[k_]
         pop.init([100 + s for s in seeds])
         stats, status = pop.train(tr, dv, 2, etas, order=order)
         pop.close()
@@ -469,6 +473,10 @@ def test_full_size_properties(dev):
     a = run(8, 2, seeds)
     b = run(8, 1, seeds)
     assert a.tobytes() == b.tobytes(), "fused vs back-to-back schedule differ"   # (1)
+    # (1b, round 2) reduce-in-sweep (the last feature workgroup of a cell sums the partial slabs) vs the chain reducing them
+    # itself, and the persistent step loop in its streaming form (one launch per epoch, per-candidate flags): same bits
+    assert run(8, 2, seeds, env=(("MFAS_NO_RED_IN_SWEEP", "1"),)).tobytes() == a.tobytes(), "reduce-in-sweep changes results"
+    assert run(8, 1, seeds, env=(("MFAS_PERSIST", "1"),)).tobytes() == a.tobytes(), "persistent (streaming) step loop differs"
     c = run(3, 1, [5, 2, 7])
     for j, s_ in enumerate([5, 2, 7]):
         assert c[j].tobytes() == a[s_].tobytes(), "population-dependent result"   # (2) + (3)
@@ -477,6 +485,46 @@ def test_full_size_properties(dev):
         assert a[k]["train_loss_sum"][1] < a[k]["train_loss_sum"][0] < 10000 * np.log(60) * 1.05
         assert a[k]["dev_corrects"][1] > 0.5 * 5600
         assert 0 <= a[k]["train_corrects"][0] <= 10000 and 0 <= a[k]["dev_corrects"][0] <= 5600
+
+
+@pytest.mark.parametrize("K,B,bn,cc,mixed", [(6, 20, False, 256, False), (9, 20, True, 128, True), (7, 16, True, 512, True), (16, 16, False, 1024, False)])
+def test_persistent_resident_schedule_bit_identical_full_size(dev, K, B, bn, cc, mixed):
+    """Search-script defaults at full size (R=16, N_train=10,000, N_dev=5,600, bf16 taps, drpt 0.5, shuffled, E=2): the
+    persistent resident schedule (k_persist: W/m/v in registers, resident lean chain, per-candidate flags — the default for
+    small populations) against the launch-per-phase schedule on the same units: statistics, parameters and both Adam moments
+    must be bit-identical; 1024-column units exercise the raw 16-bit staging."""
+    import os
+    from mfas_amd import FeatureTable, Hyper, Population
+    hp = Hyper(R=16, C=60, B=B, bn=bn, drpt=0.5, alphas=mixed, tap_bits=16)
+    rng = np.random.default_rng(5)
+    confs = [np.array(CONFS["c4"])] * K
+    if mixed:
+        confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in rng.integers(1, 5, K)]
+    tr = FeatureTable.synthetic(10000, 1, dev, torch.bfloat16, snr=0.5)
+    dv = FeatureTable.synthetic(5600, 2, dev, torch.bfloat16, snr=0.5)
+    nb = -(-10000 // B)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, 10000 / B, 2 * nb)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    order = torch.stack([torch.randperm(10000, generator=g, device=dev) for _ in range(2)]).to(torch.int32)
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["MFAS_PERSIST"] = mode
+        os.environ["MFAS_NO_TAP_MAJOR"] = "1"        # the persistent schedule runs per-segment units
+        try:
+            pop = Population(hp, confs, dev, drop_seeds=list(range(50, 50 + K)), chunk_cols=cc)
+        finally:
+            del os.environ["MFAS_PERSIST"], os.environ["MFAS_NO_TAP_MAJOR"]
+        pop.init(list(range(1, K + 1)))
+        stats, status = pop.train(tr, dv, 2, etas, order=order)
+        assert not status.any()
+        out[mode] = (stats, [[pop.get_params(k, pl).cpu().numpy() for pl in range(3)] for k in range(K)])
+        pop.close()
+    assert out["0"][0].tobytes() == out["1"][0].tobytes()
+    for k in range(K):
+        for pl in range(3):
+            assert np.array_equal(out["0"][1][k][pl], out["1"][1][k][pl]), (k, pl)
+    assert (out["1"][0]["dev_corrects"][:, 1] > 0.05 * 5600).all()      # and it trains (chance = 1.7 %)
 
 
 @pytest.mark.parametrize("B,R", [(48, 16), (33, 128)])
