@@ -128,6 +128,9 @@ struct mfas_population {
     bool red_in_sweep = false;
     bool res_wide = false;          // resident units of more than 512 columns (16-bit staging): f32 tables cannot be trained
     bool res_chain = false;         // resident lean chain: owns OUT / HEAD + vector block on chip; persistent units = feature units only
+    int res_nu = 1;                 // resident units per workgroup (2: a workgroup serves units of two candidates)
+    int nres_wg = 0;                // resident workgroups = ceil(nres / res_nu)
+    int res_buf_words = 0;          // LDS words of one staged batch of a resident unit
     int nres = 0;                   // resident feature units (one workgroup each, W/m/v in registers): the first nres persistent units
     SegDesc* d_pdescs = nullptr;    // persistent schedule's unit list: [resident feature units | streamed units]
     int n_pdescs = 0;
@@ -239,12 +242,31 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             }
         return n;
     };
+    // LDS of a resident workgroup: nu units x 2 staged batches (raw 16-bit rows when the caller promised 16-bit taps, f32 rows
+    // otherwise) + the cross-wave reduction slabs + the loop's own words
+    auto res_lds = [&](int cc, int nu) {
+        const size_t batch = hp->tap_bits == 16 ? (size_t)g.Bp * (cc + 8) * 2 : (size_t)g.Bp * (cc + 4) * 4;
+        return (size_t)nu * 2 * batch + (size_t)STEP_NW * g.MB * 256 * 4 + 4 * PERSIST_LDS_WORDS + 64;
+    };
+    auto res_fits = [&](int cc, int nu, int64_t units) {
+        return (cc <= 128 * PERSIST_NTR || (hp->tap_bits == 16 && nu == 1 && cc <= 128 * PERSIST_NTR16)) &&
+               res_lds(cc, nu) <= 160 * 1024 && K + (units + nu - 1) / nu + 1 <= p->n_cus;
+    };
     int target = chunk_cols;
+    int plan_nu = 1;
     if (plan_res && target <= 0) {
-        int pick = 0;
-        for (int cct : {128, 256, 512, 1024})   // (1024 needs 16-bit staging: only when the caller promised 16-bit taps)
-            if (!pick && (cct <= 512 || hp->tap_bits == 16) && K + count_feat_units(cct) + 1 <= p->n_cus) pick = cct;
-        if (pick) target = pick;
+        // smallest units first (fewest tiles per wave on the critical path); two units per workgroup before 1024-column units
+        // (measured: 16 candidates, 1024-column units: 34.8 us per step)
+        const int opts[6][2] = {{128, 1}, {256, 1}, {512, 1}, {256, 2}, {512, 2}, {1024, 1}};
+        int pick = -1;
+        for (int o = 0; o < 6 && pick < 0; ++o)
+            if (res_fits(opts[o][0], opts[o][1], count_feat_units(opts[o][0]))) pick = o;
+        if (pick >= 0) { target = opts[pick][0]; plan_nu = opts[pick][1]; }
+        else plan_res = false;
+    } else if (plan_res) {
+        const int64_t units = count_feat_units(target);
+        if (res_fits(target, 1, units)) plan_nu = 1;
+        else if (res_fits(target, 2, units)) plan_nu = 2;
         else plan_res = false;
     }
     if (target <= 0) {
@@ -395,12 +417,13 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         for (const SegDesc& d : p->descs)
             if (d.kind <= KIND_V) { ++nfeat; max_fcc = std::max(max_fcc, d.cc); }
         const bool wide = max_fcc > 128 * PERSIST_NTR;      // 16-bit staging only
-        const size_t lds_res = wide ? ((size_t)2 * g.Bp * (max_fcc + 8) * 2 + (size_t)STEP_NW * g.MB * 256 * 4)
-                                    : ((size_t)2 * g.Bp * (max_fcc + 4) + (size_t)STEP_NW * g.MB * 256) * 4;
-        const bool res_ok = plan_res && max_fcc <= 128 * PERSIST_NTR16 && (!wide || hp->tap_bits == 16) && K + nfeat + 1 <= p->n_cus &&
-                            lds_res + 4 * PERSIST_LDS_WORDS <= 160 * 1024;
+        const size_t lds_res = res_lds(max_fcc, plan_nu);
+        const bool res_ok = plan_res && res_fits(max_fcc, plan_nu, nfeat);
         p->res_wide = res_ok && wide;
         p->nres = res_ok ? nfeat : 0;
+        p->res_nu = plan_nu;
+        p->nres_wg = res_ok ? (nfeat + plan_nu - 1) / plan_nu : 0;
+        p->res_buf_words = (int)((hp->tap_bits == 16 ? (size_t)g.Bp * (max_fcc + 8) * 2 : (size_t)g.Bp * (max_fcc + 4) * 4) / 4);
         size_t ls = 0;
         for (const SegDesc& d : p->descs) {
             if (res_ok && d.kind <= KIND_V) continue;
@@ -474,9 +497,9 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
         {   // persistent step loop: small populations (one workgroup per CU must hold every chain + a useful number of sweep workgroups)
             const bool want = want_persist;
-            const int64_t n_stream = (int64_t)p->descs.size() - p->nres;
-            const bool fits = K <= p->n_cus / 4 && g.MB != 4 && K + p->nres < p->n_cus &&
-                              n_stream <= (int64_t)PERSIST_MAX_UNITS * (p->n_cus - K - p->nres) &&
+            const int64_t n_stream = p->res_chain ? 0 : (int64_t)p->descs.size() - p->nres;   // (a resident lean chain owns OUT / HEAD)
+            const bool fits = K <= p->n_cus / 4 && g.MB != 4 && K + p->nres_wg + (n_stream > 0 ? 1 : 0) <= p->n_cus &&
+                              n_stream <= (int64_t)PERSIST_MAX_UNITS * (p->n_cus - K - p->nres_wg) &&
                               (double)p->plane_stride * 4.0 < 3.9e9 && (double)step_off * 4.0 < 3.9e9 && (double)wt_off * 4.0 < 3.9e9;
             p->persist = want && fits && (p->res_chain || force_persist);
             if (p->persist) ngroups = 1;
@@ -729,7 +752,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     const int K = p->K, B = g.B;
     const int64_t N = train->N;
     const int64_t nb = (N + B - 1) / B;
-    if (p->persist && p->res_wide && train->dtype == MFAS_DT_F32)
+    if (p->persist && p->nres > 0 && p->hp.tap_bits == 16 && train->dtype == MFAS_DT_F32)
         return fail(MFAS_EINVAL, "this population was created for 16-bit feature tables (mfas_hyper.tap_bits = 16); f32 tables need tap_bits = 32 or 0");
     if (N - (nb - 1) * B == 1 && g.bn)   // torch BatchNorm1d raises on a size-1 train batch
         return fail(MFAS_EINVAL, "final train batch of size 1 with batchnorm (reference raises ValueError)");
@@ -864,14 +887,15 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         pa.sa.desc = p->d_pdescs; pa.sa.tdesc = nullptr; pa.sa.ntap = 0;
         pa.ca.cands = p->d_cands;
         pa.nchain = K; pa.nitems = p->n_pdescs; pa.nres = p->nres; pa.res_chain = p->res_chain ? 1 : 0; pa.res_wide = p->res_wide ? 1 : 0;
+        pa.res_nu = p->res_nu; pa.nres_wg = p->nres_wg; pa.res_buf_words = p->res_buf_words;
         pa.T = (int)T; pa.epoch = ep;
         pa.N = N; pa.pos0 = (int64_t)ep * N;
         pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);
         pa.scal = p->d_scal; pa.sync = p->d_sync; pa.need = p->d_need; pa.trace = p->d_trace;
         const int n_stream = pa.nitems - pa.nres;
-        const unsigned grid = (unsigned)(K + pa.nres + (n_stream > 0 ? std::max(1, std::min(n_stream, p->n_cus - K - pa.nres)) : 0));
+        const unsigned grid = (unsigned)(K + pa.nres_wg + (n_stream > 0 ? std::max(1, std::min(n_stream, p->n_cus - K - pa.nres_wg)) : 0));
         const int ldsw = (int)(p->lds_persist / 4) - PERSIST_LDS_WORDS;
-        if ((n_stream > 0 && n_stream > PERSIST_MAX_UNITS * (int)(grid - K - pa.nres)) || (int)grid > p->n_cus) return hipErrorInvalidConfiguration;
+        if ((n_stream > 0 && n_stream > PERSIST_MAX_UNITS * (int)(grid - K - pa.nres_wg)) || (int)grid > p->n_cus) return hipErrorInvalidConfiguration;
         const bool prof = p->profiling;
         if (prof) {
             if (p->ev.size() < ev_used + 2) {

@@ -24,7 +24,9 @@ struct PersistArgs {
     SweepArgs sa;              // desc = the population's sweep units (per-segment), cands = all candidates
     ChainArgs ca;              // cands = all candidates
     int32_t nchain, nitems;    // K, number of sweep units
-    int32_t res_wide, _pad1;   // resident units wider than 512 columns exist (16-bit staging, 8 tiles per wave)
+    int32_t res_wide, res_nu;  // resident units wider than 512 columns exist (16-bit staging, 8 tiles per wave); units per workgroup (1 / 2)
+    int32_t nres_wg, res_buf_words;   // resident workgroups (blocks K .. K + nres_wg: unit u of workgroup w = w + u * nres_wg);
+                                      // LDS words of one staged batch
     int32_t nres, res_chain;   // units [0, nres) are RESIDENT feature units: one workgroup each (blocks K .. K + nres);
                                // res_chain: the (lean) chain owns OUT / HEAD and keeps them + its vector block on chip
     int32_t T, epoch;          // train steps of this launch, epoch index (statistics slot)
@@ -79,19 +81,21 @@ __device__ __forceinline__ void wg_publish_barrier() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// sweep_resident — ONE feature unit (a column chunk of one S / V segment, R <= 16: one row block) owned by ONE workgroup
-// for the whole launch, with its W / m / v tiles held IN REGISTERS across the epoch's steps: the 128 MB register file of
-// the chip is the parameter store of a small population (the search trains 6-16 candidates of ~125 K parameters per GPU:
-// 1.5 MB of state each).  Per step the unit reads dy (2 KB, from the chain) and the batch's table rows and writes its 2 KB
+// sweep_resident — feature units (a column chunk of one S / V segment, R <= 16: one row block) owned by ONE workgroup for
+// the whole launch, with their W / m / v tiles held IN REGISTERS across the epoch's steps: the 128 MB register file of the
+// chip is the parameter store of a small population (the search trains 6-16 candidates of ~125 K parameters per GPU:
+// 1.5 MB of state each).  Per step a unit reads dy (2 KB, from the chain) and the batch's table rows and writes its 2 KB
 // forward partial — no W/m/v traffic at all; the state is loaded at launch start and stored back at its end (the dev
-// evaluation and the next epoch's launch read it from memory).  The rows of batch t+1 are staged into LDS BEFORE the
-// workgroup waits for the chain of step t (the sample order is known), and batch t's rows are still there from the previous
-// step, so no table access sits on the critical path: wait -> dy -> dW (MFMA) -> Adam -> forward (MFMA) -> partial.
+// evaluation and the next epoch's launch read it from memory).  The rows of batch t+2 are staged into LDS right after a
+// unit finishes step t (the sample order is known), so no table access sits on the critical path:
+// wait -> dy -> dW (MFMA) -> Adam -> forward (MFMA) -> partial.
+// NU = 2: a workgroup owns TWO units (of different candidates) and serves whichever candidate has published its step —
+// twice the candidates fit one GPU at the price of an occasional wait behind the co-tenant.
 // Tile -> wave mapping, MFMA order, Adam arithmetic and the cross-wave reduction are those of sweep_body's k-split path:
 // bit-identical to the launch-per-phase schedule run on the same units.
-// ------------------------------------------------------------------------------------------------
 // X16: bf16 / f16 tables are staged RAW (16-bit) and converted when read as MFMA operands (exact: the same f32 values as the
-// f32 staging) — half the LDS, so a unit may span 1024 columns and ~28 candidates of the search's size fit one GPU.
+// f32 staging) — half the LDS, so a unit may span 1024 columns.
+// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float cvt16(uint32_t u, int dtype) {
     return dtype == MFAS_DT_BF16 ? __uint_as_float(u << 16) : __half2float(__ushort_as_half((unsigned short)u));
 }
@@ -110,26 +114,71 @@ __device__ __forceinline__ void stage_table16(uint16_t* dst, int S16, const void
     }
 }
 
-template <int MB, int NTR, bool X16>
-__device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int unit, float* lds, int* ldsw) {
+struct ResUnit {              // wave-uniform constants of one resident unit
+    int32_t valid, index, cand, cell, kind, cc, nkb, S, width, k0;
+    const void* tp;
+    int64_t part, dyo, gsco;  // step-buffer indices: partial slot, dy_i, alpha scale
+    float *Wp, *Mp, *Vp;
+    uint32_t *flag, *cnt;
+    float* xb[2];             // the two staged batches in LDS
+};
+
+template <int MB, int NTR, bool X16, int NU>
+__device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int wg, const int nwg, float* lds, int* ldsw) {
     const SweepArgs& sa = a.sa;
-    const SegDesc d = sa.desc[unit];
-    const CandDev& cd = sa.cands[d.cand];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     constexpr int Bp = MB * 16;
-    const int cc = d.cc, nkb = cc >> 4;
-    const int S = X16 ? cc + 8 : cc + 4;          // row stride (elements) of both staged batches (16 B aligned rows)
-    const int bufw = X16 ? (Bp * S) / 2 : Bp * S; // LDS words per staged batch
-    float* xbuf[2] = {lds, lds + bufw};
-    float* wred = lds + 2 * bufw;                 // [8 waves][MB][256] cross-wave reduction of the forward partial
     const int dt = sa.tab.dtype;
+    const int K = a.nchain;
+    uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
+    float* wred = lds + (size_t)NU * 2 * a.res_buf_words;      // [8 waves][MB][256] cross-wave reduction of the forward partial
+    int* nxt = ldsw + 8;                                          // next step of my u-th unit
+
+    ResUnit U[NU];
+    f32x4 w4[NU][NTR], m4[NU][NTR], v4[NU][NTR];
+    int cur[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int ui = wg + u * nwg;
+        U[u].valid = ui < a.nres;
+        U[u].index = ui;
+        const SegDesc d = sa.desc[U[u].valid ? ui : wg];
+        const CandDev& cd = sa.cands[d.cand];
+        U[u].cand = d.cand; U[u].cell = d.cell; U[u].kind = d.kind; U[u].cc = d.cc; U[u].nkb = d.cc >> 4;
+        U[u].S = X16 ? d.cc + 8 : d.cc + 4;       // row stride (elements) of a staged batch: 16 B aligned rows
+        U[u].width = d.width; U[u].k0 = d.k0;
+        U[u].tp = d.kind == KIND_S ? sa.tab.s[d.tap] : sa.tab.v[d.tap];
+        const int64_t sbo = cd.step_off;
+        U[u].part = sbo + sa.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * MB) << 8);
+        U[u].dyo = sbo + sa.g.sb_dy + (int64_t)d.cell * Bp * sa.g.Rp;      // dy_i [Bp][Rp = 16]
+        U[u].gsco = sbo + sa.g.sb_gsc + d.cell * 2 + d.kind;
+        U[u].Wp = sa.plane + d.w_off;
+        U[u].Mp = U[u].Wp + sa.plane_stride;
+        U[u].Vp = U[u].Mp + sa.plane_stride;
+        U[u].flag = PERSIST_FLAG(a.sync, d.cand);
+        U[u].cnt = PERSIST_CNT(a.sync, d.cand);
+        U[u].xb[0] = lds + (size_t)(2 * u) * a.res_buf_words;
+        U[u].xb[1] = lds + (size_t)(2 * u + 1) * a.res_buf_words;
+        cur[u] = 0;
+        // the unit's state: wave w owns k-blocks w, w + 8, ... (as sweep_body's k-split)
+#pragma unroll
+        for (int s = 0; s < NTR; ++s) {
+            const int kb = wave + STEP_NW * s;
+            const int64_t off = (int64_t)(kb < U[u].nkb ? kb : 0) * 256 + lane * 4;
+            w4[u][s] = *reinterpret_cast<const f32x4*>(U[u].Wp + off);
+            m4[u][s] = *reinterpret_cast<const f32x4*>(U[u].Mp + off);
+            v4[u][s] = *reinterpret_cast<const f32x4*>(U[u].Vp + off);
+        }
+    }
+    AdamC ac = sa.ac;
+
     // MFMA operand reads from a staged batch: one element (dW: A[i = column][k = batch row]) / four consecutive columns
-    auto x1 = [&](const float* xb, int row, int col) -> float {
+    auto x1 = [&](const float* xb, int S, int row, int col) -> float {
         if constexpr (X16) return cvt16(reinterpret_cast<const uint16_t*>(xb)[row * S + col], dt);
         else return xb[row * S + col];
     };
-    auto x4of = [&](const float* xb, int row, int col) -> f32x4 {
+    auto x4of = [&](const float* xb, int S, int row, int col) -> f32x4 {
         if constexpr (X16) {
             const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(xb) + row * S + col);
             return (f32x4){cvt16(r.x & 0xFFFFu, dt), cvt16(r.x >> 16, dt), cvt16(r.y & 0xFFFFu, dt), cvt16(r.y >> 16, dt)};
@@ -137,146 +186,177 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int u
             return *reinterpret_cast<const f32x4*>(xb + row * S + col);
         }
     };
-    const int K = a.nchain;
-    uint32_t* flag = PERSIST_FLAG(a.sync, d.cand);
-    uint32_t* cnt = PERSIST_CNT(a.sync, d.cand);
-    uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
-    const void* tp = d.kind == KIND_S ? sa.tab.s[d.tap] : sa.tab.v[d.tap];
-    const int64_t sbo = cd.step_off;
-    const int64_t part = sbo + sa.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * MB) << 8);
-    const int64_t dyo = sbo + sa.g.sb_dy + (int64_t)d.cell * Bp * sa.g.Rp;      // dy_i [Bp][Rp = 16]
-    float* Wp = sa.plane + d.w_off;
-    float* Mp = Wp + sa.plane_stride;
-    float* Vp = Mp + sa.plane_stride;
-
-    // ---- the unit's state: wave w owns k-blocks w, w + 8, ... (as sweep_body's k-split)
-    f32x4 w4[NTR], m4[NTR], v4[NTR];
-#pragma unroll
-    for (int s = 0; s < NTR; ++s) {
-        const int kb = wave + STEP_NW * s;
-        const int64_t off = (int64_t)(kb < nkb ? kb : 0) * 256 + lane * 4;
-        w4[s] = *reinterpret_cast<const f32x4*>(Wp + off);
-        m4[s] = *reinterpret_cast<const f32x4*>(Mp + off);
-        v4[s] = *reinterpret_cast<const f32x4*>(Vp + off);
-    }
-    AdamC ac = sa.ac;
-
-    auto stage = [&](float* dst, int t) {     // rows of batch t -> LDS (f32)
+    auto stage = [&](const ResUnit& un, float* dst, int t) {     // rows of batch t -> LDS
         const int nv = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
         if constexpr (X16)
-            stage_table16(reinterpret_cast<uint16_t*>(dst), S, tp, d.width, d.k0, cc, sa.order, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
+            stage_table16(reinterpret_cast<uint16_t*>(dst), un.S, un.tp, un.width, un.k0, un.cc, sa.order, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
         else
-            stage_table(dst, S, tp, sa.tab.dtype, d.width, d.k0, cc, sa.order, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
+            stage_table(dst, un.S, un.tp, sa.tab.dtype, un.width, un.k0, un.cc, sa.order, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
     };
-    // forward partial of the staged batch `xn` with the current weights -> partial slot (write-through) -> arrive
-    auto reduce_publish = [&](const f32x4 (&yacc)[MB]) {
+    // cross-wave reduction of a forward partial (fixed order 0..7, as sweep_body) -> partial slot (write-through) -> arrive
+    auto reduce_publish = [&](const ResUnit& un, const f32x4 (&yacc)[MB]) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
             *reinterpret_cast<f32x4*>(wred + ((wave * MB + mb) << 8) + lane * 4) = yacc[mb];
         __syncthreads();
-        for (int e = tid; e < MB * 64; e += STEP_THREADS) {    // fixed order 0..7, as sweep_body
+        for (int e = tid; e < MB * 64; e += STEP_THREADS) {
             const int slot = e >> 6, ln = e & 63;
             f32x4 sum = *reinterpret_cast<const f32x4*>(wred + (slot << 8) + ln * 4);
 #pragma unroll
             for (int w = 1; w < STEP_NW; ++w)
                 sum += *reinterpret_cast<const f32x4*>(wred + ((w * MB + slot) << 8) + ln * 4);
-            stc4<true>(sa.stepbuf, part + (slot << 8) + ln * 4, sum);
+            stc4<true>(sa.stepbuf, un.part + (slot << 8) + ln * 4, sum);
         }
         wg_publish_barrier();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
-    // ---- prologue: forward partial sums of batch 0 (no update)
-    int cur = 0;
-    stage(xbuf[cur], 0);
-    __syncthreads();
-    {
-        f32x4 yacc[MB];
+    // ---- prologue per unit: forward partial sums of batch 0 (no update), then batch 1 staged
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NU; ++u) {
+        if (U[u].valid) {            // (wave-uniform, workgroup-uniform)
+            stage(U[u], U[u].xb[0], 0);
+            __syncthreads();
+            f32x4 yacc[MB];
 #pragma unroll
-        for (int s = 0; s < NTR; ++s) {
-            const int kb = wave + STEP_NW * s;
-            if (kb < nkb) {
+            for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const f32x4 x4 = x4of(xbuf[cur], mb * 16 + l15, kb * 16 + 4 * lg);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[s][q], yacc[mb]);
-                }
-            }
-        }
-        reduce_publish(yacc);
-    }
-    // ---- the epoch's train steps
-    for (int t = 0; t < a.T; ++t) {
-        const bool fwd = t + 1 < a.T;
-        float* xt = xbuf[cur];
-        float* xn = xbuf[cur ^ 1];
-        if (fwd) stage(xn, t + 1);               // batch t+1 lands while the chain of step t is still running
-        const bool tr_on = unit == 0 && tid == 0 && t >= 8 && t < 16;
-        const int tr_base = (t - 8) * 8 + 4;
-        PTRACE(0);
-        if (!wg_wait_ge(flag, (uint32_t)(t + 1), abortw, ldsw)) return;    // (its barriers also publish the staging)
-        PTRACE(1);
-        if (a.trace && d.cand == 0 && t == 12 && tid == 0 && unit < 64) a.trace[64 + unit] = wall_clock64();    // saw the flag
-        float dyf[MB * 4];
-#pragma unroll
-        for (int j = 0; j < MB * 4; ++j) dyf[j] = ldc1<true>(sa.stepbuf + dyo + (4 * j + lg) * 16 + l15);
-        float gsc = 1.0f;
-        if (sa.g.alphas) gsc = ldc1<true>(sa.stepbuf + sbo + sa.g.sb_gsc + d.cell * 2 + d.kind);
-        ac.ss = a.scal[2 * (int64_t)(a.gstep0 + t)];
-        ac.bc2s = a.scal[2 * (int64_t)(a.gstep0 + t) + 1];
-        f32x4 yacc[MB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NTR; ++s) {
-            const int kb = wave + STEP_NW * s;
-            if (kb < nkb) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < MB * 4; ++j)
-                    acc = MFMA16(x1(xt, 4 * j + lg, kb * 16 + l15), dyf[j], acc);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float w = w4[s][q], m = m4[s][q], v = v4[s][q];
-                    adam1(w, m, v, acc[q] * gsc, ac);
-                    w4[s][q] = w;
-                    m4[s][q] = m;
-                    v4[s][q] = v;
-                }
-                if (fwd) {
+            for (int s = 0; s < NTR; ++s) {
+                const int kb = wave + STEP_NW * s;
+                if (kb < U[u].nkb) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
-                        const f32x4 x4 = x4of(xn, mb * 16 + l15, kb * 16 + 4 * lg);
+                        const f32x4 x4 = x4of(U[u].xb[0], U[u].S, mb * 16 + l15, kb * 16 + 4 * lg);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[s][q], yacc[mb]);
+                        for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][s][q], yacc[mb]);
                     }
                 }
             }
+            reduce_publish(U[u], yacc);
+            if (1 < a.T) stage(U[u], U[u].xb[1], 1);
         }
-        PTRACE(2);
-        if (a.trace && d.cand == 0 && t == 12 && tid == 0 && unit < 64) a.trace[128 + unit] = wall_clock64();   // compute done
-        if (fwd) {
-            reduce_publish(yacc);
-        } else {
-            wg_publish_barrier();
-            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) nxt[u] = U[u].valid ? 0 : a.T;
+    }
+    __syncthreads();
+
+    // ---- the epoch's train steps: serve whichever of my units' candidates has published the step the unit waits for
+    int last = NU - 1;
+    for (;;) {
+        if (tid == 0) {
+            int pick = -2;   // -2: every unit has finished its last step
+            uint32_t spins = 0;
+            for (;;) {
+                bool pending = false;
+#pragma unroll
+                for (int q = 1; q <= NU; ++q) {
+                    const int j = (last + q) % NU;
+                    const int tj = nxt[j];
+                    if (tj < a.T && pick < 0) {
+                        pending = true;
+                        uint32_t* fl = U[0].flag;
+#pragma unroll
+                        for (int u = 1; u < NU; ++u) if (j == u) fl = U[u].flag;
+                        if (ld_u32_relaxed(fl) >= (uint32_t)(tj + 1)) pick = j;
+                    }
+                }
+                if (pick >= 0 || !pending) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 0x3FFu) == 0 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
+                    __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pick = -3;
+                    break;
+                }
+            }
+            ldsw[0] = pick;
         }
-        PTRACE(3);
-        if (a.trace && d.cand == 0 && t == 12 && tid == 0 && unit < 64) a.trace[192 + unit] = wall_clock64();   // arrived
-        cur ^= 1;
+        __syncthreads();
+        const int pick = ldsw[0];
+        if (pick == -3) return;
+        if (pick < 0) break;
+        const int t = nxt[pick];
+        __syncthreads();   // everyone has read the pick / step before lane 0 can overwrite them
+        last = pick;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (pick == u) {
+                const ResUnit& un = U[u];
+                const bool fwd = t + 1 < a.T;
+                const float* xt = un.xb[cur[u]];
+                const float* xn = un.xb[cur[u] ^ 1];
+                const bool tr_on = un.index == 0 && tid == 0 && t >= 8 && t < 16;
+                const int tr_base = (t - 8) * 8 + 4;
+                PTRACE(1);
+                if (a.trace && un.cand == 0 && t == 12 && tid == 0 && un.index < 64) a.trace[64 + un.index] = wall_clock64();    // saw the flag
+                float dyf[MB * 4];
+#pragma unroll
+                for (int j = 0; j < MB * 4; ++j) dyf[j] = ldc1<true>(sa.stepbuf + un.dyo + (4 * j + lg) * 16 + l15);
+                float gsc = 1.0f;
+                if (sa.g.alphas) gsc = ldc1<true>(sa.stepbuf + un.gsco);
+                ac.ss = a.scal[2 * (int64_t)(a.gstep0 + t)];
+                ac.bc2s = a.scal[2 * (int64_t)(a.gstep0 + t) + 1];
+                f32x4 yacc[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < NTR; ++s) {
+                    const int kb = wave + STEP_NW * s;
+                    if (kb < un.nkb) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int j = 0; j < MB * 4; ++j)
+                            acc = MFMA16(x1(xt, un.S, 4 * j + lg, kb * 16 + l15), dyf[j], acc);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float w = w4[u][s][q], m = m4[u][s][q], v = v4[u][s][q];
+                            adam1(w, m, v, acc[q] * gsc, ac);
+                            w4[u][s][q] = w;
+                            m4[u][s][q] = m;
+                            v4[u][s][q] = v;
+                        }
+                        if (fwd) {
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) {
+                                const f32x4 x4 = x4of(xn, un.S, mb * 16 + l15, kb * 16 + 4 * lg);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][s][q], yacc[mb]);
+                            }
+                        }
+                    }
+                }
+                PTRACE(2);
+                if (a.trace && un.cand == 0 && t == 12 && tid == 0 && un.index < 64) a.trace[128 + un.index] = wall_clock64();   // compute done
+                if (fwd) {
+                    reduce_publish(un, yacc);
+                } else {
+                    wg_publish_barrier();
+                    if (tid == 0) __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                PTRACE(3);
+                if (a.trace && un.cand == 0 && t == 12 && tid == 0 && un.index < 64) a.trace[192 + un.index] = wall_clock64();   // arrived
+                if (tid == 0) nxt[u] = t + 1;
+                cur[u] ^= 1;
+                // batch t+2 into the buffer batch t just vacated: it lands while this unit's chain runs step t+1
+                if (t + 2 < a.T) stage(un, un.xb[cur[u] ^ 1], t + 2);
+            }
+        }
     }
     // ---- state back to memory (dev evaluation, parameter export and the next epoch's launch read it there)
 #pragma unroll
-    for (int s = 0; s < NTR; ++s) {
-        const int kb = wave + STEP_NW * s;
-        if (kb < nkb) {
-            const int64_t off = (int64_t)kb * 256 + lane * 4;
-            *reinterpret_cast<f32x4*>(Wp + off) = w4[s];
-            *reinterpret_cast<f32x4*>(Mp + off) = m4[s];
-            *reinterpret_cast<f32x4*>(Vp + off) = v4[s];
+    for (int u = 0; u < NU; ++u) {
+        if (U[u].valid) {
+#pragma unroll
+            for (int s = 0; s < NTR; ++s) {
+                const int kb = wave + STEP_NW * s;
+                if (kb < U[u].nkb) {
+                    const int64_t off = (int64_t)kb * 256 + lane * 4;
+                    *reinterpret_cast<f32x4*>(U[u].Wp + off) = w4[u][s];
+                    *reinterpret_cast<f32x4*>(U[u].Mp + off) = m4[u][s];
+                    *reinterpret_cast<f32x4*>(U[u].Vp + off) = v4[u][s];
+                }
+            }
         }
     }
 }
@@ -352,13 +432,20 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
     // ever re-read by the same CU, so they stay coherent without any fence.  A workgroup that owns several units serves
     // whichever of them is ready (its candidate's chain has published the step the unit is waiting for): units of different
     // candidates never block each other (in-order service convoys all candidates behind the slowest chain).
-    if (bid < K + a.nres) {
-        if (a.sa.tab.dtype == MFAS_DT_F32) sweep_resident<MB, PERSIST_NTR, false>(a, bid - K, lds, ldsw);
-        else if (a.res_wide) sweep_resident<MB, PERSIST_NTR16, true>(a, bid - K, lds, ldsw);
-        else sweep_resident<MB, PERSIST_NTR, true>(a, bid - K, lds, ldsw);
+    if (bid < K + a.nres_wg) {
+        const int rw = bid - K;
+        if (a.sa.tab.dtype == MFAS_DT_F32) {
+            if (a.res_nu == 2) sweep_resident<MB, PERSIST_NTR, false, 2>(a, rw, a.nres_wg, lds, ldsw);
+            else sweep_resident<MB, PERSIST_NTR, false, 1>(a, rw, a.nres_wg, lds, ldsw);
+        } else if (a.res_wide) {
+            sweep_resident<MB, PERSIST_NTR16, true, 1>(a, rw, a.nres_wg, lds, ldsw);
+        } else {
+            if (a.res_nu == 2) sweep_resident<MB, PERSIST_NTR, true, 2>(a, rw, a.nres_wg, lds, ldsw);
+            else sweep_resident<MB, PERSIST_NTR, true, 1>(a, rw, a.nres_wg, lds, ldsw);
+        }
         return;
     }
-    const int G = (int)gridDim.x - K - a.nres, wg = bid - K - a.nres;
+    const int G = (int)gridDim.x - K - a.nres_wg, wg = bid - K - a.nres_wg;
     const int n_gen = a.nitems - a.nres;      // units served by the generic (streaming) workgroups: [nres, nitems)
     const int n_my = wg < n_gen ? (n_gen - wg + G - 1) / G : 0;   // <= PERSIST_MAX_UNITS (host)
     int* nxt = ldsw + 8;                     // next step of my j-th unit (-1 = the epoch's prologue: forward of batch 0, no update)
