@@ -1159,16 +1159,8 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             const bool from_head = (i == L - 1);
             float gr = 0.f;
             if (g.bn) gr = vecW[vbl + VEC_G * Rp + r] * rstd_l[i * Rp + r];
-            const int64_t ob = vb + VEC_B * Rp + r, og = vb + VEC_G * Rp + r, obe = vb + VEC_BE * Rp + r;
-            float pw[3] = {0.f, 0.f, 0.f}, pm[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f};
-            if (lg == 0 && colok) {
-                const int lb = vbl + VEC_B * Rp + r, lgm = vbl + VEC_G * Rp + r, lbe = vbl + VEC_BE * Rp + r;
-                pw[0] = vecW[lb]; pm[0] = vecM[lb]; pv[0] = vecV[lb];
-                if (g.bn) {
-                    pw[1] = vecW[lgm]; pm[1] = vecM[lgm]; pv[1] = vecV[lgm];
-                    pw[2] = vecW[lbe]; pm[2] = vecM[lbe]; pv[2] = vecV[lbe];
-                }
-            }
+            float* gv = yf_l;   // (the reduced feature sums are dead once the forward is done) gradients of the vector parameters:
+                                // [cell][b | gamma | beta][16] + [192 + cell] alpha; their Adam runs after the backward, on all waves
             f32x4 a4[MB], xh4[MB], df4[MB], acc[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -1251,31 +1243,38 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                     dcur[b * SX + r] = dy;
                 }
             const float db = colsum(sdy);
-            if (lg == 0 && colok) {   // Adam on the column's vector parameters (one owner lane per column)
-                adam1(pw[0], pm[0], pv[0], db, ac);
-                put_vec(ob, pw[0], pm[0], pv[0]);
-                if (g.bn) {
-                    adam1(pw[1], pm[1], pv[1], dgam, ac);
-                    put_vec(og, pw[1], pm[1], pv[1]);
-                    adam1(pw[2], pm[2], pv[2], dbet, ac);
-                    put_vec(obe, pw[2], pm[2], pv[2]);
-                }
+            if (lg == 0) {   // one owner lane per column hands the column's gradients to the deferred Adam below
+                gv[(i * 3 + 0) * 16 + r] = db;
+                gv[(i * 3 + 1) * 16 + r] = dgam;
+                gv[(i * 3 + 2) * 16 + r] = dbet;
             }
             if (g.alphas) {   // d(alpha_i) = sigma'(alpha) * sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]
                 for (int o = 32; o > 0; o >>= 1) dalpha += __shfl_xor(dalpha, o);
-                if (lane == 0) {
-                    const float tot = dalpha;
-                    const int64_t o = vb + 5 * Rp;
-                    float w = vecW[vbl + 5 * Rp], m = vecM[vbl + 5 * Rp], v = vecV[vbl + 5 * Rp];
-                    const float sg = 1.0f / (1.0f + expf(-w));
-                    adam1(w, m, v, tot * sg * (1.0f - sg), ac);
-                    put_vec(o, w, m, v);
-                }
+                if (lane == 0) gv[192 + i] = dalpha;
             }
         }
     }
     lds_barrier();
     CT_STAMP(12);
+    {   // Adam on the vector parameters (bias, BN gamma / beta, alpha) of every cell: same arithmetic as before, but on 192 threads
+        // at once after the backward instead of inside wave 0's serial cell loop (~50 instructions per cell off the critical path)
+        const float* gv = yf_l;
+        if (tid < L * 48) {
+            const int i = tid / 48, which = (tid - i * 48) >> 4, rr = tid & 15;
+            if (rr < R && (which == 0 || g.bn)) {
+                const int e = i * g.vec_cell_stride + (which == 0 ? VEC_B : (which == 1 ? VEC_G : VEC_BE)) * Rp + rr;
+                float w = vecW[e], m = vecM[e], v = vecV[e];
+                adam1(w, m, v, gv[(i * 3 + which) * 16 + rr], ac);
+                put_vec(cvec_off + e, w, m, v);
+            }
+        } else if (g.alphas && tid >= 256 && tid < 256 + L) {
+            const int i = tid - 256, e = i * g.vec_cell_stride + 5 * Rp;
+            float w = vecW[e], m = vecM[e], v = vecV[e];
+            const float sg = 1.0f / (1.0f + expf(-w));
+            adam1(w, m, v, gv[192 + i] * sg * (1.0f - sg), ac);
+            put_vec(cvec_off + e, w, m, v);
+        }
+    }
     {   // dy_i -> step buffer (dy operand of the sweep), coalesced
         if constexpr (RES) {   // 16 B write-through stores: [L][Bp][16] = one f32x4 per thread and cell pair
             for (int e4 = tid; e4 < L * Bp * 4; e4 += CHAIN_THREADS)
