@@ -773,12 +773,13 @@ struct LeanRes {
     int bad;            // non-finite loss seen
 };
 #define LEAN_OWN_TILES 7   // slots 0..2: OUT_1..OUT_3, slots 3..6: head class blocks 0..3
+#define LEAN_SCR 1024      // floats: BN exchange [2][8][16] | bias-gradient partials [L][8][16] | alpha partials [L][8] | dgamma / dbeta [L][2][16]
 
 // LDS layout shared by chain_lean and the resident helpers
 template <int MB>
 struct LeanLds {
     static constexpr int Bp = MB * 16, Rp = 16, SX = Rp + 4, sav_plane = MFAS_MAX_CELLS * MB * 256;
-    float *xo_l, *dy_l, *lg_l, *rstd_l, *red_l, *yf_l, *vec_l, *sav_a, *sav_x, *sav_d, *own;
+    float *xo_l, *dy_l, *lg_l, *rstd_l, *red_l, *yf_l, *vec_l, *scr, *own;
     int* lab_l;
     int nvec, SC;
     __device__ __forceinline__ LeanLds(float* lds, const Geo& g) {
@@ -792,10 +793,9 @@ struct LeanLds {
         lab_l = reinterpret_cast<int*>(red_l + 2 * Bp + 16); // [Bp]
         yf_l = reinterpret_cast<float*>(lab_l + Bp);         // [1 or 2][L][MB][256] reduced feature sums
         vec_l = yf_l + (g.alphas ? 2 : 1) * sav_plane;       // [3][nvec] vector block + Adam state
-        sav_a = vec_l + 3 * nvec;                            // [L][MB][256] activations
-        sav_x = sav_a + sav_plane;                           // xhat (batchnorm only)
-        sav_d = sav_a + (g.bn ? 2 : 1) * sav_plane;          // yS - yV (alphas only)
-        own = sav_a + (((1 + (g.bn ? 1 : 0) + (g.alphas ? 1 : 0)) * sav_plane + 3) & ~3);   // resident: [W|M|V|T][7 tiles][256]
+        // (activations / x-hat / alpha differences needed by the backward live in the owning lanes' registers)
+        scr = vec_l + ((3 * nvec + 3) & ~3);                 // cross-wave exchange scratch (LEAN_SCR floats)
+        own = scr + LEAN_SCR;                                                                 // resident: [W|M|V|T][7 tiles][256]
     }
     static __host__ __device__ constexpr int own_floats() { return 4 * LEAN_OWN_TILES * 256; }
 };
@@ -829,9 +829,6 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     int* lab_l = ll.lab_l;
     float* yf_l = ll.yf_l;
     float* vec_l = ll.vec_l;
-    float* sav_a = ll.sav_a;
-    float* sav_x = ll.sav_x;
-    float* sav_d = ll.sav_d;
     // vector-parameter updates: memory (MODE 0 / 1) or the resident LDS copy (MODE 2; flushed at the end of the launch)
     auto put_vec = [&](int64_t o, float w, float m, float v) {
         if constexpr (RES) { const int e = (int)(o - cd.vec_off); vec_l[e] = w; vec_l[nvec + e] = m; vec_l[2 * nvec + e] = v; }
@@ -904,20 +901,8 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             tHT[u] = ldc4<COH>(a.wt, cd.headT_off + ((int64_t)(u < ncb ? u : 0) << 8) + lane * 4);
         tH = ldc4<COH>(W, cd.head_off + ((int64_t)(wave < ncb ? wave : 0) << 8) + lane * 4);
     }
-    // dropout keep bits of this lane's elements (wave 0 owns the row block): bit (i*MB + mb)*4 + q — computed while the
-    // loads above are in flight, used by the forward AND the backward pass
     const int r = l15;
     const bool colok = r < R;
-    uint32_t keep = 0xFFFFFFFFu;
-    if (wave == 0 && g.use_drop) {
-#pragma unroll
-        for (int i = 0; i < MFAS_MAX_CELLS; ++i)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (!drop_keep(h0, i, (uint32_t)((mb * 16 + 4 * lg + q) * R + r), g.drop_thr)) keep &= ~(1u << ((i * MB + mb) * 4 + q));
-    }
     // phase 0: reduce the sweep's column-chunk partial sums (fixed order) into LDS; stage the vector block
     if (has_item) {
         f32x4 accS = z4, accV = z4;
@@ -959,9 +944,31 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     lds_barrier();
     CT_STAMP(0);
 
-    // ------------------------------------------------------------------ forward: wave 0, all cells, no barrier
-    if (wave == 0) {
-        for (int i = 0; i < L; ++i) {
+    // ------------------------------------------------------------------ forward: ELEMENT-PARALLEL over the waves.
+    // A 16-wide cell is ~150 dependent VALU / transcendental instructions per lane when one wave owns all Bp x 16 outputs (8 per
+    // lane at B = 20); here wave w < 4*MB owns ONE element row group — batch rows mb*16 + 4*lg + q with (mb, q) = (w >> 2, w & 3)
+    // — every wave recomputes the cell's tiny product (4 MFMAs) from the shared out_{i-1} in LDS and finishes one element per
+    // lane, then one workgroup barrier hands out_i to the next cell.  BatchNorm's batch statistics and the backward's column
+    // sums are exchanged through LDS (fixed order over the waves).  What each lane needs again in the backward (activation,
+    // x-hat, alpha difference) stays in its registers.
+    const int ew = wave, emb = ew >> 2, eq = ew & 3;
+    const bool eact = ew < MB * 4;
+    const int eb = emb * 16 + 4 * lg + eq;                  // this lane's batch row
+    float* bnw = ll.scr;                                     // [2][8][16] cross-wave column sums
+    float* gv2 = ll.scr + 256;                               // [cell][dgamma | dbeta][16]
+    auto sel4 = [&](const f32x4& v4) -> float { return eq == 0 ? v4[0] : (eq == 1 ? v4[1] : (eq == 2 ? v4[2] : v4[3])); };
+    float av[MFAS_MAX_CELLS], xhs[MFAS_MAX_CELLS], dsv[MFAS_MAX_CELLS];
+    uint32_t ekeep = 0xFu;
+    if (g.use_drop) {
+        ekeep = 0u;
+#pragma unroll
+        for (int i = 0; i < MFAS_MAX_CELLS; ++i)
+            if (drop_keep(h0, i, (uint32_t)(eb * R + r), g.drop_thr)) ekeep |= 1u << i;
+    }
+#pragma unroll
+    for (int i = 0; i < MFAS_MAX_CELLS; ++i) {
+        av[i] = 0.f; xhs[i] = 0.f; dsv[i] = 0.f;
+        if (i < L) {      // (workgroup-uniform)
             CT_STAMP(1 + i);
             const int nl = (nlbits >> (2 * i)) & 3;
             const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
@@ -974,67 +981,50 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                 const float sg = 1.0f / (1.0f + expf(-vecW[vbl + 5 * Rp]));
                 sgS = sg;
                 sgV = 1.0f - sg;
-                if (lane == 0) {
+                if (tid == 0) {
                     stc1<COH>(sb + g.sb_gsc + i * 2, sgS);
                     stc1<COH>(sb + g.sb_gsc + i * 2 + 1, sgV);
                 }
             }
-            f32x4 acc[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const int o = ((i * MB + mb) << 8) + lane * 4;
-                acc[mb] = *reinterpret_cast<const f32x4*>(yf_l + o);
+            float v = 0.f;
+            if (eact) {
+                const int o = ((i * MB + emb) << 8) + lane * 4;
+                f32x4 acc = *reinterpret_cast<const f32x4*>(yf_l + o);
                 if (g.alphas) {
                     const f32x4 yv = *reinterpret_cast<const f32x4*>(yf_l + sav_plane + o);
-                    *reinterpret_cast<f32x4*>(sav_d + o) = acc[mb] - yv;
-                    acc[mb] = acc[mb] * sgS + yv * sgV;
+                    dsv[i] = sel4(acc) - sel4(yv);
+                    acc = acc * sgS + yv * sgV;
                 }
+                if (i > 0) {
+                    const f32x4 w = pick4(tP, i);
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xo_l + (i - 1) * Bp * SX + (emb * 16 + l15) * SX + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], w[q], acc);
+                }
+                v = act_fwd(sel4(acc) + bias, nl);
             }
-            if (i > 0) {
-                const f32x4 w = pick4(tP, i);
-                const float* xprev = xo_l + (i - 1) * Bp * SX;
+            float z = v;
+            if (g.bn) {   // batch statistics over the valid rows: two exchanges (mean, then the variance of the deviations)
+                float s1 = colsum((eact && eb < nvalid) ? v : 0.f);
+                if (lg == 0) bnw[ew * 16 + r] = s1;
+                lds_barrier();
+                float tot = 0.f;
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xprev + (mb * 16 + l15) * SX + 4 * lg);
+                for (int w = 0; w < MB * 4; ++w) tot += bnw[w * 16 + r];
+                const float mu = tot / nf;
+                const float dlt = v - mu;
+                float s2 = colsum((eact && eb < nvalid) ? dlt * dlt : 0.f);
+                if (lg == 0) bnw[128 + ew * 16 + r] = s2;
+                lds_barrier();
+                float tot2 = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w[q], acc[mb]);
-                }
-            }
-            float av[MB][4];
-            float s = 0.f;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int b = mb * 16 + 4 * lg + q;
-                    const float v = act_fwd(acc[mb][q] + bias, nl);
-                    av[mb][q] = v;
-                    if (b < nvalid) s += v;
-                }
-            float zv[MB][4];
-            if (g.bn) {
-                const float mu = colsum(s) / nf;
-                float s2 = 0.f;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int b = mb * 16 + 4 * lg + q;
-                        const float dlt = av[mb][q] - mu;
-                        if (b < nvalid) s2 += dlt * dlt;
-                    }
-                const float var = colsum(s2) / nf;
+                for (int w = 0; w < MB * 4; ++w) tot2 += bnw[128 + w * 16 + r];
+                const float var = tot2 / nf;
                 const float rstd = 1.0f / sqrtf(var + g.bn_eps);
-                f32x4 xh4[MB];
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float xh = (av[mb][q] - mu) * rstd;
-                        xh4[mb][q] = xh;
-                        zv[mb][q] = xh * gam + bet;
-                    }
-                if (lg == 0) {
+                const float xh = (v - mu) * rstd;
+                xhs[i] = xh;
+                z = xh * gam + bet;
+                if (wave == 0 && lg == 0) {
                     rstd_l[i * Rp + r] = rstd;
                     if (colok) {   // running stats: momentum 0.1, unbiased variance
                         float rm = vecW[vbl + VEC_RM * Rp + r], rv = vecW[vbl + VEC_RV * Rp + r];
@@ -1045,33 +1035,15 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                         else { W[vb + VEC_RM * Rp + r] = rm; W[vb + VEC_RV * Rp + r] = rv; }
                     }
                 }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-                    *reinterpret_cast<f32x4*>(sav_x + ((i * MB + mb) << 8) + lane * 4) = xh4[mb];
-            } else {
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) zv[mb][q] = av[mb][q];
             }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                f32x4 a4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a4[q] = av[mb][q];
-                *reinterpret_cast<f32x4*>(sav_a + ((i * MB + mb) << 8) + lane * 4) = a4;
+            av[i] = v;
+            if (eact) {
+                float o = z;
+                if (g.use_drop) o = ((ekeep >> i) & 1u) ? o * g.drop_scale : 0.0f;
+                if (!(colok && eb < nvalid)) o = 0.0f;
+                xo_l[i * Bp * SX + eb * SX + r] = o;
             }
-            float* xcur = xo_l + i * Bp * SX;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int b = mb * 16 + 4 * lg + q;
-                    float o = zv[mb][q];
-                    if (g.use_drop) o = ((keep >> ((i * MB + mb) * 4 + q)) & 1u) ? o * g.drop_scale : 0.0f;
-                    if (!(colok && b < nvalid)) o = 0.0f;
-                    xcur[b * SX + r] = o;
-                }
+            if (i + 1 < L) lds_barrier();     // (the last cell's hand-off is the barrier below)
         }
     }
     if (wave == 1 && lane < Bp) lab_l[lane] = lab;   // visible to the loss after the head's barrier
@@ -1118,6 +1090,121 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     }
     lds_barrier();
     CT_STAMP(7);
+    // ------------------------------------------------------------------ backward: element-parallel like the forward; one
+    // barrier per cell (two with BatchNorm: the column sums of dz and dz * x-hat are needed before the activation gradient)
+#pragma unroll
+    for (int i = MFAS_MAX_CELLS - 1; i >= 0; --i) {
+        if (i < L) {
+            CT_STAMP(8 + (L - 1 - i));
+            const int nl = (nlbits >> (2 * i)) & 3;
+            const int vbl = i * g.vec_cell_stride;
+            const bool from_head = (i == L - 1);
+            float gr = 0.f;
+            if (g.bn) gr = vecW[vbl + VEC_G * Rp + r] * rstd_l[i * Rp + r];
+            float d = 0.f;
+            if (eact) {
+                f32x4 acc = z4;
+                if (from_head) {   // d_out = dlogits . Wc: even / odd class blocks in two chains
+                    f32x4 acc2 = z4;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < ncb) {
+                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(lg_l + (emb * 16 + l15) * SC + u * 16 + 4 * lg);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (u & 1) acc2 = MFMA16(x4[q], tHT[u][q], acc2);
+                                else acc = MFMA16(x4[q], tHT[u][q], acc);
+                            }
+                        }
+                    acc += acc2;
+                } else {
+                    const f32x4 w = pick4(tT, i + 1);
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(dy_l + (i + 1) * Bp * SX + (emb * 16 + l15) * SX + 4 * lg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], w[q], acc);
+                }
+                d = sel4(acc);
+                if (g.use_drop) d = ((ekeep >> i) & 1u) ? d * g.drop_scale : 0.0f;
+                if (!(eb < nvalid)) d = 0.f;
+            }
+            float dz = d;
+            if (g.bn) {
+                const float p0 = colsum(d), p1 = colsum(d * xhs[i]);
+                if (lg == 0) { bnw[ew * 16 + r] = p0; bnw[128 + ew * 16 + r] = p1; }
+                lds_barrier();
+                float dbet = 0.f, dgam = 0.f;
+#pragma unroll
+                for (int w = 0; w < MB * 4; ++w) { dbet += bnw[w * 16 + r]; dgam += bnw[128 + w * 16 + r]; }
+                const float k1 = dbet / nf, k2 = dgam / nf;
+                const float da = gr * (d - k1 - xhs[i] * k2);
+                dz = (eact && eb < nvalid) ? da : 0.f;
+                if (wave == 0 && lg == 0) { gv2[(i * 2 + 0) * 16 + r] = dgam; gv2[(i * 2 + 1) * 16 + r] = dbet; }
+            }
+            float dy = eact ? act_bwd(av[i], dz, nl) : 0.f;
+            if (!colok) dy = 0.f;
+            if (eact) {
+                dy_l[i * Bp * SX + eb * SX + r] = dy;
+                // d(alpha_i) needs sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]: the products go to the (now dead) V plane of the
+                // reduced feature sums, summed in fixed order by chain_lean_tail
+                if (g.alphas) yf_l[sav_plane + (i * Bp + eb) * 16 + r] = dy * dsv[i];
+            }
+            lds_barrier();
+        }
+    }
+    CT_STAMP(12);
+    {   // dy_i -> step buffer (dy operand of the sweep), coalesced
+        if constexpr (RES) {   // 16 B write-through stores: [L][Bp][16] = one f32x4 per thread and cell pair
+            for (int e4 = tid; e4 < L * Bp * 4; e4 += CHAIN_THREADS)
+                stc4<true>(a.stepbuf, sbo + g.sb_dy + (int64_t)e4 * 4, *reinterpret_cast<const f32x4*>(dy_l + (e4 >> 2) * SX + (e4 & 3) * 4));
+        } else {
+            float* dy_g = sb + g.sb_dy;   // [L][Bp][Rp]
+            for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(dy_g + e, dy_l[(e >> 4) * SX + (e & 15)]);
+        }
+    }
+    if constexpr (!RES) {   // dlogits -> step buffer (dy operand of the HEAD segment)
+        float* dlg = sb + g.sb_dlog;
+        for (int e = tid; e < Bp * Cp; e += CHAIN_THREADS) {
+            const int b = e / Cp, c = e - b * Cp;
+            stc1<COH>(dlg + e, lg_l[b * SC + c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// chain_lean_tail — what a train step still owes after dy is out: the epoch statistics and Adam on the vector parameters
+// (head bias; per cell bias, BN gamma / beta, alpha).  Gradients are summed from the step's LDS state (dy_i, dlogits, the BN
+// exchange totals) in fixed order.  Launch-per-phase schedules call it right after chain_lean; the resident persistent chain
+// calls it AFTER publishing dy, off the critical path.
+// ------------------------------------------------------------------------------------------------
+template <int MB, int MODE>
+__device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds, LeanRes* rs = nullptr) {
+    constexpr bool RES = MODE == 2;
+    const CandDev& cd = a.cands[bid];
+    const Geo& g = a.g;
+    const LeanLds<MB> ll(lds, g);
+    constexpr int Bp = MB * 16, Rp = 16, SX = Rp + 4, sav_plane = MFAS_MAX_CELLS * MB * 256;
+    const int tid = threadIdx.x;
+    const int C = g.C, R = g.R, L = cd.L, SC = ll.SC, nvec = ll.nvec;
+    const float* lg_l = ll.lg_l;
+    const float* dy_l = ll.dy_l;
+    const float* red_l = ll.red_l;
+    float* vec_l = ll.vec_l;
+    const float* gv2 = ll.scr + 256;
+    const int64_t cvec_off = cd.vec_off;
+    const int cgidx = cd.gidx;
+    AdamC ac = a.ac;
+    ac.ss = cs.ss;
+    ac.bc2s = cs.bc2s;
+    // parameters + moments: the LDS copy (MODE 2: the master copy; MODE 0 / 1: what chain_lean staged at entry — only the running
+    // statistics and nothing below have been written since)
+    const float* vecW = vec_l;
+    const float* vecM = vec_l + nvec;
+    const float* vecV = vec_l + 2 * nvec;
+    auto put_vec = [&](int64_t o, float w, float m, float v) {
+        if constexpr (RES) { const int e = (int)(o - cd.vec_off); vec_l[e] = w; vec_l[nvec + e] = m; vec_l[2 * nvec + e] = v; }
+        else { a.plane[o] = w; a.plane[a.plane_stride + o] = m; a.plane[2 * a.plane_stride + o] = v; }
+    };
+    if (a.logits_out) return;       // train-mode forward only: no statistics, no update
     if (tid == CHAIN_THREADS - 64) {
         float ls = 0.f, ncor = 0.f;
         for (int b = 0; b < Bp; ++b) { ls += red_l[b]; ncor += red_l[Bp + b]; }
@@ -1132,157 +1219,45 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
         }
     }
-    if (wave != 0) {   // dlogits -> step buffer (dy operand of the HEAD segment); head-bias Adam
-        if constexpr (!RES) {
-            float* dlg = sb + g.sb_dlog;
-            for (int e = tid - 64; e < Bp * Cp; e += CHAIN_THREADS - 64) {
-                const int b = e / Cp, c = e - b * Cp;
-                stc1<COH>(dlg + e, lg_l[b * SC + c]);
-            }
-        }
-        const int hc = tid - (CHAIN_THREADS - 256);
-        if (hc >= 0 && hc < C) {
-            float gsum = 0.f;
-            for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + hc];
-            const int64_t o = cvec_off + g.vec_head + hc;
-            float w = vecW[g.vec_head + hc], m = vecM[g.vec_head + hc], v = vecV[g.vec_head + hc];
-            adam1(w, m, v, gsum, ac);
-            put_vec(o, w, m, v);
-        }
-    } else {
-        // -------------------------------------------------------------- backward: wave 0, all cells, no barrier
-        for (int i = L - 1; i >= 0; --i) {
-            CT_STAMP(8 + (L - 1 - i));
-            const int nl = (nlbits >> (2 * i)) & 3;
-            const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
-            const int vbl = i * g.vec_cell_stride;
-            const bool from_head = (i == L - 1);
-            float gr = 0.f;
-            if (g.bn) gr = vecW[vbl + VEC_G * Rp + r] * rstd_l[i * Rp + r];
-            float* gv = yf_l;   // (the reduced feature sums are dead once the forward is done) gradients of the vector parameters:
-                                // [cell][b | gamma | beta][16] + [192 + cell] alpha; their Adam runs after the backward, on all waves
-            f32x4 a4[MB], xh4[MB], df4[MB], acc[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const int o = ((i * MB + mb) << 8) + lane * 4;
-                a4[mb] = *reinterpret_cast<const f32x4*>(sav_a + o);
-                xh4[mb] = z4;
-                df4[mb] = z4;
-                if (g.bn) xh4[mb] = *reinterpret_cast<const f32x4*>(sav_x + o);
-                if (g.alphas) df4[mb] = *reinterpret_cast<const f32x4*>(sav_d + o);
-                acc[mb] = z4;
-            }
-            if (from_head) {   // d_out = dlogits . Wc: even / odd class blocks in two chains (as mma_tiles)
-                f32x4 acc2[MB];
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc2[mb] = z4;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (u < ncb) {
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(lg_l + (mb * 16 + l15) * SC + u * 16 + 4 * lg);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                if (u & 1) acc2[mb] = MFMA16(x4[q], tHT[u][q], acc2[mb]);
-                                else acc[mb] = MFMA16(x4[q], tHT[u][q], acc[mb]);
-                            }
-                        }
-                    }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[mb] += acc2[mb];
-            } else {
-                const f32x4 w = pick4(tT, i + 1);
-                const float* src = dy_l + (i + 1) * Bp * SX;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(src + (mb * 16 + l15) * SX + 4 * lg);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[mb] = MFMA16(x4[q], w[q], acc[mb]);
-                }
-            }
-            float dz[MB][4];
-            float sdz = 0.f, sdzx = 0.f;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int b = mb * 16 + 4 * lg + q;
-                    float d = acc[mb][q];
-                    if (g.use_drop) d = ((keep >> ((i * MB + mb) * 4 + q)) & 1u) ? d * g.drop_scale : 0.0f;
-                    if (!(b < nvalid)) d = 0.f;
-                    dz[mb][q] = d;
-                    sdz += d;
-                    if (g.bn) sdzx += d * xh4[mb][q];
-                }
-            float dgam = 0.f, dbet = 0.f;
-            if (g.bn) {
-                dbet = colsum(sdz);
-                dgam = colsum(sdzx);
-                const float k1 = dbet / nf, k2 = dgam / nf;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int b = mb * 16 + 4 * lg + q;
-                        const float da = gr * (dz[mb][q] - k1 - xh4[mb][q] * k2);
-                        dz[mb][q] = b < nvalid ? da : 0.f;
-                    }
-            }
-            float sdy = 0.f, dalpha = 0.f;
-            float* dcur = dy_l + i * Bp * SX;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int b = mb * 16 + 4 * lg + q;
-                    float dy = act_bwd(a4[mb][q], dz[mb][q], nl);
-                    if (!colok) dy = 0.f;
-                    sdy += dy;
-                    dalpha += dy * df4[mb][q];
-                    dcur[b * SX + r] = dy;
-                }
-            const float db = colsum(sdy);
-            if (lg == 0) {   // one owner lane per column hands the column's gradients to the deferred Adam below
-                gv[(i * 3 + 0) * 16 + r] = db;
-                gv[(i * 3 + 1) * 16 + r] = dgam;
-                gv[(i * 3 + 2) * 16 + r] = dbet;
-            }
-            if (g.alphas) {   // d(alpha_i) = sigma'(alpha) * sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]
-                for (int o = 32; o > 0; o >>= 1) dalpha += __shfl_xor(dalpha, o);
-                if (lane == 0) gv[192 + i] = dalpha;
-            }
-        }
+    const int hc = tid - (CHAIN_THREADS - 256);
+    if (hc >= 0 && hc < C) {            // head bias: column sums of dlogits
+        float gsum = 0.f;
+        for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + hc];
+        const int64_t o = cvec_off + g.vec_head + hc;
+        float w = vecW[g.vec_head + hc], m = vecM[g.vec_head + hc], v = vecV[g.vec_head + hc];
+        adam1(w, m, v, gsum, ac);
+        put_vec(o, w, m, v);
     }
-    lds_barrier();
-    CT_STAMP(12);
-    {   // Adam on the vector parameters (bias, BN gamma / beta, alpha) of every cell: same arithmetic as before, but on 192 threads
-        // at once after the backward instead of inside wave 0's serial cell loop (~50 instructions per cell off the critical path)
-        const float* gv = yf_l;
-        if (tid < L * 48) {
-            const int i = tid / 48, which = (tid - i * 48) >> 4, rr = tid & 15;
-            if (rr < R && (which == 0 || g.bn)) {
-                const int e = i * g.vec_cell_stride + (which == 0 ? VEC_B : (which == 1 ? VEC_G : VEC_BE)) * Rp + rr;
-                float w = vecW[e], m = vecM[e], v = vecV[e];
-                adam1(w, m, v, gv[(i * 3 + which) * 16 + rr], ac);
-                put_vec(cvec_off + e, w, m, v);
+    if (tid < L * 48) {                 // per cell: bias (column sums of dy_i over the batch rows, in row order), BN gamma / beta
+        const int i = tid / 48, which = (tid - i * 48) >> 4, rr = tid & 15;
+        if (rr < R && (which == 0 || g.bn)) {
+            float gsum = 0.f;
+            if (which == 0) {
+                for (int b = 0; b < Bp; ++b) gsum += dy_l[i * Bp * SX + b * SX + rr];
+            } else {
+                gsum = gv2[(i * 2 + (which - 1)) * 16 + rr];
             }
-        } else if (g.alphas && tid >= 256 && tid < 256 + L) {
-            const int i = tid - 256, e = i * g.vec_cell_stride + 5 * Rp;
+            const int e = i * g.vec_cell_stride + (which == 0 ? VEC_B : (which == 1 ? VEC_G : VEC_BE)) * Rp + rr;
             float w = vecW[e], m = vecM[e], v = vecV[e];
-            const float sg = 1.0f / (1.0f + expf(-w));
-            adam1(w, m, v, gv[192 + i] * sg * (1.0f - sg), ac);
+#ifdef MFAS_DEBUG_GSUM
+            if (bid == 0 && cs.gstep == 0 && which == 0) { a.status[64 + i * 16 + rr] = __float_as_int(gsum); a.status[128 + i * 16 + rr] = __float_as_int(w); }
+#endif
+            adam1(w, m, v, gsum, ac);
             put_vec(cvec_off + e, w, m, v);
         }
-    }
-    {   // dy_i -> step buffer (dy operand of the sweep), coalesced
-        if constexpr (RES) {   // 16 B write-through stores: [L][Bp][16] = one f32x4 per thread and cell pair
-            for (int e4 = tid; e4 < L * Bp * 4; e4 += CHAIN_THREADS)
-                stc4<true>(a.stepbuf, sbo + g.sb_dy + (int64_t)e4 * 4, *reinterpret_cast<const f32x4*>(dy_l + (e4 >> 2) * SX + (e4 & 3) * 4));
-        } else {
-            float* dy_g = sb + g.sb_dy;   // [L][Bp][Rp]
-            for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(dy_g + e, dy_l[(e >> 4) * SX + (e & 15)]);
+    } else if (g.alphas && tid >= 192 && tid < 192 + L) {   // alpha_i: sum over rows, then over columns, of dy * (yS - yV)
+        const int i = tid - 192, e = i * g.vec_cell_stride + 5 * Rp;
+        const float* prod = ll.yf_l + sav_plane + i * Bp * 16;
+        float tot = 0.f;
+        for (int rr = 0; rr < 16; ++rr) {
+            float col = 0.f;
+            for (int b = 0; b < Bp; ++b) col += prod[b * 16 + rr];
+            tot += col;
         }
+        float w = vecW[e], m = vecM[e], v = vecV[e];
+        const float sg = 1.0f / (1.0f + expf(-w));
+        adam1(w, m, v, tot * sg * (1.0f - sg), ac);
+        put_vec(cvec_off + e, w, m, v);
     }
 }
 

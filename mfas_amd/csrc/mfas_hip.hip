@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bid = (int)blockIdx.x;
     if (bid < a.nchain) {
-        if constexpr (LEAN) chain_lean<MB>(a.ca, chain_step_of(a.ca), bid, lds);
+        if constexpr (LEAN) { chain_lean<MB>(a.ca, chain_step_of(a.ca), bid, lds); chain_lean_tail<MB, 0>(a.ca, chain_step_of(a.ca), bid, lds); }
         else chain_body<MB, false>(a.ca, chain_step_of(a.ca), bid, lds);
     }
     else if (bid < a.nchain + a.sa.ntap) sweep_tap_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain, lds);
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
 template <int MB, bool LEAN>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_chain(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if constexpr (LEAN) chain_lean<MB>(a, chain_step_of(a), (int)blockIdx.x, lds);
+    if constexpr (LEAN) { chain_lean<MB>(a, chain_step_of(a), (int)blockIdx.x, lds); chain_lean_tail<MB, 0>(a, chain_step_of(a), (int)blockIdx.x, lds); }
     else chain_body<MB, true>(a, chain_step_of(a), (int)blockIdx.x, lds);
 }
 
@@ -230,7 +230,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     // resident lean chain will run with it, otherwise the unit size chosen for it would be wrong for the fallback schedule)
     const size_t lean_bytes_early = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
                                      + (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.MB * 256 + (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp)
-                                     + (size_t)(1 + (g.bn ? 1 : 0) + (g.alphas ? 1 : 0)) * MFAS_MAX_CELLS * g.MB * 256) * 4;
+                                     + LEAN_SCR + 8) * 4;
     const bool lean_ok_early = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean_bytes_early <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
     bool plan_res = want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT") && (lean_ok_early || force_persist);
     auto count_feat_units = [&](int cc_target) {
@@ -443,8 +443,10 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         // chain_lean's LDS: out_i / dy_i of all cells, logits, misc, reduced sums, vector block, saved activations
         const size_t plane = (size_t)MFAS_MAX_CELLS * g.MB * 256;
         const size_t lean = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
-                             + (g.alphas ? 2 : 1) * plane + vec / 4 + (1 + (g.bn ? 1 : 0) + (g.alphas ? 1 : 0)) * plane) * 4;
-        p->lean_chain = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && std::max(ls, lean) <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
+                             + (g.alphas ? 2 : 1) * plane + vec / 4 + LEAN_SCR + 8) * 4;
+        // (the chain form must not depend on the sweep's chunk size: since round 2 the lean chain sums bias gradients and BN
+        // statistics in its own — element-parallel — order, so lean and general chains agree to rounding, not bit for bit)
+        p->lean_chain = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
         if (p->lean_chain) { p->lds_chain = lean; p->lds_step = std::max(p->lds_step, lean); }
         p->res_chain = res_ok && p->lean_chain && !getenv("MFAS_PERSIST_NO_RES_CHAIN");
         const size_t lds_rchain = p->res_chain ? p->lds_chain + 16 + 4 * (size_t)LeanLds<1>::own_floats() : 0;
@@ -476,7 +478,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     CREATE_CHK(hipMalloc(&p->stepbuf, sizeof(float) * (size_t)p->step_total));
     CREATE_CHK(hipMalloc(&p->d_cands, sizeof(CandDev) * K));
     CREATE_CHK(hipMalloc(&p->d_descs, sizeof(SegDesc) * p->descs.size()));
-    CREATE_CHK(hipMalloc(&p->d_status, sizeof(int32_t) * (K + 128)));   // + debug timestamp slots (MFAS_CHAIN_TIMING builds)
+    CREATE_CHK(hipMalloc(&p->d_status, sizeof(int32_t) * (K + 256)));   // + debug timestamp slots (MFAS_CHAIN_TIMING builds)
     CREATE_CHK(hipMalloc(&p->d_seeds, sizeof(uint32_t) * K));
     CREATE_CHK(hipMalloc(&p->d_corr, sizeof(long long)));
     {
@@ -1004,6 +1006,18 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         stats[i].dev_corrects = hstats[i].dev_corr;
     }
     if (status) memcpy(status, hstatus.data(), sizeof(int32_t) * K);
+#ifdef MFAS_DEBUG_GSUM
+    {
+        int32_t ts[128];
+        if (hipMemcpy(ts, p->d_status + 64, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[gsum cand0 step0]");
+            for (int i = 0; i < 64; ++i) { float f; memcpy(&f, &ts[i], 4); fprintf(stderr, " %.9g", f); }
+            fprintf(stderr, "\n[bias cand0 step0]");
+            for (int i = 64; i < 128; ++i) { float f; memcpy(&f, &ts[i], 4); fprintf(stderr, " %.9g", f); }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 #ifdef MFAS_CHAIN_TIMING
     {
         int32_t ts[16];

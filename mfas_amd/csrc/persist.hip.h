@@ -398,7 +398,8 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
                     wg_publish_barrier();
                     if (tid == 0) __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     PTRACE(3);
-                    lean_res_update<MB>(a.ca, cs, bid, lds);   // OUT / HEAD dW + Adam while the sweep units run
+                    chain_lean_tail<MB, 2>(a.ca, cs, bid, lds, &rs);   // statistics + vector-parameter Adam, after dy is out
+                    lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the sweep units run
                 }
                 lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs);
                 return;
@@ -424,6 +425,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
             wg_publish_barrier();
             if (tid == 0) __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             PTRACE(3);
+            if constexpr (LEAN) chain_lean_tail<MB, 1>(a.ca, cs, bid, lds);
         }
         return;
     }

@@ -34,7 +34,7 @@ toggle = next((a.split("=")[1] for a in sys.argv if a.startswith("toggle=")), No
 res = {}
 for mode in ("0", "1", "0", "1"):
     if toggle:
-        os.environ["MFAS_PERSIST"] = "0"
+        os.environ["MFAS_PERSIST"] = "1" if "force=1" in sys.argv else "0"
         if mode == "0":
             os.environ[toggle] = "1"
         else:
