@@ -3,6 +3,15 @@
 #pragma once
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Explicit LDS / global address spaces for pointers whose provenance the compiler cannot see (a buffer picked by a runtime
+// index, "in LDS if it fits, else scratch"): a generic pointer is accessed with FLAT instructions, and every flat load is
+// followed by s_waitcnt vmcnt(0) lgkmcnt(0) -- it drains all of the wave's prefetches in flight.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 / uint2 classes have no address-space-qualified operators)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#define MFAS_LDS __attribute__((address_space(3)))
+#define MFAS_GLB __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ MFAS_LDS T* as_lds(T* p) { return (MFAS_LDS T*)p; }
+template <typename T> __device__ __forceinline__ MFAS_GLB T* as_glb(T* p) { return (MFAS_GLB T*)p; }
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define KIND_S 0
@@ -139,10 +148,17 @@ __device__ __forceinline__ float row_ce(const float* x, int C, int lab) {
 }
 
 // sum over the 4 lane groups that share (lane & 15): column reduction of an MFMA D block
+// (gfx950 row swaps instead of two ds_bpermute round trips through the LDS crossbar: v_permlane16_swap exchanges the odd
+// rows of one operand with the even rows of the other, v_permlane32_swap the wave halves; with both operands = x the two
+// results are "x of the even / lower partner" and "x of the odd / upper partner", whose sum is the xor-16 / xor-32 butterfly.
+// own + partner or partner + own: the same f32 sum)
 __device__ __forceinline__ float colsum(float x) {
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    return x;
+    int xi = __float_as_int(x);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    x = __int_as_float(r16[0]) + __int_as_float(r16[1]);
+    xi = __float_as_int(x);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    return __int_as_float(r32[0]) + __int_as_float(r32[1]);
 }
 
 __device__ __forceinline__ int64_t tile_addr(int64_t seg_off, int rows_p, int cc, int rb, int kb) {
@@ -167,7 +183,7 @@ __device__ __forceinline__ void stage_table(float* dst, int stride, const void* 
                 const int64_t row = ord ? (int64_t)ord[pos + b] : (int64_t)(base + b);
                 val = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(tab) + row * width + col0 + c);
             }
-            *reinterpret_cast<f32x4*>(dst + b * stride + c) = val;
+            *as_lds(reinterpret_cast<f32x4*>(dst + b * stride + c)) = val;
         }
     } else {
         const int vpr = ncols >> 3;
@@ -193,8 +209,8 @@ __device__ __forceinline__ void stage_table(float* dst, int stride, const void* 
                 lo = (f32x4){f[0], f[1], f[2], f[3]};
                 hi = (f32x4){f[4], f[5], f[6], f[7]};
             }
-            *reinterpret_cast<f32x4*>(dst + b * stride + c) = lo;
-            *reinterpret_cast<f32x4*>(dst + b * stride + c + 4) = hi;
+            *as_lds(reinterpret_cast<f32x4*>(dst + b * stride + c)) = lo;
+            *as_lds(reinterpret_cast<f32x4*>(dst + b * stride + c + 4)) = hi;
         }
     }
 }

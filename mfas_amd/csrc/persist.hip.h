@@ -105,12 +105,12 @@ __device__ __forceinline__ void stage_table16(uint16_t* dst, int S16, const void
     const int vpr = ncols >> 3;
     for (int e = tid; e < nrows * vpr; e += nthreads) {
         const int b = e / vpr, c = (e - b * vpr) << 3;
-        uint4 raw = {0u, 0u, 0u, 0u};
+        u32x4 raw = {0u, 0u, 0u, 0u};
         if (b < nvalid) {
             const int64_t row = ord ? (int64_t)ord[pos + b] : (int64_t)(base + b);
-            raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(tab) + row * width + col0 + c);
+            raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(tab) + row * width + col0 + c);
         }
-        *reinterpret_cast<uint4*>(dst + b * S16 + c) = raw;
+        *as_lds(reinterpret_cast<u32x4*>(dst + b * S16 + c)) = raw;
     }
 }
 
@@ -120,7 +120,7 @@ struct ResUnit {              // wave-uniform constants of one resident unit
     int64_t part, dyo, gsco;  // step-buffer indices: partial slot, dy_i, alpha scale
     float *Wp, *Mp, *Vp;
     uint32_t *flag, *cnt;
-    float* xb[2];             // the two staged batches in LDS
+    int32_t xbo[2];           // the two staged batches in LDS (word offsets: a pointer picked at run time would be a flat pointer)
 };
 
 template <int MB, int NTR, bool X16, int NU>
@@ -158,8 +158,8 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         U[u].Vp = U[u].Mp + sa.plane_stride;
         U[u].flag = PERSIST_FLAG(a.sync, d.cand);
         U[u].cnt = PERSIST_CNT(a.sync, d.cand);
-        U[u].xb[0] = lds + (size_t)(2 * u) * a.res_buf_words;
-        U[u].xb[1] = lds + (size_t)(2 * u + 1) * a.res_buf_words;
+        U[u].xbo[0] = (2 * u) * a.res_buf_words;
+        U[u].xbo[1] = (2 * u + 1) * a.res_buf_words;
         cur[u] = 0;
         // the unit's state: wave w owns k-blocks w, w + 8, ... (as sweep_body's k-split)
 #pragma unroll
@@ -175,15 +175,15 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
 
     // MFMA operand reads from a staged batch: one element (dW: A[i = column][k = batch row]) / four consecutive columns
     auto x1 = [&](const float* xb, int S, int row, int col) -> float {
-        if constexpr (X16) return cvt16(reinterpret_cast<const uint16_t*>(xb)[row * S + col], dt);
-        else return xb[row * S + col];
+        if constexpr (X16) return cvt16(as_lds(reinterpret_cast<const uint16_t*>(xb))[row * S + col], dt);
+        else return as_lds(xb)[row * S + col];
     };
     auto x4of = [&](const float* xb, int S, int row, int col) -> f32x4 {
         if constexpr (X16) {
-            const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(xb) + row * S + col);
+            const u32x2 r = *as_lds(reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(xb) + row * S + col));
             return (f32x4){cvt16(r.x & 0xFFFFu, dt), cvt16(r.x >> 16, dt), cvt16(r.y & 0xFFFFu, dt), cvt16(r.y >> 16, dt)};
         } else {
-            return *reinterpret_cast<const f32x4*>(xb + row * S + col);
+            return *as_lds(reinterpret_cast<const f32x4*>(xb + row * S + col));
         }
     };
     auto stage = [&](const ResUnit& un, float* dst, int t) {     // rows of batch t -> LDS
@@ -215,7 +215,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         if (U[u].valid) {            // (wave-uniform, workgroup-uniform)
-            stage(U[u], U[u].xb[0], 0);
+            stage(U[u], lds + U[u].xbo[0], 0);
             __syncthreads();
             f32x4 yacc[MB];
 #pragma unroll
@@ -226,14 +226,14 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 if (kb < U[u].nkb) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
-                        const f32x4 x4 = x4of(U[u].xb[0], U[u].S, mb * 16 + l15, kb * 16 + 4 * lg);
+                        const f32x4 x4 = x4of(lds + U[u].xbo[0], U[u].S, mb * 16 + l15, kb * 16 + 4 * lg);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][s][q], yacc[mb]);
                     }
                 }
             }
             reduce_publish(U[u], yacc);
-            if (1 < a.T) stage(U[u], U[u].xb[1], 1);
+            if (1 < a.T) stage(U[u], lds + U[u].xbo[1], 1);
         }
     }
     if (tid == 0) {
@@ -284,8 +284,8 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
             if (pick == u) {
                 const ResUnit& un = U[u];
                 const bool fwd = t + 1 < a.T;
-                const float* xt = un.xb[cur[u]];
-                const float* xn = un.xb[cur[u] ^ 1];
+                const float* xt = lds + un.xbo[cur[u]];
+                const float* xn = lds + un.xbo[cur[u] ^ 1];
                 const bool tr_on = un.index == 0 && tid == 0 && t >= 8 && t < 16;
                 const int tr_base = (t - 8) * 8 + 4;
                 PTRACE(1);
@@ -339,7 +339,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 if (tid == 0) nxt[u] = t + 1;
                 cur[u] ^= 1;
                 // batch t+2 into the buffer batch t just vacated: it lands while this unit's chain runs step t+1
-                if (t + 2 < a.T) stage(un, un.xb[cur[u] ^ 1], t + 2);
+                if (t + 2 < a.T) stage(un, lds + un.xbo[cur[u] ^ 1], t + 2);
             }
         }
     }
