@@ -244,6 +244,16 @@ def main():
         ms = sum(p[1] for p in NS.PROFILE)
         bytes_per_launch = NS.PROFILE[-1][2] if NS.PROFILE else 0.0
         achieved = bytes_per_launch / (ms / n_launch * 1e-3) / 1e9 if n_launch else None
+        sched = NS.PROFILE[-1][3] if NS.PROFILE else {}
+        if sched.get("persistent"):
+            kernel = ("k_persist (ONE launch per epoch: per-candidate chain workgroups + "
+                      + (f"{sched['resident_units']} feature units resident in registers on {sched['resident_workgroups']} workgroups" if sched.get("resident_units")
+                         else "streaming feature units")
+                      + "; algorithmic bytes = what one epoch of a streaming schedule moves (24 B/param/step + taps): resident W/m/v never touch HBM, "
+                        "so `achieved` is a nominal rate for comparison, the loop itself is latency-bound, DESIGN.md 4a)")
+        else:
+            kernel = ("k_step (chain blocks of one group + sweep blocks of the other: dW, Adam, next-step forward)" if sched.get("groups", 2) > 1
+                      else "k_step (sweep of the whole population: dW, Adam, next-step forward; the chain runs in its own k_chain launch)")
         total_trained = total * a.steps
         # HBM traffic / MfmaUtil need rocprofv3 --pmc passes (separate runs, MI355X_MICROARCH.md): they are NOT measured in this
         # process.  When the committed passes of exactly this workload exist they are quoted WITH their source; else null.
@@ -288,7 +298,7 @@ def main():
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (a.backend if world > 1 else None),
                        "rank_seconds": rank_dt,
                        "mean_best_dev_acc": float(np.mean(accs))},
-            "roofline": {"bound": "hbm", "kernel": "k_step (chain blocks of one group + sweep blocks of the other: dW, Adam, next-step forward)",
+            "roofline": {"bound": "hbm", "kernel": kernel, "schedule": sched,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": n_launch, "avg_launch_us": (ms / n_launch * 1e3) if n_launch else None,

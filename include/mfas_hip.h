@@ -146,6 +146,13 @@ int mfas_population_sweep_profile(const mfas_population* pop, int64_t* launches,
                                   double* bytes_per_launch);
 int mfas_population_set_profiling(mfas_population* pop, int32_t on);
 
+/* (new) The step schedule this population was laid out for, so that a measurement can name the kernel it
+ * timed: info[0] = 1 persistent step loop (k_persist, one launch per epoch) / 0 launch per phase (k_step / k_chain);
+ * info[1] = feature units resident in registers; info[2] = their workgroups; info[3] = units per resident workgroup;
+ * info[4] = 1 when the resident lean chain owns OUT/HEAD; info[5] = 1 lean chain (R <= 16); info[6] = candidate groups of the
+ * fused launch-per-phase schedule (1 = chain and sweep back to back); info[7] = candidates. */
+int mfas_population_schedule(const mfas_population* pop, int32_t info[8]);
+
 /* (new) Streaming ceiling of this device for the sweep's access pattern: three planes of `bytes_per_plane` are
  * read-modify-written in 1 KiB tiles with nontemporal 16 B/lane accesses and no compute; returns GB/s (read + write). */
 int mfas_stream_probe(int64_t bytes_per_plane, int32_t iters, double* gb_per_s);

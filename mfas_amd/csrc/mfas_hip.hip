@@ -1176,6 +1176,13 @@ extern "C" int mfas_population_set_profiling(mfas_population* p, int32_t on) {
     return MFAS_OK;
 }
 
+extern "C" int mfas_population_schedule(const mfas_population* p, int32_t info[8]) {
+    if (!p || !info) return fail(MFAS_EINVAL, "null");
+    info[0] = p->persist ? 1 : 0; info[1] = p->nres; info[2] = p->nres_wg; info[3] = p->res_nu;
+    info[4] = p->res_chain ? 1 : 0; info[5] = p->lean_chain ? 1 : 0; info[6] = (int32_t)p->groups.size(); info[7] = p->K;
+    return MFAS_OK;
+}
+
 extern "C" int mfas_population_sweep_profile(const mfas_population* p, int64_t* launches, double* total_ms,
                                              double* bytes_per_launch) {
     if (!p) return fail(MFAS_EINVAL, "null");

@@ -411,6 +411,13 @@ class Population:
     def set_profiling(self, on: bool):
         _lib.check(self.lib.mfas_population_set_profiling(self._h, int(on)))
 
+    def schedule(self):
+        """The step schedule the engine laid this population out for (mfas_population_schedule)."""
+        info = (C.c_int32 * 8)()
+        _lib.check(self.lib.mfas_population_schedule(self._h, info))
+        keys = ("persistent", "resident_units", "resident_workgroups", "units_per_workgroup", "resident_chain", "lean_chain", "groups", "candidates")
+        return dict(zip(keys, (int(x) for x in info)))
+
     def sweep_profile(self):
         n, ms, by = C.c_int64(0), C.c_double(0), C.c_double(0)
         _lib.check(self.lib.mfas_population_sweep_profile(self._h, C.byref(n), C.byref(ms), C.byref(by)))

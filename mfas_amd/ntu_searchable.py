@@ -378,7 +378,7 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
         stats, status = pop.train(train_l.table, dev_l.table, E, etas, order=order,
                                   snapshot_best=bool(return_model))
         if getattr(args, "engine_profile", False):
-            PROFILE.append(pop.sweep_profile())
+            PROFILE.append(pop.sweep_profile() + (pop.schedule(),))
         for j, i in enumerate(mine):
             if getattr(args, "verbose", False):
                 for e in range(E):
