@@ -856,7 +856,9 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         // MB == 2: the two-workgroups-per-CU build unless a co-scheduled chain would bound the launch (see SweepU)
         const bool occ = nch == 0 || p->groups[gs].alg_state > p->occ_bytes;
         if (g.MB == 1) STEP_PICK(1, 4);
-        else if (g.MB == 2) { if (occ || p->lean_chain) STEP_PICK(2, 4); else STEP_PICK(2, 2); }   // chain_lean never spills
+        // (lean chain: the 128-VGPR build spills 8 registers of the element-parallel chain to scratch and is still the faster
+        //  one — R=16, B=20, 50 / 128 / 512 candidates: 47.2 / 99.2 / 418 us per step against 50.5 / 117.4 / 447 for the 2-workgroup build)
+        else if (g.MB == 2) { if (occ || p->lean_chain) STEP_PICK(2, 4); else STEP_PICK(2, 2); }
         else { if (p->nontemporal) STEP_LAUNCH(4, true, 2, false); else STEP_LAUNCH(4, false, 2, false); }
 #undef STEP_PICK
 #undef STEP_LAUNCH

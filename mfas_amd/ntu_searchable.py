@@ -16,6 +16,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -299,6 +301,42 @@ def make_order(N, epochs, shuffle, seed, device):
     return torch.stack([torch.randperm(N, generator=gen, device=device) for _ in range(epochs)]).to(torch.int32)
 
 
+ROUNDS_MIN_COST = 34 * 127_000     # parameter-cost units (population.candidate_cost) of ~34 conf-4-sized R=16 candidates
+
+
+def _plan_rounds(hp, confs, mine, cost_of, device, seed_base, chunk_cols):
+    """The rank's share as ONE population, or as TWO trained one after the other when the share is too large for the
+    persistent resident schedule (parameters in registers, one launch per epoch: <= ~28 conf-4-sized candidates at R <= 16)
+    but its halves fit: measured at R=16, B=20 on MI355X, 36...56 candidates take 47-55 us per train step with launches and
+    2 x 20 us as two resident rounds (29...33: equal, left alone).  Candidates are independent and carry their own seeds, so
+    the split changes nothing but the column-chunk summation order (as any change of population size does).
+    Yields (indices, Population)."""
+    if not mine:
+        return
+
+    def make(idx):
+        return Population(hp, [confs[i] for i in idx], device, drop_seeds=[(seed_base * 7 + i) & 0xFFFFFFFF for i in idx],
+                          chunk_cols=chunk_cols)
+
+    full = make(mine)
+    if (full.schedule()["persistent"] or hp.R > 16 or len(mine) < 4
+            or sum(cost_of[i] for i in mine) < ROUNDS_MIN_COST or os.environ.get("MFAS_NO_ROUNDS")):
+        yield mine, full
+        return
+    half = popmod.assign([cost_of[i] for i in mine], 2)
+    groups = [[i for i, h in zip(mine, half) if h == r] for r in (0, 1)]
+    pops = [make(g) for g in groups]
+    if all(p.schedule()["persistent"] for p in pops):
+        full.close()
+        for g, p in zip(groups, pops):
+            yield g, p
+        return
+    for p in pops:
+        p.close()
+    yield mine, full
+
+
+
 def train_sampled_models(sampled_configurations, searchable_type, dataloaders, args, device,
                          return_model=[], premodels=[], preaccuracies=[],
                          train_only_central_params=True, state_dict=dict(), _hp=None, _pos_weight=None):
@@ -341,37 +379,35 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
     owner, cap = popmod.shard(costs, world)
     mine = [i for i, o in zip(wanted, owner) if o == rank]
 
-    local_acc, models = [], {}
-    if mine:
-        pop = Population(hp, [confs[i] for i in mine], device,
-                         drop_seeds=[(seed_base * 7 + i) & 0xFFFFFFFF for i in mine],
-                         chunk_cols=int(getattr(args, "engine_chunk_cols", 0)))
+    local_acc_by_idx, models = {}, {}
+    sched = LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, num_batches_per_epoch)
+    etas = sched.eta_table(E * nb)
+    order = make_order(N_tr, E, train_l.shuffle, seed_base + 1, device) if mine else None
+    for group, pop in _plan_rounds(hp, confs, mine, dict(zip(wanted, costs)), device, seed_base,
+                                   int(getattr(args, "engine_chunk_cols", 0))):
         if _pos_weight is not None:
             pop.set_pos_weight(_pos_weight)
         mods = {}
         if premodels:
-            for j, i in enumerate(mine):
+            for j, i in enumerate(group):
                 src = premodels[i].module if getattr(args, "use_dataparallel", False) else premodels[i]
                 m = searchable_type(args, confs[i])
                 m.load_state_dict(src.state_dict())
                 pop.set_params(j, m.flat_params())
                 mods[i] = m
         elif getattr(args, "engine_init", "torch") == "device":
-            pop.init([(seed_base + 2 + i) & 0x7FFFFFFF for i in mine])
+            pop.init([(seed_base + 2 + i) & 0x7FFFFFFF for i in group])
         else:
-            for j, i in enumerate(mine):
+            for j, i in enumerate(group):
                 with torch.random.fork_rng(devices=[]):
                     torch.manual_seed(seed_base + 2 + i)   # world-size independent per-candidate stream
                     m = searchable_type(args, confs[i])
                 pop.set_params(j, m.flat_params())
                 if return_model:
                     mods[i] = m
-        sched = LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, num_batches_per_epoch)
-        etas = sched.eta_table(E * nb)
-        order = make_order(N_tr, E, train_l.shuffle, seed_base + 1, device)
         if getattr(args, "verbose", False):
             print("Now training: ")
-            for i in mine:
+            for i in group:
                 print(confs[i])
         if getattr(args, "engine_profile", False):
             pop.set_profiling(True)
@@ -379,15 +415,15 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
                                   snapshot_best=bool(return_model))
         if getattr(args, "engine_profile", False):
             PROFILE.append(pop.sweep_profile() + (pop.schedule(),))
-        for j, i in enumerate(mine):
+        for j, i in enumerate(group):
             if getattr(args, "verbose", False):
                 for e in range(E):
                     print("train Loss: {:.4f} Acc: {:.4f}".format(stats["train_loss_sum"][j, e] / N_tr,
                                                                   stats["train_corrects"][j, e] / N_tr))
                     print("dev Loss: {:.4f} Acc: {:.4f}".format(stats["dev_loss_sum"][j, e] / N_dev,
                                                                 stats["dev_corrects"][j, e] / N_dev))
-            local_acc.append(best_dev_f1(stats[j], bool(status[j]), N_dev) if hp.loss_mode == 1
-                             else best_dev_accuracy(stats[j], N_dev))
+            local_acc_by_idx[i] = (best_dev_f1(stats[j], bool(status[j]), N_dev) if hp.loss_mode == 1
+                                   else best_dev_accuracy(stats[j], N_dev))
             if return_model:
                 m = mods.get(i) or searchable_type(args, confs[i])
                 m.load_flat(pop.get_params(j))
@@ -396,6 +432,7 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
                 m.train(False)
                 models[i] = m
         pop.close()
+    local_acc = [local_acc_by_idx[i] for i in mine]
     accs_all = popmod.gather_accuracies(mine, local_acc, K, device, cap=cap)
     real_accuracies = [accs_all[i] for i in wanted]
     if return_model:

@@ -353,3 +353,33 @@ def test_search_cli_two_ranks_matches_single(dev):
 
     one, two = run(1), run(2)
     assert len(one) == 5 and one == two, (one, two)
+
+
+def test_large_share_trains_in_two_resident_rounds(dev, monkeypatch):
+    """A share too large for the persistent resident schedule whose halves fit is trained as two populations one after the other
+    (ntu_searchable._plan_rounds): same accuracies, candidate by candidate, as the single launch-per-phase population on the
+    same column chunks (candidates are independent; every schedule of the same units is bit-identical)."""
+    import mfas_amd as M
+    from mfas_amd import ntu_searchable as NS
+    monkeypatch.setenv("MFAS_NO_TAP_MAJOR", "1")       # per-segment units in both schedules
+    rng = np.random.default_rng(3)
+    monkeypatch.setattr(NS, "ROUNDS_MIN_COST", 0)      # (the default only splits shares of >= ~34 conf-4-sized candidates)
+    confs = [np.stack([rng.integers(0, 4, 4), rng.integers(0, 4, 4), rng.integers(0, 2, 4)], 1) for _ in range(30)]
+    ttr, tdv = O.synth_table(400, 41, snr=0.5), O.synth_table(200, 42, snr=0.5)
+    ld = loaders(ttr, tdv, dev, 20, dtype=torch.bfloat16)
+    args = mkargs(batchsize=20, epochs=2, engine_init="device", engine_chunk_cols=256, engine_profile=True)
+
+    def run():
+        NS.PROFILE.clear()
+        torch.manual_seed(11)
+        acc = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev)
+        return acc, [p[3] for p in NS.PROFILE]
+
+    monkeypatch.setenv("MFAS_NO_ROUNDS", "1")
+    one, sched_one = run()
+    monkeypatch.delenv("MFAS_NO_ROUNDS")
+    two, sched_two = run()
+    assert len(sched_one) == 1 and not sched_one[0]["persistent"] and sched_one[0]["candidates"] == 30
+    assert len(sched_two) == 2 and all(s["persistent"] and s["resident_units"] > 0 for s in sched_two)
+    assert sorted(s["candidates"] for s in sched_two) == [15, 15]
+    assert one == two
