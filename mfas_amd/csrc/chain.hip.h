@@ -1239,9 +1239,6 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
             }
             const int e = i * g.vec_cell_stride + (which == 0 ? VEC_B : (which == 1 ? VEC_G : VEC_BE)) * Rp + rr;
             float w = vecW[e], m = vecM[e], v = vecV[e];
-#ifdef MFAS_DEBUG_GSUM
-            if (bid == 0 && cs.gstep == 0 && which == 0) { a.status[64 + i * 16 + rr] = __float_as_int(gsum); a.status[128 + i * 16 + rr] = __float_as_int(w); }
-#endif
             adam1(w, m, v, gsum, ac);
             put_vec(cvec_off + e, w, m, v);
         }
