@@ -1008,18 +1008,6 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         stats[i].dev_corrects = hstats[i].dev_corr;
     }
     if (status) memcpy(status, hstatus.data(), sizeof(int32_t) * K);
-#ifdef MFAS_DEBUG_GSUM
-    {
-        int32_t ts[128];
-        if (hipMemcpy(ts, p->d_status + 64, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
-            fprintf(stderr, "[gsum cand0 step0]");
-            for (int i = 0; i < 64; ++i) { float f; memcpy(&f, &ts[i], 4); fprintf(stderr, " %.9g", f); }
-            fprintf(stderr, "\n[bias cand0 step0]");
-            for (int i = 64; i < 128; ++i) { float f; memcpy(&f, &ts[i], 4); fprintf(stderr, " %.9g", f); }
-            fprintf(stderr, "\n");
-        }
-    }
-#endif
 #ifdef MFAS_CHAIN_TIMING
     {
         int32_t ts[16];
