@@ -21,7 +21,7 @@ struct EvalArgs {
 #define EVAL_CE 128   // staged feature columns per pass
 
 template <int MBE, int NRBW>
-__global__ void __launch_bounds__(256) k_eval(const EvalArgs a) {
+__global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cand = a.cand0 + blockIdx.y;
     const CandDev& cd = a.cands[cand];
