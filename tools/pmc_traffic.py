@@ -53,5 +53,38 @@ def main():
     print(json.dumps(res["per_launch"]), json.dumps(res["calibration"]))
 
 
+def small(outdir):
+    """Small-population regime (bench.py --workload c2: 16 sampled L=4 confs, R=16, B=20, one epoch of 100 steps): HBM bytes per
+    train step of the whole population, persistent resident schedule (k_persist, one launch) against launch-per-phase
+    (k_step + k_chain), next to the algorithmic 24 B/param + taps of a streaming schedule."""
+    outdir = os.path.abspath(outdir)
+    os.makedirs(outdir, exist_ok=True)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--no-cpu-baseline", "--steps", "1", "--warmup", "0",
+           "--epochs", "1", "--n-train", "2000", "--n-dev", "320"]
+    steps = 100
+    res = {}
+    for mode, env in (("persistent_resident", {}), ("launch_per_phase", {"MFAS_PERSIST": "0"})):
+        os.environ.pop("MFAS_PERSIST", None)
+        os.environ.update(env)
+        tot = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            rows = collect(outdir, f"small_{mode}_{counter}", counter, cmd)
+            ks = [r for r in rows if r["Kernel_Name"].startswith(("void k_persist", "void k_step", "void k_chain"))]
+            tot[counter] = sum(float(r["Counter_Value"]) for r in ks) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+            tot["kernels"] = sorted({r["Kernel_Name"].split("(")[0] for r in ks})
+            tot["dispatches"] = len(ks)
+        res[mode] = {"kernels": tot["kernels"], "dispatches": tot["dispatches"], "read_bytes_per_step": tot["FETCH_SIZE"] / steps,
+                     "write_bytes_per_step": tot["WRITE_SIZE"] / steps, "total_bytes_per_step": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / steps}
+    os.environ.pop("MFAS_PERSIST", None)
+    res["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; x2.00 / x1.00, KB = 1024 B) summed over the train kernels of "
+                   "`bench.py --workload c2 --steps 1 --warmup 0 --epochs 1 --n-train 2000 --n-dev 320` (16 candidates, 100 train steps), "
+                   "divided by 100; the first step's parameter load and the last step's store are included")
+    json.dump(res, open(os.path.join(outdir, "pmc_traffic_small.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[2] == "small":
+        small(sys.argv[1])
+    else:
+        main()
