@@ -29,6 +29,8 @@ struct PersistArgs {
                                       // LDS words of one staged batch
     int32_t nres, res_chain;   // units [0, nres) are RESIDENT feature units: one workgroup each (blocks K .. K + nres);
                                // res_chain: the (lean) chain owns OUT / HEAD and keeps them + its vector block on chip
+    int32_t lose_step, _pad0;  // test hook (MFAS_PERSIST_TEST_LOSE_STEP): candidate 0's chain never publishes this step (-1: off) -- the
+                               // bounded waits must then end the launch with an error instead of hanging
     int32_t T, epoch;          // train steps of this launch, epoch index (statistics slot)
     int64_t N, pos0;           // N_train, epoch * N_train (position in the sample-order table)
     int32_t B, gstep0;         // batch size, epoch * batches-per-epoch (Adam / dropout step counter base)
@@ -396,7 +398,8 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
                     chain_lean<MB, 2>(a.ca, cs, bid, lds, &rs);
                     PTRACE(2);
                     wg_publish_barrier();
-                    if (tid == 0) __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0 && !(bid == 0 && t == a.lose_step))
+                        __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     PTRACE(3);
                     chain_lean_tail<MB, 2>(a.ca, cs, bid, lds, &rs);   // statistics + vector-parameter Adam, after dy is out
                     lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the sweep units run

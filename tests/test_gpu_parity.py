@@ -527,6 +527,34 @@ def test_persistent_resident_schedule_bit_identical_full_size(dev, K, B, bn, cc,
     assert (out["1"][0]["dev_corrects"][:, 1] > 0.05 * 5600).all()      # and it trains (chance = 1.7 %)
 
 
+def test_persistent_loop_lost_dependency_ends_with_an_error(dev, monkeypatch):
+    """The persistent step loop's waits are bounded: when a dependency never arrives (test hook: candidate 0's chain does not
+    publish step 3) the launch ends by itself — the starved workgroups time out, set the abort word, everybody leaves — and
+    train() reports an error instead of hanging the GPU; the device is usable afterwards."""
+    from mfas_amd import FeatureTable, Hyper, Population
+    hp = Hyper(R=16, C=60, B=20, bn=False, drpt=0.5, tap_bits=16)
+    confs = [np.array(CONFS["c4"])] * 4
+    tr = FeatureTable.synthetic(400, 1, dev, torch.bfloat16, snr=0.5)
+    dv = FeatureTable.synthetic(200, 2, dev, torch.bfloat16, snr=0.5)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, 400 / 20, 20)
+
+    def run():
+        pop = Population(hp, confs, dev, drop_seeds=[1, 2, 3, 4])
+        assert pop.schedule()["persistent"] and pop.schedule()["resident_chain"]
+        pop.init([1, 2, 3, 4])
+        try:
+            return pop.train(tr, dv, 1, etas)
+        finally:
+            pop.close()
+
+    monkeypatch.setenv("MFAS_PERSIST_TEST_LOSE_STEP", "3")
+    with pytest.raises(RuntimeError, match="timed out"):
+        run()
+    monkeypatch.delenv("MFAS_PERSIST_TEST_LOSE_STEP")
+    stats, status = run()
+    assert not status.any() and (stats["train_corrects"] >= 0).all()
+
+
 @pytest.mark.parametrize("B,R", [(48, 16), (33, 128)])
 def test_large_batch_paths(dev, B, R):
     """batch > 32 runs the MB=4 (64 padded rows) instantiation; 33 leaves the last 31 padded rows inert."""
