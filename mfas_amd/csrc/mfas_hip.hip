@@ -34,6 +34,8 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <thread>
+#include <chrono>
 
 #include "mfas_hip.h"
 
@@ -882,7 +884,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         HIPCHK(hipMemcpyAsync(p->d_scal, step_scalars, sizeof(float) * have, hipMemcpyHostToDevice, p->stream));
     }
     // one persistent launch = all train steps of one epoch (persist.hip.h)
-    auto persist_epoch = [&](int ep, int64_t T) -> hipError_t {
+    auto persist_epoch_once = [&](int ep, int64_t T) -> hipError_t {
         hipError_t e = hipMemsetAsync(p->d_sync, 0, sizeof(uint32_t) * ((size_t)K * PERSIST_SYNC_STRIDE + 64), p->stream);
         if (e != hipSuccess) return e;
         PersistArgs pa;
@@ -924,6 +926,24 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         return hipMemcpyAsync(&aborts[ep], p->d_sync + (size_t)K * PERSIST_SYNC_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
+    };
+    // The launch is only valid when its whole grid is resident at once (roll call in k_persist).  When another process holds
+    // part of the GPU the roll call fails BEFORE anything is modified (abort code 2): wait a little (jittered, so that two
+    // processes that collided do not collide again in lockstep) and launch the epoch again.
+    auto persist_epoch = [&](int ep, int64_t T) -> hipError_t {
+        for (int attempt = 0;; ++attempt) {
+            hipError_t e = persist_epoch_once(ep, T);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(p->stream);
+            if (e != hipSuccess) return e;
+            if (aborts[ep] != PERSIST_ABORT_NOT_RESIDENT || attempt >= 400) {
+                if (attempt && getenv("MFAS_PERSIST_VERBOSE")) fprintf(stderr, "[persist] epoch %d: grid not resident at once, relaunched %d time(s)\n", ep, attempt);
+                return hipSuccess;
+            }
+            if (p->profiling && ev_used >= 2) { ev_used -= 2; ev_bytes.pop_back(); }       // the failed attempt is not a measurement
+            aborts[ep] = 0;
+            std::this_thread::sleep_for(std::chrono::microseconds(200 + (uint64_t)((reinterpret_cast<uintptr_t>(p) >> 6) * 2654435761u % 1800u) + 50u * (attempt % 16)));
+        }
     };
 
     int64_t done = 0;   // train steps completed (max_steps bookkeeping)

@@ -49,6 +49,9 @@ struct PersistArgs {
 #define PERSIST_LDS_WORDS 32            // LDS words the loop itself uses (behind the bodies' LDS)
 #define PTRACE(slot) do { if (a.trace && tr_on) a.trace[tr_base + (slot)] = wall_clock64(); } while (0)
 #define PERSIST_SPIN_LIMIT (1u << 22)   // a few seconds of s_sleep polls: only a lost workgroup or a bug gets here
+#define PERSIST_ROLL_LIMIT 6000u        // roll call at launch start: ~5 ms of polls for every workgroup of the grid to be resident
+#define PERSIST_ROLL(sync, K) ((sync) + (size_t)(K) * PERSIST_SYNC_STRIDE + 32)   // workgroups that have started (own cache line)
+#define PERSIST_ABORT_NOT_RESIDENT 2u   // abort code of a failed roll call: nothing has been modified, the host may simply relaunch
 
 __device__ __forceinline__ uint32_t ld_u32_relaxed(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -373,6 +376,36 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
     const int bid = (int)blockIdx.x, tid = threadIdx.x;
     const int K = a.nchain;
     uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
+
+    // Roll call: the loop below is only deadlock-free when EVERY workgroup of the grid is resident at the same time.  That holds
+    // when the process owns the GPU (grid <= #CUs, one workgroup per CU); when another process's kernels hold CUs, part of the
+    // grid may be waiting for a slot that the resident part — spinning on it — never frees.  So nobody touches any state before
+    // all workgroups have checked in; if that does not happen within ~5 ms the resident ones leave (abort code 2), the late ones
+    // see the code and leave too, and the host relaunches the epoch.
+    // (count and verdict live in ONE word, so "everybody is here" and "somebody gave up" cannot both be observed)
+    if (tid == 0) {
+        uint32_t* roll = PERSIST_ROLL(a.sync, K);
+        constexpr uint32_t GAVE_UP = 0x80000000u;
+        const uint32_t G = gridDim.x;
+        int ok = -1;
+        if (__hip_atomic_fetch_add(roll, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & GAVE_UP) ok = 0;
+        uint32_t spins = 0;
+        while (ok < 0) {
+            const uint32_t v = ld_u32_relaxed(roll);
+            if (v & GAVE_UP) ok = 0;
+            else if (v >= G) ok = 1;
+            else if (++spins > PERSIST_ROLL_LIMIT) {
+                uint32_t expect = v;
+                if (__hip_atomic_compare_exchange_strong(roll, &expect, v | GAVE_UP, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(abortw, PERSIST_ABORT_NOT_RESIDENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                }
+            } else __builtin_amdgcn_s_sleep(8);
+        }
+        ldsw[1] = ok;
+    }
+    __syncthreads();
+    if (!ldsw[1]) return;
 
     if (bid < K) {
         // ------------------------------------------------------------------ chain workgroup of candidate `bid`

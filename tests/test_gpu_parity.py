@@ -555,6 +555,58 @@ def test_persistent_loop_lost_dependency_ends_with_an_error(dev, monkeypatch):
     assert not status.any() and (stats["train_corrects"] >= 0).all()
 
 
+_SHARE_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from mfas_amd import FeatureTable, Hyper, Population
+from oracle import np_oracle as O
+dev = torch.device("cuda:0")
+hp = Hyper(R=16, C=60, B=20, bn=False, drpt=0.5, tap_bits=16)
+conf = np.array([[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]])
+K, E, N = 20, 10, 10000
+tr = FeatureTable.synthetic(N, 1, dev, torch.bfloat16, snr=0.5)
+dv = FeatureTable.synthetic(600, 2, dev, torch.bfloat16, snr=0.5)
+etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / 20, E * (N // 20))
+pop = Population(hp, [conf] * K, dev, drop_seeds=list(range(7, 7 + K)), chunk_cols=512)
+assert pop.schedule()["persistent"] and pop.schedule()["resident_workgroups"] + K > 128      # two such grids cannot be co-resident
+pop.init(list(range(1, K + 1)))
+torch.cuda.synchronize()
+if len(sys.argv) > 3:       # start together with the other process: <dir> <n processes>
+    import os, time
+    open(os.path.join(sys.argv[2], "ready_%d" % os.getpid()), "w").close()
+    t0 = time.time()
+    while len([f for f in os.listdir(sys.argv[2]) if f.startswith("ready_")]) < int(sys.argv[3]) and time.time() - t0 < 120:
+        time.sleep(0.001)
+stats, status = pop.train(tr, dv, E, etas)
+assert not status.any()
+print("DIGEST", hashlib.sha256(stats.tobytes()).hexdigest(), flush=True)
+"""
+
+
+def test_two_processes_share_the_gpu_with_persistent_grids(dev, tmp_path):
+    """Two processes whose persistent grids (one workgroup per CU each, > half the chip) cannot be resident together train on
+    the same GPU at the same time: the roll call at the start of every launch detects a partially resident grid before anything
+    is modified and the host relaunches the epoch — both finish, with the results of a solo run."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "share.py"
+    script.write_text(_SHARE_SCRIPT)
+
+    def digest(out):
+        return [l.split()[1] for l in out.splitlines() if l.startswith("DIGEST")]
+
+    solo = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300)
+    assert solo.returncode == 0, solo.stderr[-2000:]
+    env = dict(os.environ, MFAS_PERSIST_VERBOSE="1")
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(tmp_path), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+        assert digest(o) == digest(solo.stdout) and len(digest(o)) == 1
+    print("relaunched epochs per process:", [e.count("relaunched") for _, e in outs])     # (typically most of the 10)
+
+
 @pytest.mark.parametrize("B,R", [(48, 16), (33, 128)])
 def test_large_batch_paths(dev, B, R):
     """batch > 32 runs the MB=4 (64 padded rows) instantiation; 33 leaves the last 31 padded rows inert."""
