@@ -142,6 +142,30 @@ def test_layer_configurations_and_module_surface():
                 m(({k: v for k, v in x.items() if k[0] == "v"}, {k: v for k, v in x.items() if k[0] == "s"}))
 
 
+def test_initial_flat_params_equals_module_construction():
+    """train_sampled_models initialises candidates without building the module: the numbers must be the module's, bit for bit."""
+    from types import SimpleNamespace
+    import torch
+    from mfas_amd import ntu_searchable as NS
+    rng = np.random.default_rng(2)
+    for bn, drpt, R, C in [(False, 0.5, 16, 60), (True, 0.5, 128, 60), (True, 0.0, 32, 11)]:
+        args = SimpleNamespace(vid_len=(8, 32), num_outputs=C, drpt=drpt, inner_representation_size=R, batchnorm=bn, alphas=True, batchsize=16,
+                               multitask=False)
+        for L in (1, 2, 4):
+            conf = np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1)
+            torch.manual_seed(1234 + L)
+            want = NS.Searchable_Skeleton_Image_Net(args, conf).flat_params()
+            after_module = torch.rand(1)
+            torch.manual_seed(1234 + L)
+            got = NS.initial_flat_params(args, conf)
+            after_fast = torch.rand(1)
+            assert torch.equal(want, got), (bn, drpt, R, C, L)
+            assert torch.equal(after_module, after_fast)        # the same amount of the random stream was consumed
+    with pytest.raises(ValueError):
+        NS.initial_flat_params(SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=0.0, inner_representation_size=16, batchnorm=False, batchsize=16,
+                                               alphas=False, multitask=False), np.array([[0, 0, 0]]))
+
+
 def test_weight_sharing_keys():
     import mfas_amd as M
     args = mkargs()
