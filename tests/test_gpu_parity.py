@@ -527,6 +527,66 @@ def test_persistent_resident_schedule_bit_identical_full_size(dev, K, B, bn, cc,
     assert (out["1"][0]["dev_corrects"][:, 1] > 0.05 * 5600).all()      # and it trains (chance = 1.7 %)
 
 
+@pytest.mark.parametrize("seed", range(20))
+def test_persistent_schedule_fuzz_bit_identical(dev, seed):
+    """Random small populations at R <= 16 (population size up to the resident capacity, mixed depths, B in 2..32, BN / alphas /
+    dropout on or off, bf16 / f16 / f32 taps, ragged last batch, odd class counts, one or two units per workgroup, units up to
+    1024 columns): the persistent schedule the engine picks by default against launch-per-phase on the same units — statistics,
+    parameters and both Adam moments bit for bit."""
+    import os
+    from mfas_amd import FeatureTable, Hyper, Population
+    rng = np.random.default_rng(1000 + seed)
+    R = int(rng.choice([8, 16, 16, 16]))
+    B = int(rng.choice([2, 7, 16, 20, 20, 32]))
+    bn = bool(rng.integers(0, 2)) or False
+    drpt = float(rng.choice([0.0, 0.5])) if bn else 0.5
+    alphas = bool(rng.integers(0, 2))
+    C = int(rng.choice([60, 23, 5]))
+    dtype = [torch.bfloat16, torch.float16, torch.float32][int(rng.integers(0, 3))]
+    cc = int(rng.choice([128, 256, 512, 1024])) if dtype != torch.float32 else int(rng.choice([128, 256]))
+    K = int(rng.choice({128: [1, 3, 6], 256: [1, 4, 9, 12], 512: [2, 7, 16, 24], 1024: [3, 8, 17]}[cc]))   # around the resident capacity
+    N = int(rng.integers(3 * B + 1, 9 * B))
+    if N % B == 1:
+        N += 1            # (a final batch of one sample is an error with BatchNorm, as in the reference)
+    E = 2
+    hp = Hyper(R=R, C=C, B=B, bn=bn, drpt=drpt, alphas=alphas, tap_bits=16 if dtype != torch.float32 else 32)
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in rng.integers(1, 5, K)]
+    tr = FeatureTable.synthetic(N, 1 + seed, dev, dtype, snr=0.5, C=C)
+    dv = FeatureTable.synthetic(2 * B + 3, 100 + seed, dev, dtype, snr=0.5, C=C)
+    nb = -(-N // B)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, E * nb)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    order = torch.stack([torch.randperm(N, generator=g, device=dev) for _ in range(E)]).to(torch.int32)
+    out, sched = {}, {}
+    for mode in ("0", "default"):
+        os.environ["MFAS_NO_TAP_MAJOR"] = "1"
+        if mode == "0":
+            os.environ["MFAS_PERSIST"] = "0"
+        try:
+            try:
+                pop = Population(hp, confs, dev, drop_seeds=list(range(9, 9 + K)), chunk_cols=cc)
+            except RuntimeError as e:          # launch-per-phase LDS limit for this (B, cc): nothing to compare on this draw
+                if "LDS" in str(e):
+                    pytest.skip(str(e))
+                raise
+        finally:
+            os.environ.pop("MFAS_PERSIST", None)
+            del os.environ["MFAS_NO_TAP_MAJOR"]
+        sched[mode] = pop.schedule()
+        pop.init(list(range(1, K + 1)))
+        stats, status = pop.train(tr, dv, E, etas, order=order)
+        out[mode] = (stats, status, [[pop.get_params(k, pl).cpu().numpy() for pl in range(3)] for k in range(K)])
+        pop.close()
+    assert not sched["0"]["persistent"]
+    assert out["0"][0].tobytes() == out["default"][0].tobytes(), (sched["default"], R, B, bn, alphas, C, K, cc)
+    assert np.array_equal(out["0"][1], out["default"][1])
+    for k in range(K):
+        for pl in range(3):
+            assert np.array_equal(out["0"][2][k][pl], out["default"][2][k][pl]), (k, pl, sched["default"])
+    print("schedule:", sched["default"])
+
+
 def test_persistent_loop_lost_dependency_ends_with_an_error(dev, monkeypatch):
     """The persistent step loop's waits are bounded: when a dependency never arrives (test hook: candidate 0's chain does not
     publish step 3) the launch ends by itself — the starved workgroups time out, set the abort word, everybody leaves — and
