@@ -253,6 +253,7 @@ def main():
                         "so `achieved` is a nominal rate for comparison, the loop itself is latency-bound, DESIGN.md 4a)")
         else:
             kernel = ("k_step (chain blocks of one group + sweep blocks of the other: dW, Adam, next-step forward)" if sched.get("groups", 2) > 1
+                      else "k_step_same (chain blocks + sweep blocks of the same candidates, units released per cell as the backward pass publishes dy)" if sched.get("groups") == -1
                       else "k_step (sweep of the whole population: dW, Adam, next-step forward; the chain runs in its own k_chain launch)")
         total_trained = total * a.steps
         # HBM traffic / MfmaUtil need rocprofv3 --pmc passes (separate runs, MI355X_MICROARCH.md): they are NOT measured in this

@@ -150,7 +150,8 @@ int mfas_population_set_profiling(mfas_population* pop, int32_t on);
  * timed: info[0] = 1 persistent step loop (k_persist, one launch per epoch) / 0 launch per phase (k_step / k_chain);
  * info[1] = feature units resident in registers; info[2] = their workgroups; info[3] = units per resident workgroup;
  * info[4] = 1 when the resident lean chain owns OUT/HEAD; info[5] = 1 lean chain (R <= 16); info[6] = candidate groups of the
- * fused launch-per-phase schedule (1 = chain and sweep back to back); info[7] = candidates. */
+ * launch-per-phase schedule (2 = fused A/B launches, 1 = chain and sweep back to back, -1 = one launch per step holding the chain
+ * AND the sweep of the same candidates, released cell by cell through per-cell flags); info[7] = candidates. */
 int mfas_population_schedule(const mfas_population* pop, int32_t info[8]);
 
 /* (new) Streaming ceiling of this device for the sweep's access pattern: three planes of `bytes_per_plane` are

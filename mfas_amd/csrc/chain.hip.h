@@ -23,6 +23,9 @@ struct ChainArgs {
     DevStats* stats;
     int32_t* status;
     const float* pos_w;   // loss_mode 1: per-class positive weights
+    // same-group fused launch (k_step_same): publish cellflag[candidate][i] = flag_target as soon as dy_i (slot 4: dlogits) is out
+    uint32_t* cellflag;
+    uint32_t flag_target, _padf;
     int32_t yf_reduced, _padr;   // the sweep already reduced the partial sums into the step buffer's yf area (sweep.hip.h)
     float* logits_out;           // train-mode FORWARD ONLY (mfas_population_forward_train): write the batch's logits (nvalid x C)
                                  // after the head and stop — batch-statistics BN (running stats updated), dropout stream of `gstep`
@@ -616,7 +619,6 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
             W[o] = w; Mv[o] = m; Vv[o] = v;
         }
     }
-
     if (pf) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) wa[u] = wb[u];
@@ -743,6 +745,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
             W[o] = w; Mv[o] = m; Vv[o] = v;
         }
         if (g.alphas) lds_barrier();
+        if constexpr (COH) {
+            if (a.cellflag) {   // dy_i (and, with alphas, this step's scales) are out: cell i's sweep units of this launch may start
+                wg_publish_barrier();
+                if (tid == 0) __hip_atomic_store(a.cellflag + (size_t)cgidx * CELLFLAG_STRIDE + i, a.flag_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     CT_STAMP(12);
 }

@@ -147,6 +147,20 @@ __device__ __forceinline__ float row_ce(const float* x, int C, int lab) {
     return -(x[lab] - mx - logf(se));
 }
 
+__device__ __forceinline__ uint32_t ld_u32_relaxed(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every storing wave has drained its (write-through) stores when the barrier releases; then ONE lane signals
+__device__ __forceinline__ void wg_publish_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+// Per-(candidate, cell) "dy is out" flags of the same-group fused launch (k_step_same): [candidate][8] uint32, slot i < 4: dy_i of
+// cell i (published after backward cell i, i.e. when the chain no longer reads W_out_{i+1}^T / Wc^T either); the value is the
+// global step index + 1 (monotonic over a train() call)
+#define CELLFLAG_STRIDE 8
+#define CELLFLAG_SPIN_LIMIT (1u << 21)
+
 // sum over the 4 lane groups that share (lane & 15): column reduction of an MFMA D block
 // (gfx950 row swaps instead of two ds_bpermute round trips through the LDS crossbar: v_permlane16_swap exchanges the odd
 // rows of one operand with the even rows of the other, v_permlane32_swap the wave halves; with both operands = x the two

@@ -66,6 +66,19 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
     else sweep_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, sweep_step_of(a.sa), bid - a.nchain - a.sa.ntap, lds);
 }
 
+// Same-group fused launch (small populations with the general chain, R >= 128): chain blocks AND sweep blocks of the SAME
+// candidates in one launch; a sweep unit waits for its cell's dy (per-cell flags published by the chain as the backward pass
+// reaches the cell) instead of for a kernel boundary, so the sweeps of cells L-1 .. 1 overlap the rest of the backward pass.
+// The work list is ordered last cell first; chain blocks have the lowest block indices (dispatched first).
+template <int MB, bool NT>
+__global__ void __launch_bounds__(STEP_THREADS, 4) k_step_same(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int bid = (int)blockIdx.x;
+    if (bid < a.nchain) {
+        chain_body<MB, false, true>(a.ca, chain_step_of(a.ca), bid, lds);
+    } else sweep_body<MB, NT, SweepU<MB, 4>::v, true>(a.sa, sweep_step_of(a.sa), bid - a.nchain, lds);
+}
+
 // Standalone chain launch (small populations: chain and sweep run back to back, so the chain's latency is on the
 // critical path): full register budget, next-product weight tiles prefetched into registers.
 template <int MB, bool LEAN>
@@ -129,6 +142,8 @@ struct mfas_population {
     uint32_t* d_red_cnt = nullptr;  // reduce-in-sweep arrival counters [K][4] (small populations, general chain)
     bool red_in_sweep = false;
     bool res_wide = false;          // resident units of more than 512 columns (16-bit staging): f32 tables cannot be trained
+    bool same_group = false;        // one launch per step: chain blocks + sweep blocks of the same candidates, per-cell dy flags (k_step_same)
+    uint32_t* d_cellflag = nullptr; // [K][CELLFLAG_STRIDE]
     bool res_chain = false;         // resident lean chain: owns OUT / HEAD + vector block on chip; persistent units = feature units only
     int res_nu = 1;                 // resident units per workgroup (2: a workgroup serves units of two candidates)
     int nres_wg = 0;                // resident workgroups = ceil(nres / res_nu)
@@ -512,6 +527,18 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                 return MFAS_RETRY_NO_PERSIST;
             }
         }
+        // same-group fused launch (k_step_same): general chain, one group, R >= 128 (no tap-major units), launch-per-phase
+        {
+            const int sgenv = getenv("MFAS_SAME_GROUP") ? atoi(getenv("MFAS_SAME_GROUP")) : -1;     // 0: never, 2: whatever the size (A/B runs)
+            // measured (MI355X, conf 4, B=16): pays while the population's W/m/v stream is <= ~260 MB per step — R=128: 1 / 3 / 6 / 8 / 12
+            // candidates 56 / 65 / 76 / 81 / 91 -> 50 / 54 / 63 / 70 / 88 us per step (16: equal); R=64: 6 / 12 / 16: 52 / 61 / 64 -> 45 / 55 / 61
+            // (24: 74 -> 79); R=32: 6 / 12 / 32: 45 / 54 / 68 -> 36 / 41 / 60 (64: 85 -> 90)
+            double state_bytes = 0;
+            for (const SegDesc& d : p->descs) state_bytes += 24.0 * d.cc * d.rows_p;
+            const bool two_forced = getenv("MFAS_GROUPS") && atoi(getenv("MFAS_GROUPS")) >= 2;      // (tests: the two-group fused schedule)
+            p->same_group = !p->persist && !p->lean_chain && g.MB <= 2 && (state_bytes <= 260e6 || sgenv == 2) && sgenv != 0 && !two_forced;
+        }
+        if (p->same_group) ngroups = 1;
         int split = K;
         if (ngroups == 2) {
             double tot = 0, run = 0;
@@ -535,7 +562,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             // small R (1, 2 or 4 row blocks): feature segments are regrouped tap-major (sweep_tap_body)
             std::vector<SegDesc> sorted;
             std::vector<TapDesc> taps;
-            const bool tap_major = (g.nrb == 1 || g.nrb == 2 || g.nrb == 4) && !getenv("MFAS_NO_TAP_MAJOR") && !p->persist;
+            const bool tap_major = (g.nrb == 1 || g.nrb == 2 || g.nrb == 4) && !getenv("MFAS_NO_TAP_MAJOR") && !p->persist && !p->same_group;
             if (tap_major) {
                 const int per_wg = STEP_NW / g.nrb;
                 std::vector<const SegDesc*> feat;
@@ -568,6 +595,12 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                 sorted = all;
             }
             std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) { return x.cc * x.rows_p > y.cc * y.rows_p; });
+            if (p->same_group)   // the order the chain releases the units in
+                std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) {
+                    // (the slot each unit waits for: feature units of cell i -> i, OUT_i -> i - 1, HEAD -> the last cell; highest slot first)
+                    auto slot = [](const SegDesc& d) { return d.kind == KIND_HEAD ? MFAS_MAX_CELLS : (d.kind == KIND_OUT ? d.cell - 1 : d.cell); };
+                    return slot(x) > slot(y);
+                });
             gr.ndesc = (int)sorted.size();
             gr.ntap = (int)taps.size();
             CREATE_CHK(hipMalloc(&gr.d_descs, sizeof(SegDesc) * std::max<size_t>(sorted.size(), 1)));
@@ -586,6 +619,11 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     if (p->red_in_sweep) {
         CREATE_CHK(hipMalloc(&p->d_red_cnt, sizeof(uint32_t) * K * MFAS_MAX_CELLS));
         CREATE_CHK(hipMemset(p->d_red_cnt, 0, sizeof(uint32_t) * K * MFAS_MAX_CELLS));
+    }
+    if (p->same_group) {
+        CREATE_CHK(hipMalloc(&p->d_cellflag, sizeof(uint32_t) * K * CELLFLAG_STRIDE));
+        CREATE_CHK(set_lds((k_step_same<1, false>), p->lds_step)); CREATE_CHK(set_lds((k_step_same<1, true>), p->lds_step));
+        CREATE_CHK(set_lds((k_step_same<2, false>), p->lds_step)); CREATE_CHK(set_lds((k_step_same<2, true>), p->lds_step));
     }
     CREATE_CHK(hipMemsetAsync(p->plane, 0, sizeof(float) * 3 * (size_t)p->plane_stride, p->stream));
     CREATE_CHK(hipMemsetAsync(p->wt, 0, sizeof(float) * (size_t)std::max<int64_t>(p->wt_size, 64), p->stream));
@@ -657,6 +695,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
     hipFree(p->d_seeds); hipFree(p->d_corr); hipFree(p->d_posw);
     hipFree(p->d_red_cnt);
+    hipFree(p->d_cellflag);
     hipFree(p->d_sync); hipFree(p->d_need); hipFree(p->d_scal); hipFree(p->d_trace); hipFree(p->d_pdescs);
     delete p;
 }
@@ -797,6 +836,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     st.sa.red_cnt = p->red_in_sweep ? p->d_red_cnt : nullptr;
     st.ca.yf_reduced = p->red_in_sweep ? 1 : 0;
     if (p->red_in_sweep) HIPCHK(hipMemsetAsync(p->d_red_cnt, 0, sizeof(uint32_t) * K * MFAS_MAX_CELLS, p->stream));
+    if (p->same_group) HIPCHK(hipMemsetAsync(p->d_cellflag, 0, sizeof(uint32_t) * K * CELLFLAG_STRIDE, p->stream));
 
     const int elt = train->dtype == MFAS_DT_F32 ? 4 : 2;
     p->prof_launches = 0; p->prof_ms = 0.0; p->prof_bytes = 0.0;
@@ -852,6 +892,16 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
 #undef CHAIN_LAUNCH
             return;
         }
+        if (p->same_group && gs >= 0 && gc == gs && upd) {   // chain(g, t) and sweep(g, t) in ONE launch, per-cell flags
+            st.sa.cellflag = p->d_cellflag; st.ca.cellflag = p->d_cellflag;
+            st.sa.flag_target = st.ca.flag_target = (uint32_t)st.ca.gstep + 1u;
+            st.sa.flag_status = p->d_status;
+            if (g.MB == 1) { if (p->nontemporal) hipLaunchKernelGGL((k_step_same<1, true>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st);
+                             else hipLaunchKernelGGL((k_step_same<1, false>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st); }
+            else { if (p->nontemporal) hipLaunchKernelGGL((k_step_same<2, true>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st);
+                   else hipLaunchKernelGGL((k_step_same<2, false>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st); }
+            st.sa.cellflag = nullptr; st.ca.cellflag = nullptr;
+        } else {
 #define STEP_LAUNCH(M, T, W, F) hipLaunchKernelGGL((k_step<M, T, W, F>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
 #define STEP_PICK(M, W) do { if (p->nontemporal) { if (p->lean_chain) STEP_LAUNCH(M, true, W, true); else STEP_LAUNCH(M, true, W, false); } \
                              else { if (p->lean_chain) STEP_LAUNCH(M, false, W, true); else STEP_LAUNCH(M, false, W, false); } } while (0)
@@ -864,6 +914,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         else { if (p->nontemporal) STEP_LAUNCH(4, true, 2, false); else STEP_LAUNCH(4, false, 2, false); }
 #undef STEP_PICK
 #undef STEP_LAUNCH
+        }
         if (prof) {
             hipEventRecord(p->ev[ev_used + 1], p->stream);
             ev_used += 2;
@@ -955,7 +1006,9 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             HIPCHK(persist_epoch(ep, T));
         } else {
         for (int gi = 0; gi < NG; ++gi) step(gi, 0, 1, ep, 0, -1, 0);   // prologue: forward sums of batch 0
-        if (NG == 1) {
+        if (NG == 1 && p->same_group) {
+            for (int64_t t = 0; t < T; ++t) step(0, 1, (t + 1 < T) ? 1 : 0, ep, t, 0, t);
+        } else if (NG == 1) {
             for (int64_t t = 0; t < T; ++t) {
                 step(-1, 0, 0, ep, 0, 0, t);
                 step(0, 1, (t + 1 < T) ? 1 : 0, ep, t, -1, 0);
@@ -1005,6 +1058,8 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     HIPCHK(hipGetLastError());
     for (uint32_t ab : aborts)
         if (ab) return fail(MFAS_EHIP, "persistent step loop: a workgroup timed out waiting for its dependency (launch aborted)");
+    for (int32_t sv : hstatus)
+        if (sv == 2) return fail(MFAS_EHIP, "same-group fused launch: a sweep unit timed out waiting for its cell's dy");
     if (p->d_trace && p->persist) {
         unsigned long long tr[256];
         if (hipMemcpy(tr, p->d_trace, sizeof(tr), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1190,7 +1245,7 @@ extern "C" int mfas_population_set_profiling(mfas_population* p, int32_t on) {
 extern "C" int mfas_population_schedule(const mfas_population* p, int32_t info[8]) {
     if (!p || !info) return fail(MFAS_EINVAL, "null");
     info[0] = p->persist ? 1 : 0; info[1] = p->nres; info[2] = p->nres_wg; info[3] = p->res_nu;
-    info[4] = p->res_chain ? 1 : 0; info[5] = p->lean_chain ? 1 : 0; info[6] = (int32_t)p->groups.size(); info[7] = p->K;
+    info[4] = p->res_chain ? 1 : 0; info[5] = p->lean_chain ? 1 : 0; info[6] = p->same_group ? -1 : (int32_t)p->groups.size(); info[7] = p->K;
     return MFAS_OK;
 }
 

@@ -53,10 +53,6 @@ struct PersistArgs {
 #define PERSIST_ROLL(sync, K) ((sync) + (size_t)(K) * PERSIST_SYNC_STRIDE + 32)   // workgroups that have started (own cache line)
 #define PERSIST_ABORT_NOT_RESIDENT 2u   // abort code of a failed roll call: nothing has been modified, the host may simply relaunch
 
-__device__ __forceinline__ uint32_t ld_u32_relaxed(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Workgroup-wide wait until *p >= target: lane 0 polls (relaxed, sc1), everyone else parks at the barrier.
 // Returns false when the launch is being aborted.  `ldsw` = one LDS word outside the bodies' LDS footprint.
 __device__ __forceinline__ bool wg_wait_ge(const uint32_t* p, uint32_t target, uint32_t* abortw, int* ldsw) {
@@ -77,12 +73,6 @@ __device__ __forceinline__ bool wg_wait_ge(const uint32_t* p, uint32_t target, u
     const int ok = *ldsw;
     __syncthreads();
     return ok != 0;
-}
-
-// every storing wave has drained its (write-through) stores when the barrier releases; then ONE lane signals
-__device__ __forceinline__ void wg_publish_barrier() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -107,6 +107,11 @@ struct SweepArgs {
     // cell to finish sums the cell's partial slabs (fixed order = the chain's phase 0) into the step buffer's yf area, so the
     // next launch's chain reads 1 (or 2, alphas) reduced slab per cell instead of pulling every partial through its one CU
     uint32_t* red_cnt;
+    // same-group fused launch: this unit's dy is published by a chain workgroup of the SAME launch (cellflag != nullptr): wait
+    // for cellflag[candidate][cell] >= flag_target before reading it; flag_status[] receives an abort mark on timeout
+    const uint32_t* cellflag;
+    uint32_t flag_target;
+    int32_t* flag_status;
 };
 
 // what changes from one train step to the next (k_step takes it from the launch arguments, the persistent loop computes it)
@@ -149,21 +154,43 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
     const int64_t sbo = cd.step_off;   // this candidate's step buffers inside a.stepbuf
     const bool red = a.red_cnt != nullptr;
 
+    if (upd && feat) {
+        const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
+        stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, st.pos_t, st.base_t, st.nvalid_t, Bp, tid, STEP_THREADS);
+    }
+    if (fwd) {
+        const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
+        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, st.pos_n, st.base_n, st.nvalid_n, Bp, tid, STEP_THREADS);
+    }
+    if constexpr (COH) {
+        if (upd && a.cellflag) {   // the table rows above are in flight while the chain of this launch gets to this cell's dy
+            __shared__ int s_go;
+            if (tid == 0) {
+                // feature units of cell i need dy_i; OUT_i (the prev-out block of cell i) and HEAD also OVERWRITE weights the chain of
+                // this launch still reads in its backward pass (W_out_i^T for d out_{i-1}, Wc^T for d out_{L-1}): they wait until
+                // the chain is past that product, i.e. for dy_{i-1} / dy_{L-1}
+                const int slot = d.kind == KIND_HEAD ? cd.L - 1 : (d.kind == KIND_OUT ? d.cell - 1 : d.cell);
+                const uint32_t* f = a.cellflag + (size_t)cd.gidx * CELLFLAG_STRIDE + slot;
+                uint32_t spins = 0;
+                int go = 1;
+                while (ld_u32_relaxed(f) < a.flag_target) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > CELLFLAG_SPIN_LIMIT) { go = 0; a.flag_status[cd.gidx] = 2; break; }
+                }
+                s_go = go;
+            }
+            __syncthreads();
+            if (!s_go) return;
+        }
+    }
     if (upd) {
-        if (feat) {
-            const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
-            stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, st.pos_t, st.base_t, st.nvalid_t, Bp, tid, STEP_THREADS);
-        } else {
+        if (!feat) {
             const int xcell = d.kind == KIND_OUT ? d.cell - 1 : cd.L - 1;
             stage_f32<COH>(xt, ST, a.stepbuf, sbo + a.g.sb_xo + (int64_t)xcell * Bp * a.g.Rp + d.k0, a.g.Rp, cc, Bp, tid, STEP_THREADS);
         }
         // dy of this unit's rows: columns [16*rb0, 16*rb0 + rows_p) of the segment's dy (row stride = the segment's padded rows)
         const int64_t dsrc = d.kind == KIND_HEAD ? sbo + a.g.sb_dlog : sbo + a.g.sb_dy + (int64_t)d.cell * Bp * a.g.Rp;
         stage_f32<COH>(dyl, SD, a.stepbuf, dsrc + d.rb0 * 16, d.seg_nrb * 16, rows_p, Bp, tid, STEP_THREADS);
-    }
-    if (fwd) {
-        const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
-        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, st.pos_n, st.base_n, st.nvalid_n, Bp, tid, STEP_THREADS);
     }
     __syncthreads();
 

@@ -477,6 +477,9 @@ def test_full_size_properties(dev):
     # itself, and the persistent step loop in its streaming form (one launch per epoch, per-candidate flags): same bits
     assert run(8, 2, seeds, env=(("MFAS_NO_RED_IN_SWEEP", "1"),)).tobytes() == a.tobytes(), "reduce-in-sweep changes results"
     assert run(8, 1, seeds, env=(("MFAS_PERSIST", "1"),)).tobytes() == a.tobytes(), "persistent (streaming) step loop differs"
+    # (1c) `b` ran the same-group fused launch (one launch per step, units released per cell: the default at this size); the plain
+    # two-launch schedule (k_chain, then the sweep) must give the same bits as well
+    assert run(8, 1, seeds, env=(("MFAS_SAME_GROUP", "0"),)).tobytes() == a.tobytes(), "same-group fused launch differs"
     c = run(3, 1, [5, 2, 7])
     for j, s_ in enumerate([5, 2, 7]):
         assert c[j].tobytes() == a[s_].tobytes(), "population-dependent result"   # (2) + (3)
@@ -585,6 +588,52 @@ def test_persistent_schedule_fuzz_bit_identical(dev, seed):
         for pl in range(3):
             assert np.array_equal(out["0"][2][k][pl], out["default"][2][k][pl]), (k, pl, sched["default"])
     print("schedule:", sched["default"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_same_group_launch_fuzz_bit_identical(dev, seed):
+    """Random small populations with the general chain (R = 32 / 64 / 128): the same-group fused launch — chain and sweep of the
+    same candidates in ONE launch per step, sweep units released cell by cell by flags the backward pass publishes, OUT / HEAD
+    units held back until the chain no longer reads the weights they overwrite — against the two-launch schedule: bit for bit."""
+    import os
+    from mfas_amd import FeatureTable, Hyper, Population
+    rng = np.random.default_rng(2000 + seed)
+    R = int(rng.choice([32, 64, 128]))
+    B = int(rng.choice([5, 16, 20, 32]))
+    bn = bool(rng.integers(0, 2))
+    drpt = float(rng.choice([0.0, 0.5])) if bn else 0.5
+    alphas = bool(rng.integers(0, 2))
+    C = int(rng.choice([60, 23]))
+    K = int(rng.choice([1, 2, 5, 8]))
+    dtype = [torch.bfloat16, torch.float32][int(rng.integers(0, 2))]
+    N = int(rng.integers(3 * B + 2, 8 * B))
+    if N % B == 1:
+        N += 1
+    hp = Hyper(R=R, C=C, B=B, bn=bn, drpt=drpt, alphas=alphas)
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in rng.integers(1, 5, K)]
+    tr = FeatureTable.synthetic(N, 1 + seed, dev, dtype, snr=0.5, C=C)
+    dv = FeatureTable.synthetic(2 * B + 3, 100 + seed, dev, dtype, snr=0.5, C=C)
+    nb = -(-N // B)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, 2 * nb)
+    out, sched = {}, {}
+    for mode in ("two-launch", "default"):
+        if mode == "two-launch":
+            os.environ["MFAS_SAME_GROUP"] = "0"
+        try:
+            pop = Population(hp, confs, dev, drop_seeds=list(range(3, 3 + K)), chunk_cols=128)
+        finally:
+            os.environ.pop("MFAS_SAME_GROUP", None)
+        sched[mode] = pop.schedule()
+        pop.init(list(range(1, K + 1)))
+        stats, status = pop.train(tr, dv, 2, etas)
+        out[mode] = (stats, status, [[pop.get_params(k, pl).cpu().numpy() for pl in range(3)] for k in range(K)])
+        pop.close()
+    assert sched["default"]["groups"] == -1 and sched["two-launch"]["groups"] in (1, 2), sched     # (8 candidates: fused A/B launches)
+    assert out["two-launch"][0].tobytes() == out["default"][0].tobytes(), (R, B, bn, alphas, C, K)
+    assert np.array_equal(out["two-launch"][1], out["default"][1])
+    for k in range(K):
+        for pl in range(3):
+            assert np.array_equal(out["two-launch"][2][k][pl], out["default"][2][k][pl]), (k, pl)
 
 
 def test_persistent_loop_lost_dependency_ends_with_an_error(dev, monkeypatch):
