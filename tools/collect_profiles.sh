@@ -11,6 +11,10 @@ if [ "$part" = sweep ] || [ "$part" = all ]; then
     timeout 400 python tools/popsweep.py 16 16 1 10 6,16,28
     timeout 400 python tools/popsweep.py 64 16 1 10 6,16,32
     timeout 600 python tools/popsweep.py 128 16 1 10 3,6,8,12,16,24,32; } 2>&1 | grep -v amdgpu > $out/popsweep.log
+  { timeout 600 python tools/popsweep.py 128 16 1 10 1,3,6,8,12,16,24,32
+    timeout 400 python tools/popsweep.py 64 16 1 10 6,16,32
+    timeout 400 python tools/popsweep.py 32 20 0 10 6,16,32
+    MFAS_SAME_GROUP=0 timeout 400 python tools/popsweep.py 128 16 1 10 1,3,6,8; } 2>&1 | grep -v amdgpu > $out/popsweep_general.log
   { for cfg in "16 20 0 6 2 2000 800 cc=256" "16 16 1 9 2 2000 800 cc=128" "16 20 0 7 2 2000 800 mixed alphas cc=512"; do
       timeout 300 python tools/persist_check.py $cfg 2>&1 | grep -E "cand/s|IDENT|MISMATCH|differ"; done; } > $out/persist_check.log
   MFAS_PERSIST_TRACE=1 timeout 300 python tools/persist_check.py 16 20 0 6 2 2000 800 cc=256 2>&1 | grep -v amdgpu > $out/persist_trace_k6_r16.log
