@@ -341,16 +341,17 @@ def initial_flat_params(args, conf, hp=None) -> torch.Tensor:
     return flat
 
 
-ROUNDS_MIN_COST = 34 * 127_000     # parameter-cost units (population.candidate_cost) of ~34 conf-4-sized R=16 candidates
+ROUNDS_MIN_COST = 29 * 127_000     # parameter-cost units (population.candidate_cost) of ~29 conf-4-sized R=16 candidates
 
 
 def _plan_rounds(hp, confs, mine, cost_of, device, seed_base, chunk_cols):
-    """The rank's share as ONE population, or as TWO trained one after the other when the share is too large for the
-    persistent resident schedule (parameters in registers, one launch per epoch: <= ~28 conf-4-sized candidates at R <= 16)
-    but its halves fit: measured at R=16, B=20 on MI355X, 36...56 candidates take 47-55 us per train step with launches and
-    2 x 20 us as two resident rounds (29...33: equal, left alone).  Candidates are independent and carry their own seeds, so
-    the split changes nothing but the column-chunk summation order (as any change of population size does).
-    Yields (indices, Population)."""
+    """The rank's share as ONE population, or as several trained one after the other when the share is too large for the
+    persistent resident schedule (parameters in registers, one launch per epoch: <= ~28 conf-4-sized candidates at R <= 16):
+    every round but the last is filled to the resident capacity (a resident round costs 15-21 us per train step almost
+    independently of its size), found by bisection on the engine's own layout decision.  Measured at R=16, B=20 on MI355X:
+    29...56 candidates take 38-55 us per train step with launches, 36-41 us as two resident rounds.  Candidates are
+    independent and carry their own seeds, so the split changes nothing but the column-chunk summation order (as any change
+    of population size does).  Yields (indices, Population)."""
     if not mine:
         return
 
@@ -363,18 +364,37 @@ def _plan_rounds(hp, confs, mine, cost_of, device, seed_base, chunk_cols):
             or sum(cost_of[i] for i in mine) < ROUNDS_MIN_COST or os.environ.get("MFAS_NO_ROUNDS")):
         yield mine, full
         return
-    half = popmod.assign([cost_of[i] for i in mine], 2)
-    groups = [[i for i, h in zip(mine, half) if h == r] for r in (0, 1)]
-    pops = [make(g) for g in groups]
-    if all(p.schedule()["persistent"] for p in pops):
-        full.close()
-        for g, p in zip(groups, pops):
-            yield g, p
+    rounds, rest = [], list(mine)
+    while rest and len(rounds) < 4:
+        whole = make(rest)
+        if whole.schedule()["persistent"]:
+            rounds.append((rest, whole))
+            rest = []
+            break
+        whole.close()
+        lo, hi, best = 1, len(rest) - 1, None          # largest resident prefix of `rest`
+        while lo <= hi:
+            mid = (lo + hi) // 2
+            p = make(rest[:mid])
+            if p.schedule()["persistent"]:
+                if best is not None:
+                    best[1].close()
+                best, lo = (mid, p), mid + 1
+            else:
+                p.close()
+                hi = mid - 1
+        if best is None:
+            break
+        rounds.append((rest[:best[0]], best[1]))
+        rest = rest[best[0]:]
+    if rest:                                            # no resident layout for what is left: one launch-per-phase population
+        for _, p in rounds:
+            p.close()
+        yield mine, full
         return
-    for p in pops:
-        p.close()
-    yield mine, full
-
+    full.close()
+    for g, p in rounds:
+        yield g, p
 
 
 def train_sampled_models(sampled_configurations, searchable_type, dataloaders, args, device,

@@ -383,5 +383,5 @@ def test_large_share_trains_in_two_resident_rounds(dev, monkeypatch):
     two, sched_two = run()
     assert len(sched_one) == 1 and not sched_one[0]["persistent"] and sched_one[0]["candidates"] == 30
     assert len(sched_two) == 2 and all(s["persistent"] and s["resident_units"] > 0 for s in sched_two)
-    assert sorted(s["candidates"] for s in sched_two) == [15, 15]
+    assert sum(s["candidates"] for s in sched_two) == 30 and sched_two[0]["candidates"] >= 15      # first round filled to capacity
     assert one == two
