@@ -342,6 +342,7 @@ def initial_flat_params(args, conf, hp=None) -> torch.Tensor:
 
 
 ROUNDS_MIN_COST = 29 * 127_000     # parameter-cost units (population.candidate_cost) of ~29 conf-4-sized R=16 candidates
+_ROUND_CAPACITY = {}               # (geometry) -> candidates the resident schedule held the last time it was probed
 
 
 def _plan_rounds(hp, confs, mine, cost_of, device, seed_base, chunk_cols):
@@ -364,6 +365,7 @@ def _plan_rounds(hp, confs, mine, cost_of, device, seed_base, chunk_cols):
             or sum(cost_of[i] for i in mine) < ROUNDS_MIN_COST or os.environ.get("MFAS_NO_ROUNDS")):
         yield mine, full
         return
+    key = (hp.R, hp.B, hp.C, bool(hp.bn), bool(hp.alphas), hp.tap_bits, chunk_cols, max(len(confs[i]) for i in mine))
     rounds, rest = [], list(mine)
     while rest and len(rounds) < 4:
         whole = make(rest)
@@ -372,25 +374,36 @@ def _plan_rounds(hp, confs, mine, cost_of, device, seed_base, chunk_cols):
             rest = []
             break
         whole.close()
-        lo, hi, best = 1, len(rest) - 1, None          # largest resident prefix of `rest`
+        # largest resident prefix of `rest`: bisection, started at the capacity the last call with this geometry found
+        lo, hi, best = 1, len(rest) - 1, None
+        cached = _ROUND_CAPACITY.get(key)
+        nxt = cached
         while lo <= hi:
-            mid = (lo + hi) // 2
+            mid = nxt if nxt is not None and lo <= nxt <= hi else (lo + hi) // 2
+            nxt = None
             p = make(rest[:mid])
             if p.schedule()["persistent"]:
                 if best is not None:
                     best[1].close()
                 best, lo = (mid, p), mid + 1
+                if mid == cached:
+                    nxt = mid + 1          # the neighbour is expected to fail: two probes in the common case
             else:
                 p.close()
                 hi = mid - 1
         if best is None:
             break
+        if not rounds:
+            _ROUND_CAPACITY[key] = best[0]
+            nr = -(-len(rest) // best[0])
+            last = len(rest) - (nr - 1) * best[0]
+            # three or four rounds only pay when the last one is reasonably full (measured: 64 candidates as 28 + 28 + 8: 210 vs
+            # 234 cand/s with launches; 84 as 3 x 28: 255 vs 238)
+            if nr > 4 or (nr >= 3 and last < 0.6 * best[0]):
+                best[1].close()
+                break
         rounds.append((rest[:best[0]], best[1]))
         rest = rest[best[0]:]
-    # three or four rounds only pay when the last one is reasonably full (measured: 64 candidates as 28 + 28 + 8: 210 vs 234
-    # cand/s with launches; 84 as 3 x 28: 255 vs 238)
-    if len(rounds) >= 3 and len(rounds[-1][0]) < 0.6 * len(rounds[0][0]):
-        rest = list(mine)
     if rest:                                            # no resident layout for what is left: one launch-per-phase population
         for _, p in rounds:
             p.close()
