@@ -762,11 +762,16 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
 // the candidate record, address arithmetic for up to 32 row blocks and a global round trip for its weight tile.  Here:
 //   * everything a step needs from global memory (labels, vector block, EVERY product's weight tile, the sweep's partial
 //     sums) is requested at kernel entry — one memory latency for the whole chain;
-//   * wave 0 owns the single row block and runs all L cells forward (and later backward) back to back with no barrier:
-//     the activations of all cells stay in LDS (xo_l / dy_l [L][Bp][20]) together with the saved activations;
-//   * the other seven waves do the bulk work around it: partial-sum reduction, head / softmax, coalesced copies of
-//     out_i, dy_i and dlogits to the step buffers the sweep reads, statistics, head-bias Adam.
-// Arithmetic (operation order included) is that of chain_body.
+//   * the cells are ELEMENT-PARALLEL (round 2): wave w < 4*MB owns one element group of the 16 x 16 output block (batch-row
+//     quad w & 3 of row block w >> 2), one output element per lane; every wave recomputes the cell's tiny product (4 MFMAs)
+//     from out_{i-1} in LDS, finishes its element and keeps what the backward pass needs again (activation, x-hat, alpha
+//     difference, dropout keep-bits) in REGISTERS; one workgroup barrier per cell (three with BatchNorm, whose batch statistics
+//     cross the waves through 2 KB of LDS);
+//   * head / softmax, coalesced copies of out_i, dy_i and dlogits to the step buffers use all eight waves; everything that is
+//     not needed to publish dy — epoch statistics, bias / BatchNorm / alpha gradient sums and their Adam updates — is deferred
+//     to chain_lean_tail, which the resident persistent chain runs AFTER dy is out.
+// The arithmetic is that of chain_body except for the order in which bias / BatchNorm gradient sums are accumulated: the two
+// chain forms agree to rounding, not bit for bit; which one runs depends only on (R, C, B) — mfas_hip.hip, `lean_chain`.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 pick4(const f32x4 (&t)[MFAS_MAX_CELLS], int i) {
     switch (i) { case 0: return t[0]; case 1: return t[1]; case 2: return t[2]; default: return t[3]; }
