@@ -51,7 +51,9 @@ def parse_args(argv=None):
     p.add_argument("--random_search", action="store_true", default=False)
     p.add_argument("--engine_init", default="torch", choices=["torch", "device"])
     p.add_argument("--surrogate_device", default="cpu", choices=["cpu", "gpu"],
-                   help="where the 81k-parameter LSTM surrogate trains (the reference puts it on its training device)")
+                   help="where the 81k-parameter LSTM surrogate trains (the reference puts it on its training device).  gpu: train steps "
+                        "replayed as HIP graphs (0.87 ms instead of the CPU path's 1.9 ms per step; device GEMM numerics, so sampled "
+                        "configurations may differ from the CPU path's in the last digits)")
     p.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend under torchrun: nccl = RCCL over xGMI (one GPU per rank); gloo lets several ranks "
                         "share one GPU (tests)")

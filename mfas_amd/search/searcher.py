@@ -28,7 +28,8 @@ class ModelSearcher:
         a = self.args
         surrogate, s_crite = surrogate_dict["model"], surrogate_dict["criterion"]
         s_data = surr.SurrogateDataloader()
-        s_optim = op.Adam(surrogate.parameters(), lr=a.lr_surrogate)
+        on_gpu = torch.device(device).type == "cuda"      # (graph-replayed train steps need the capturable optimizer)
+        s_optim = op.Adam(surrogate.parameters(), lr=a.lr_surrogate, **({"capturable": True, "foreach": True} if on_gpu else {}))
         train_sampled_models = dataset_searchmethods["train_sampled_fun"]
         get_layer_confs = dataset_searchmethods["get_layer_confs"]
         temperature = a.initial_temperature

@@ -385,3 +385,35 @@ def test_large_share_trains_in_two_resident_rounds(dev, monkeypatch):
     assert len(sched_two) == 2 and all(s["persistent"] and s["resident_units"] > 0 for s in sched_two)
     assert sum(s["candidates"] for s in sched_two) == 30 and sched_two[0]["candidates"] >= 15      # first round filled to capacity
     assert one == two
+
+
+def test_graphed_surrogate_trainer_matches_cpu_eager(dev):
+    """--surrogate_device gpu: the surrogate's train steps replayed as HIP graphs (padded buckets + mask, LSTM cell written out,
+    capturable Adam) follow the CPU eager loop of the reference semantics: same parameters after ONE step (so the warm-up the capture
+    needs left no trace and the masked loss is MSELoss), same predictions to 1e-3 after 30 epochs over two buckets."""
+    import copy
+    import torch.optim as op
+    from mfas_amd.search import surrogate as S
+    rng = np.random.default_rng(5)
+    data = ([torch.from_numpy(rng.integers(0, 4, (L, n, 3)).astype(np.float32)) for L, n in ((2, 40), (4, 30))],
+            [torch.from_numpy(rng.random((n, 1)).astype(np.float32)) for n in (40, 30)])
+    torch.manual_seed(3)
+    cpu = S.SimpleRecurrentSurrogate(100, 3, 100)
+    gpu = copy.deepcopy(cpu).to(dev)
+    # the written-out cell is nn.LSTM's arithmetic
+    x = data[0][1]
+    torch.testing.assert_close(cpu.forward_unrolled(x), cpu(x), rtol=1e-5, atol=1e-6)
+    crit = torch.nn.MSELoss()
+    o_cpu = op.Adam(cpu.parameters(), lr=1e-3)
+    o_gpu = op.Adam(gpu.parameters(), lr=1e-3, capturable=True, foreach=True)
+    l_cpu = S.train_simple_surrogate(cpu, crit, o_cpu, ([data[0][0]], [data[1][0]]), 1, "cpu")
+    l_gpu = S.train_simple_surrogate(gpu, crit, o_gpu, ([data[0][0]], [data[1][0]]), 1, dev)
+    assert abs(l_cpu - l_gpu) < 1e-5
+    for (k, a), (_, b) in zip(cpu.named_parameters(), gpu.named_parameters()):
+        torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=0, atol=2e-5, msg=k)     # one Adam step = lr * sign-like update
+    assert int(o_gpu.state[next(iter(gpu.parameters()))]["step"].item()) == 1                    # the warm-up steps were undone
+    S.train_simple_surrogate(cpu, crit, o_cpu, data, 30, "cpu")
+    S.train_simple_surrogate(gpu, crit, o_gpu, data, 30, dev)
+    with torch.no_grad():
+        for xx in data[0]:
+            torch.testing.assert_close(gpu(xx.to(dev)).cpu(), cpu(xx), rtol=0, atol=1e-3)
