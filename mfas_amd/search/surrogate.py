@@ -160,8 +160,10 @@ class GraphedSurrogateTrainer:
         buckets = []
         for x, y in zip(*data_tensors):
             L, n = int(x.shape[0]), int(x.shape[1])
-            if n > self.cap:
-                raise ValueError(f"surrogate bucket of {n} configurations exceeds the graph capacity {self.cap}")
+            if n > self.cap:          # the training set outgrew the padded buffers: larger ones, graphs captured again
+                while self.cap < n:
+                    self.cap *= 2
+                self.graphs.clear()
             b = self._bucket(L)
             b["x"].zero_(); b["y"].zero_(); b["mask"].zero_()
             b["x"][:, :n].copy_(x.to(self.dev)); b["y"][:n].copy_(y.to(self.dev)); b["mask"][:n].fill_(1.0)

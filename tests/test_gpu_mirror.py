@@ -412,8 +412,11 @@ def test_graphed_surrogate_trainer_matches_cpu_eager(dev):
     for (k, a), (_, b) in zip(cpu.named_parameters(), gpu.named_parameters()):
         torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=0, atol=2e-5, msg=k)     # one Adam step = lr * sign-like update
     assert int(o_gpu.state[next(iter(gpu.parameters()))]["step"].item()) == 1                    # the warm-up steps were undone
+    gpu._graphed_trainer.cap = 32          # smaller than the 40-row bucket: the trainer must grow its buffers and capture again
+    gpu._graphed_trainer.graphs.clear()
     S.train_simple_surrogate(cpu, crit, o_cpu, data, 30, "cpu")
     S.train_simple_surrogate(gpu, crit, o_gpu, data, 30, dev)
+    assert gpu._graphed_trainer.cap == 64
     with torch.no_grad():
         for xx in data[0]:
             torch.testing.assert_close(gpu(xx.to(dev)).cpu(), cpu(xx), rtol=0, atol=1e-3)
