@@ -67,6 +67,10 @@ def main(argv=None):
     import mfas_amd as M
     from mfas_amd.search import NTUSearcher
     args = parse_args(argv)
+    # torch.optim's first optimizer construction imports torch._dynamo (0.6-0.7 s): let that happen while the tables are built
+    import threading
+    warm = threading.Thread(target=lambda: __import__("torch._dynamo"), daemon=True)
+    warm.start()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local = local % max(torch.cuda.device_count(), 1)
@@ -89,6 +93,7 @@ def main(argv=None):
     else:
         tables = {s: M.FeatureTable.load(args.featuredir, s, device) for s in ("train", "dev")}
     searcher = NTUSearcher(args, device, tables)
+    warm.join()
     rank0 = int(os.environ.get("RANK", "0")) == 0
     if rank0:
         print("MFAS for NTU Started!!!!")
