@@ -318,11 +318,14 @@ def initial_flat_params(args, conf, hp=None) -> torch.Tensor:
         shape, off = where[key]
         return flat[off:off + int(np.prod(shape))].view(shape)
 
+    kgain = math.sqrt(2.0 / (1 + math.sqrt(5) ** 2))      # init.calculate_gain('leaky_relu', sqrt(5)), as nn.Linear.reset_parameters
+
     def linear(wkey, bkey):
         w, b = view(wkey), view(bkey)
-        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
-        bound = 1.0 / math.sqrt(w.shape[1]) if w.shape[1] > 0 else 0.0
-        nn.init.uniform_(b, -bound, bound)
+        fan_in = w.shape[1]
+        w.uniform_(-(math.sqrt(3.0) * (kgain / math.sqrt(fan_in))), math.sqrt(3.0) * (kgain / math.sqrt(fan_in)))   # kaiming_uniform_'s bound, same expression
+        bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+        b.uniform_(-bound, bound)
 
     with torch.no_grad():
         for i, c in enumerate(conf):
@@ -341,7 +344,7 @@ def initial_flat_params(args, conf, hp=None) -> torch.Tensor:
     return flat
 
 
-ROUNDS_MIN_COST = 29 * 127_000     # parameter-cost units (population.candidate_cost) of ~29 conf-4-sized R=16 candidates
+ROUNDS_MIN_CANDIDATES = 16         # (a share that does not fit the resident schedule has at least ~29 conf-4-sized candidates, or ~50 shallow ones)
 _ROUND_CAPACITY = {}               # (geometry) -> candidates the resident schedule held the last time it was probed
 
 
@@ -361,8 +364,7 @@ def _plan_rounds(hp, confs, mine, cost_of, device, seed_base, chunk_cols):
                           chunk_cols=chunk_cols)
 
     full = make(mine)
-    if (full.schedule()["persistent"] or hp.R > 16 or len(mine) < 4
-            or sum(cost_of[i] for i in mine) < ROUNDS_MIN_COST or os.environ.get("MFAS_NO_ROUNDS")):
+    if (full.schedule()["persistent"] or hp.R > 16 or len(mine) < ROUNDS_MIN_CANDIDATES or os.environ.get("MFAS_NO_ROUNDS")):
         yield mine, full
         return
     key = (hp.R, hp.B, hp.C, bool(hp.bn), bool(hp.alphas), hp.tap_bits, chunk_cols, max(len(confs[i]) for i in mine))
@@ -475,6 +477,11 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
         elif getattr(args, "engine_init", "torch") == "device":
             pop.init([(seed_base + 2 + i) & 0x7FFFFFFF for i in group])
         else:
+            # (the random fills below are tiny: with every host core in torch's pool their fork/join dominates — 6 ms instead of
+            #  0.7 ms per candidate on a 256-thread host; the values do not depend on the thread count)
+            nthreads = torch.get_num_threads()
+            if nthreads > 4:
+                torch.set_num_threads(4)
             for j, i in enumerate(group):
                 with torch.random.fork_rng(devices=[]):
                     torch.manual_seed(seed_base + 2 + i)   # world-size independent per-candidate stream
@@ -486,6 +493,8 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
                     else:   # same numbers, without the module objects (initial_flat_params)
                         flat0 = initial_flat_params(args, confs[i], hp)
                 pop.set_params(j, flat0)
+            if nthreads > 4:
+                torch.set_num_threads(nthreads)
         if getattr(args, "verbose", False):
             print("Now training: ")
             for i in group:

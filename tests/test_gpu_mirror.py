@@ -365,7 +365,6 @@ def test_large_share_trains_in_two_resident_rounds(dev, monkeypatch):
     from mfas_amd import ntu_searchable as NS
     monkeypatch.setenv("MFAS_NO_TAP_MAJOR", "1")       # per-segment units in both schedules
     rng = np.random.default_rng(3)
-    monkeypatch.setattr(NS, "ROUNDS_MIN_COST", 0)      # (the default only splits shares of >= ~34 conf-4-sized candidates)
     confs = [np.stack([rng.integers(0, 4, 4), rng.integers(0, 4, 4), rng.integers(0, 2, 4)], 1) for _ in range(30)]
     ttr, tdv = O.synth_table(400, 41, snr=0.5), O.synth_table(200, 42, snr=0.5)
     ld = loaders(ttr, tdv, dev, 20, dtype=torch.bfloat16)
