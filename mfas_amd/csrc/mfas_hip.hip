@@ -267,14 +267,15 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     };
     auto res_fits = [&](int cc, int nu, int64_t units) {
         return (cc <= 128 * PERSIST_NTR || (hp->tap_bits == 16 && nu == 1 && cc <= 128 * PERSIST_NTR16)) &&
-               res_lds(cc, nu) <= 160 * 1024 && K + (units + nu - 1) / nu + 1 <= p->n_cus;
+               res_lds(cc, nu) <= 160 * 1024 && K + (units + nu - 1) / nu + (lean_ok_early ? 0 : 1) <= p->n_cus;   // (+1: a streaming workgroup for OUT / HEAD when the chain does not own them)
     };
     int target = chunk_cols;
     int plan_nu = 1;
     if (plan_res && target <= 0) {
         // smallest units first (fewest tiles per wave on the critical path); two units per workgroup before 1024-column units
         // (measured: 16 candidates, 1024-column units: 34.8 us per step)
-        const int opts[6][2] = {{128, 1}, {256, 1}, {512, 1}, {256, 2}, {512, 2}, {1024, 1}};
+        // (two 256-column units per workgroup before one 512-column unit: 9..15 candidates 15.7-16.2 vs 18.0-18.7 us per step)
+        const int opts[6][2] = {{128, 1}, {256, 1}, {256, 2}, {512, 1}, {512, 2}, {1024, 1}};
         int pick = -1;
         for (int o = 0; o < 6 && pick < 0; ++o)
             if (res_fits(opts[o][0], opts[o][1], count_feat_units(opts[o][0]))) pick = o;
