@@ -154,6 +154,12 @@ def test_cli_entry_points_and_table_io(dev, tmp_path):
                                      "--batchnorm", "--no-verbose", "--engine_init", "device"])
     confs, accs, _ = data.get_k_best(3)
     assert len(confs) == 3 and all(0.0 <= a <= 1.0 for a in accs)
+    # the same search with the surrogate's train steps replayed as HIP graphs on the device
+    data = main_searchable_ntu.main(["--synthetic", "640", "320", "--epochs", "1", "--search_iterations", "1",
+                                     "--max_fusions", "2", "--num_samples", "4", "--epochs_surrogate", "3",
+                                     "--no-verbose", "--surrogate_device", "gpu"])
+    confs, accs, _ = data.get_k_best(3)
+    assert len(confs) == 3 and all(0.0 <= a <= 1.0 for a in accs)
     acc = main_found_ntu.main(["--synthetic", "640", "320", "320", "--conf", "4", "--inner_representation_size", "32",
                                "--batchnorm", "--epochs", "2", "--batchsize", "16", "--no-verbose"])
     assert 0.0 <= float(acc) <= 1.0
