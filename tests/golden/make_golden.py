@@ -716,23 +716,33 @@ class ShuffleLoader(ListLoader):
             yield {"rgb": rgb, "ske": ske, "label": self.t["label"][sl]}
 
 
+G15_DEFAULT_SNR = 0.12         # what bench.py runs (synth_table snr 0.12); the committed fixture's meta[2] must equal it
+G15_DEFAULT_NS = 64
+
+
 def g15():
     """BASELINE configs[1] exactly as bench.py runs it, through the unchanged reference: conf 4, R=128, --batchnorm,
     drpt 0.5, B=16, shuffled train order, E=10, N_train=10,000, N_dev=5,600, bf16-rounded taps
     (synth_table(N, seed, snr=G15_SNR, quant='bf16')), params = init_params(conf, hp, 3000 + 10*seed),
-    torch.manual_seed(300 + seed) for the reference's dropout / shuffle streams; NS seeds.
-    The statistic: best dev accuracy (and the per-epoch dev accuracies) over seeds."""
-    snr = float(os.environ.get("G15_SNR", "0.06"))
-    NS = int(os.environ.get("G15_NS", "16"))
+    torch.manual_seed(300 + seed) for the reference's OWN dropout (Philox) / shuffle streams; NS seeds.
+    The statistic: best dev accuracy (and the per-epoch dev accuracies) over seeds.
+    Every seed is independent, so the run can be split over processes: G15_SEED0=a G15_NS=n writes the part file
+    g15_part_<a>.npz (git-ignored); `make_golden.py g15merge` concatenates the parts in seed order into the fixture.
+    Committed fixture: `for a in 0 16 32 48; do G15_SEED0=$a G15_NS=16 G15_THREADS=1 python make_golden.py g15 & done; wait;
+    python make_golden.py g15merge` (snr 0.12, 64 seeds, E=10; 1 BLAS thread per process)."""
+    snr = float(os.environ.get("G15_SNR", G15_DEFAULT_SNR))
+    NS = int(os.environ.get("G15_NS", G15_DEFAULT_NS))
+    seed0 = int(os.environ.get("G15_SEED0", "0"))
     E = int(os.environ.get("G15_E", "10"))
+    nthreads = int(os.environ.get("G15_THREADS", "1"))
     ttr = dict(O.synth_table(10000, 1, snr=snr, quant="bf16"), vlogit=np.zeros((10000, 60), np.float32), slogit=np.zeros((10000, 60), np.float32))
     tdv = dict(O.synth_table(5600, 2, snr=snr, quant="bf16"), vlogit=np.zeros((5600, 60), np.float32), slogit=np.zeros((5600, 60), np.float32))
     conf = np.array(CONFS["c4"])
     args = mkargs(inner_representation_size=128, batchnorm=True, drpt=0.5, epochs=E, batchsize=16)
-    torch.set_num_threads(int(os.environ.get("G15_THREADS", "4")))
+    torch.set_num_threads(nthreads)
     loaders = {"train": ShuffleLoader(ttr, 16), "dev": ListLoader(tdv, 16)}
     bests, hists = [], []
-    for seed in range(NS):
+    for seed in range(seed0, seed0 + NS):
         torch.manual_seed(300 + seed)
         accs, _, hist = run_tsm([conf], args, loaders, 3000 + 10 * seed)
         bests.append(accs[0])
@@ -740,8 +750,24 @@ def g15():
         print("g15 seed", seed, accs[0], hist[1::2, 2], flush=True)
     if os.environ.get("G15_PROBE"):
         return
-    save("g15_bench_workload.npz", best_acc=np.array(bests), hist=np.array(hists),
-         meta=np.array([10000, 5600, snr, 128, 16, E, 1, 0.5]))   # N,Ndev,snr,R,B,epochs,bn,drpt
+    arrs = dict(best_acc=np.array(bests), hist=np.array(hists), seeds=np.arange(seed0, seed0 + NS),
+                meta=np.array([10000, 5600, snr, 128, 16, E, 1, 0.5]),   # N,Ndev,snr,R,B,epochs,bn,drpt
+                cmd=np.array(f"G15_SNR={snr} G15_NS={NS} G15_SEED0={seed0} G15_E={E} G15_THREADS={nthreads} make_golden.py g15"))
+    if "G15_SEED0" in os.environ:
+        save(f"g15_part_{seed0:03d}.npz", **arrs)
+    else:
+        save("g15_bench_workload.npz", **arrs)
+
+
+def g15merge():
+    import glob
+    parts = [np.load(f) for f in sorted(glob.glob(os.path.join(HERE, "g15_part_*.npz")))]
+    assert parts and all(np.array_equal(p["meta"], parts[0]["meta"]) for p in parts)
+    seeds = np.concatenate([p["seeds"] for p in parts])
+    assert np.array_equal(seeds, np.arange(len(seeds))), seeds
+    save("g15_bench_workload.npz", best_acc=np.concatenate([p["best_acc"] for p in parts]),
+         hist=np.concatenate([p["hist"] for p in parts]), seeds=seeds, meta=parts[0]["meta"],
+         cmd=np.array(" ; ".join(str(p["cmd"]) for p in parts) + " ; g15merge"))
 
 
 # ------------------------------------------------------------------ G16 weight sharing (next#4)
@@ -825,7 +851,246 @@ def g17():
     save("g17_found_twophase.npz", **out)
 
 
+# ------------------------------------------------------------------ G18 train-mode dropout pinned POINTWISE (mask injection)
+class HashDropout(nn.Module):
+    """Takes the place of the ``nn.Dropout`` INSTANCE of one constructed cell — the reference code that builds the cell
+    (ntu_searchable.py:275-282) and calls it (:237,:240) is unchanged, exactly like the stub backbones.  Arithmetic = ATen's
+    ``_dropout_impl`` (``noise = bernoulli(1-p); noise.div_(1-p); input * noise``) with the Bernoulli draw replaced by the
+    counter-based keep mask the oracle and the HIP engine share (oracle.dropout_keep(seed, step, cell, B, R, p)); ``step``
+    counts this module's train-mode calls = the candidate's global train step."""
+
+    def __init__(self, p, seed, cell):
+        super().__init__()
+        self.p, self.seed, self.cell, self.step = float(p), int(seed), int(cell), 0
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        keep = O.dropout_keep(self.seed, self.step, self.cell, x.shape[0], x.shape[1], self.p)
+        self.step += 1
+        noise = torch.from_numpy(keep.astype(np.float32))
+        noise.div_(1 - self.p)
+        return x * noise
+
+
+def inject_masks(model, seed):
+    n = 0
+    for i, cell in enumerate(model.fusion_layers):
+        last = len(cell) - 1
+        assert isinstance(cell[last], nn.Dropout), cell
+        cell[last] = HashDropout(cell[last].p, seed, i)
+        n += 1
+    return n
+
+
+class CaptureMasked(Capture):
+    """searchable_type factory: hash-generated central params (seed0 + index, optionally perturbed) AND hash dropout masks
+    (drop_seed0 + index) — candidate i of the call is exactly the oracle's / engine's candidate i."""
+
+    def __init__(self, seed0, drop_seed0, perturb_trial=None, same_params=False):
+        super().__init__(seed0)
+        self.drop_seed0, self.perturb_trial, self.same_params = drop_seed0, perturb_trial, same_params
+
+    def __call__(self, args, conf):
+        m = ntu.Searchable_Skeleton_Image_Net(args, conf)
+        i = len(self.models)
+        p = O.init_params(conf, hyper_of(args), self.seed0 + (0 if self.same_params else i))
+        if self.perturb_trial is not None:
+            p = O.perturb_params(p, self.perturb_trial)
+        sd = m.state_dict()
+        for k, v in p.items():
+            sd[k].copy_(torch.from_numpy(v))
+        inject_masks(m, self.drop_seed0 + i)
+        self.models.append(m)
+        return m
+
+
+class OrderLoader(ListLoader):
+    """DataLoader(shuffle=True) with the permutations fixed: epoch e of every candidate walks order[e]."""
+
+    def __init__(self, table, B, order):
+        super().__init__(table, B)
+        self.order, self.calls = np.asarray(order), 0
+
+    def __iter__(self):
+        perm = torch.from_numpy(self.order[self.calls % len(self.order)].astype(np.int64))
+        self.calls += 1
+        for i in range(0, len(perm), self.B):
+            sl = perm[i:i + self.B]
+            rgb = D({k: self.t[k][sl] for k in ("v0", "v1", "v2", "v3", "vlogit")})
+            ske = D({k: self.t[k][sl] for k in ("s0", "s1", "s2", "s3", "slogit")})
+            yield {"rgb": rgb, "ske": ske, "label": self.t["label"][sl]}
+
+
+G18A_VARIANTS = [("bndrop", dict(batchnorm=True, drpt=0.5)), ("drop", dict(batchnorm=False, drpt=0.5)),
+                 ("bndrop04", dict(batchnorm=True, drpt=0.4)), ("drop04", dict(batchnorm=False, drpt=0.4))]
+
+
+def g18a():
+    """ONE train-mode forward + backward with dropout ON, through the unchanged module (ntu_searchable.py:206-247, cells
+    :275-282 = [Linear, nl, BN, Dropout] and [Linear, nl, Dropout]) for nl in {ReLU, Sigmoid, LeakyReLU} (confs c4, l1, l2, l3),
+    R = 16 (all) and 128 (c4, l2), batch rows 16 and 10 (a ragged last batch), step index 0 and 7 of the mask stream.
+    table = synth_table(16, 11, snr=0.3, with_logits=True); params = init_params(conf, hp, seed, perturb_bn=True);
+    masks = dropout_keep(drop seed = seed + 5, step, cell, rows, R, p).  Stored: logits, loss, preds, every central gradient,
+    the BN running statistics after the step."""
+    out, names = {}, []
+    t = table(16, 11)
+    for ci, cname in enumerate(("c4", "l1", "l2", "l3")):
+        conf = CONFS[cname]
+        for vi, (vname, kw) in enumerate(G18A_VARIANTS):
+            for R in (16, 128):
+                if R == 128 and cname not in ("c4", "l2"):
+                    continue
+                for rows, step in ((16, 0), (10, 7)):
+                    if rows == 10 and vname.endswith("04") and R == 128:
+                        continue
+                    seed = 1800 + 100 * ci + 10 * vi + (R == 128)
+                    args = mkargs(inner_representation_size=R, **kw)
+                    model = ntu.Searchable_Skeleton_Image_Net(args, np.array(conf))
+                    load_det(model, conf, args, seed, perturb_bn=True)
+                    inject_masks(model, seed + 5)
+                    for cell in model.fusion_layers:
+                        cell[len(cell) - 1].step = step
+                    model.train(True)
+                    pre = f"{cname}/{vname}/{R}/{rows}/"
+                    names.append(f"{cname}/{vname}/{R}/{rows}/{step}/{seed}")
+                    rgb, ske = feats_of(t, slice(0, rows))
+                    label = torch.from_numpy(t["label"][:rows])
+                    output = model((rgb, ske))
+                    loss = torch.nn.CrossEntropyLoss()(output, label)
+                    out[pre + "logits"] = output.detach().numpy()
+                    out[pre + "loss"] = np.array(loss.item())
+                    out[pre + "preds"] = torch.max(output, 1)[1].numpy()
+                    loss.backward()
+                    for n_, p in model.named_parameters():
+                        if p.grad is not None:
+                            put(out, pre + "grad/" + n_, p.grad.numpy().copy())
+                    for k, v in central_sd(model).items():
+                        if "running" in k:
+                            out[pre + "after/" + k] = v
+    out["names"] = np.array(names)
+    save("g18a_dropout_forward_backward.npz", **out)
+
+
+G18B_CASES = {  # tag: (conf, R, bn, drpt, B, N_train, N_dev, snr)
+    "search": ("c4", 16, False, 0.5, 20, 120, 60, 1.0),      # the search script's defaults (main_searchable_ntu.py:28,48,56): [Linear, nl, Dropout]
+    "search_l3": ("l3", 16, False, 0.5, 20, 130, 70, 1.0),   # LeakyReLU cell, ragged last batches (130 = 6*20+10, 70 = 3*20+10)
+    "bench": ("c4", 128, True, 0.5, 16, 64, 48, 0.3),        # BASELINE configs[1]'s cell: [Linear, nl, BN, Dropout]
+    "bench16": ("l2", 16, True, 0.4, 16, 64, 48, 0.3),
+}
+
+
+def g18b_order(tag, E, N):
+    rng = np.random.default_rng(1800 + sum(map(ord, tag)))
+    return np.stack([rng.permutation(N) for _ in range(E)])
+
+
+def g18b():
+    """Dropout ON, shuffled FIXED order, through the unchanged train loop: (i) a replica of train_ntu_track_acc's train-phase
+    body (:46-69) dumping W / m / v after 1, 2 and 10 Adam steps; (ii) the unchanged train_sampled_models ->
+    train_ntu_track_acc from the same start for 3 epochs: per-epoch history as printed, best accuracy, final parameters.
+    params = init_params(conf, hp, 5), masks seeded 40, order = g18b_order(tag, 3, N_train)."""
+    out = {}
+    E = 3
+    for tag, (cname, R, bn, drpt, B, N, Nd, snr) in G18B_CASES.items():
+        conf = np.array(CONFS[cname])
+        ttr, tdv = table(N, 21, with_logits=False, snr=snr), table(Nd, 22, with_logits=False, snr=snr)
+        order = g18b_order(tag, E, N)
+        args = mkargs(inner_representation_size=R, batchnorm=bn, drpt=drpt, epochs=E, batchsize=B)
+        model = ntu.Searchable_Skeleton_Image_Net(args, conf)
+        load_det(model, conf, args, 5)
+        inject_masks(model, 40)
+        pre = tag + "/"
+        opt = torch.optim.Adam(model.central_params(), lr=args.eta_max, weight_decay=1e-4)
+        sched = sc.LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, N / B)
+        crit = torch.nn.CrossEntropyLoss()
+        model.train(True)
+        step, losses = 0, []
+        loader = OrderLoader(ttr, B, order)
+        for ep in range(E):
+            for data in loader:
+                opt.zero_grad()
+                output = model((data["rgb"], data["ske"]))
+                loss = crit(output, data["label"])
+                sched.step()
+                sched.update_optimizer(opt)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+                step += 1
+                if step in (1, 2, 10):
+                    for k, v in central_sd(model).items():
+                        if "num_batches" not in k:
+                            put(out, pre + f"step{step}/p/" + k, v)
+                    name_of = {id(p): n for n, p in model.named_parameters()}
+                    for p, st in opt.state.items():
+                        put(out, pre + f"step{step}/m/" + name_of[id(p)], st["exp_avg"].numpy().copy())
+                        put(out, pre + f"step{step}/v/" + name_of[id(p)], st["exp_avg_sq"].numpy().copy())
+        out[pre + "losses"] = np.array(losses)
+        cap = CaptureMasked(5, 40)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            accs = ntu.train_sampled_models([conf], cap, {"train": OrderLoader(ttr, B, order), "dev": ListLoader(tdv, B)}, args, "cpu")
+        out[pre + "best_acc"] = np.array(float(accs[0]))
+        out[pre + "hist"] = parse_hist(buf.getvalue())
+        out[pre + "meta"] = np.array([R, int(bn), drpt, B, N, Nd, snr])
+        for k, v in central_sd(cap.models[0]).items():
+            if "num_batches" not in k:
+                put(out, pre + "final/" + k, v)
+    save("g18b_dropout_trajectory.npz", **out)
+
+
+G18C_SNR = 0.12
+
+
+def g18c():
+    """The G14 experiment WITH dropout 0.5 and a shuffled fixed order: BASELINE configs[1] at full size (conf 4, R=128,
+    --batchnorm, drpt 0.5, B=16, N=10,000/5,600, bf16-rounded taps at snr 0.12 = bench.py's tables, 3 epochs) through the
+    unchanged train_sampled_models from NT=64 starts that differ by a 1e-7 relative perturbation of the initial weight
+    matrices; every start sees the SAME masks (seed 4040) and the SAME order (default_rng(1812)).  The oracle and the engine
+    run from the same starts with the same masks / order (tests/test_fullsize.py): all three ensembles must agree in
+    distribution.  Splittable like g15: G18C_T0=a G18C_NT=n -> part file; `g18cmerge`.
+    Committed: `for a in 0 16 32 48; do G18C_T0=$a G18C_NT=16 python make_golden.py g18c & done; wait; python make_golden.py g18cmerge`."""
+    NT = int(os.environ.get("G18C_NT", "64"))
+    t0 = int(os.environ.get("G18C_T0", "0"))
+    E = 3
+    snr = G18C_SNR
+    ttr = dict(O.synth_table(10000, 1, snr=snr, quant="bf16"), vlogit=np.zeros((10000, 60), np.float32), slogit=np.zeros((10000, 60), np.float32))
+    tdv = dict(O.synth_table(5600, 2, snr=snr, quant="bf16"), vlogit=np.zeros((5600, 60), np.float32), slogit=np.zeros((5600, 60), np.float32))
+    rng = np.random.default_rng(1812)
+    order = np.stack([rng.permutation(10000) for _ in range(E)])
+    conf = np.array(CONFS["c4"])
+    args = mkargs(inner_representation_size=128, batchnorm=True, drpt=0.5, epochs=E, batchsize=16)
+    torch.set_num_threads(int(os.environ.get("G18C_THREADS", "1")))
+    hists, bests = [], []
+    for trial in range(t0, t0 + NT):
+        cap = CaptureMasked(77, 4040, perturb_trial=trial)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            accs = ntu.train_sampled_models([conf], cap, {"train": OrderLoader(ttr, 16, order), "dev": ListLoader(tdv, 16)}, args, "cpu")
+        h = parse_hist(buf.getvalue())
+        hists.append(h)
+        bests.append(float(accs[0]))
+        print("g18c trial", trial, bests[-1], h[:, 1:].ravel(), flush=True)
+    arrs = dict(hist=np.array(hists), best_acc=np.array(bests), trials=np.arange(t0, t0 + NT), rel=np.array([1e-7]),
+                meta=np.array([10000, 5600, snr, 128, 16, E, 1, 0.5, 77, 4040, 1812]))
+    if "G18C_T0" in os.environ:
+        save(f"g18c_part_{t0:03d}.npz", **arrs)
+    else:
+        save("g18c_dropout_envelope.npz", **arrs)
+
+
+def g18cmerge():
+    import glob
+    parts = [np.load(f) for f in sorted(glob.glob(os.path.join(HERE, "g18c_part_*.npz")))]
+    assert parts and all(np.array_equal(p["meta"], parts[0]["meta"]) for p in parts)
+    trials = np.concatenate([p["trials"] for p in parts])
+    assert np.array_equal(trials, np.arange(len(trials))), trials
+    save("g18c_dropout_envelope.npz", hist=np.concatenate([p["hist"] for p in parts]),
+         best_acc=np.concatenate([p["best_acc"] for p in parts]), trials=trials, rel=parts[0]["rel"], meta=parts[0]["meta"])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g14m", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g14m", "g15", "g16", "g17", "g18a", "g18b", "g18c"]
     for w in which:
         globals()[w]()

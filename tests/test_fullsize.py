@@ -50,7 +50,7 @@ def row_of(train_loss, train_acc, dev_loss, dev_acc, best):
 
 def check_ensemble(mine, ref):
     """mine, ref: [trial][13].  Means within 3 standard errors (+0.1 % on accuracies), spreads within x3, every sample
-    within 5.5 sigma of the reference's mean."""
+    within 5.5 sigma of the reference's mean (one straggler per 64 samples)."""
     for j, nm in enumerate(NAMES):
         sr, sm = ref[:, j].std(ddof=1), mine[:, j].std(ddof=1)
         se = np.sqrt(sr ** 2 / len(ref) + sm ** 2 / len(mine))
@@ -63,7 +63,7 @@ def check_ensemble(mine, ref):
         far = dev > 5.5 * sr + (TOL if "acc" in nm else 1e-4)
         # (the epoch right after a warm restart of the cosine schedule — epoch 1 here — has a heavier tail than 64 reference
         # samples resolve: at most ONE straggler per statistic, and never beyond 12 sigma)
-        assert far.sum() <= (1 if len(mine) >= 32 else 0), (nm, mine[:, j][far], ref[:, j].mean(), sr)
+        assert far.sum() <= (max(1, len(mine) // 64) if len(mine) >= 32 else 0), (nm, mine[:, j][far], ref[:, j].mean(), sr)
         assert (dev <= 12.0 * sr + (TOL if "acc" in nm else 1e-4)).all(), (nm, mine[:, j][dev.argmax()], ref[:, j].mean(), sr)
 
 
@@ -114,24 +114,95 @@ def test_engine_fullsize_vs_reference(variant):
     check_ensemble(np.array(rows), g14_stats(variant))
 
 
+# ------------------------------------------------------------------ G18c: the same experiment WITH dropout (injected masks)
+HP_DROP = O.Hyper(R=128, B=16, bn=True, drpt=0.5, epochs=3)
+G18C_ENGINE_STARTS = 2048
+
+
+def g18c():
+    g = golden("g18c_dropout_envelope.npz")
+    N, Nd, snr, R, B, E, bn, drpt, init_seed, drop_seed, order_seed = g["meta"]
+    assert (int(N), int(Nd), int(R), int(B), int(E), int(bn), float(drpt)) == (10000, 5600, 128, 16, 3, 1, 0.5)
+    assert float(snr) == 0.12                                       # bench.py's tables
+    H = g["hist"]
+    stats = np.concatenate([H[:, :, 1:].reshape(len(H), -1), g["best_acc"][:, None]], 1)
+    rng = np.random.default_rng(int(order_seed))
+    order = np.stack([rng.permutation(int(N)) for _ in range(int(E))])
+    return stats, order, int(init_seed), int(drop_seed), float(snr)
+
+
+def test_dropout_envelope_gate_is_tight():
+    """The reference's own spread with dropout ON (same masks, same order, 1e-7 perturbed starts) and what it makes of the gate:
+    3 standard errors of (reference starts vs G18C_ENGINE_STARTS engine starts) + the north_star's 0.1 % must stay <= 0.2 %
+    top-1 on the returned quantity (best dev accuracy)."""
+    r, order, _, _, _ = g18c()
+    assert len(r) >= 256 and order.shape == (3, 10000)
+    assert 0.5 < r[:, 12].mean() < 0.9                              # not saturated
+    s = r[:, 12].std(ddof=1)
+    assert 3.0 * s * np.sqrt(1.0 / len(r) + 1.0 / G18C_ENGINE_STARTS) + TOL <= 0.002, (s, len(r))
+
+
+def test_oracle_fullsize_dropout_vs_reference():
+    r, order, init_seed, drop_seed, snr = g18c()
+    ttr, tdv = O.synth_table(10000, 1, snr=snr, quant="bf16"), O.synth_table(5600, 2, snr=snr, quant="bf16")
+    rows = []
+    for trial in range(2):
+        hist = []
+        best = O.train_candidate(CONF, HP_DROP, O.perturb_params(O.init_params(CONF, HP_DROP, init_seed), trial), ttr, tdv,
+                                 order=order, seed=drop_seed, history=hist)
+        rows.append(row_of([h["train_loss"] for h in hist], [h["train_acc"] for h in hist],
+                           [h["dev_loss"] for h in hist], [h["dev_acc"] for h in hist], best))
+    check_ensemble(np.array(rows), r)
+
+
+@pytest.mark.gpu
+def test_engine_fullsize_dropout_vs_reference():
+    """G18c on the engine: 2048 starts (16 lock-step populations of 128), every candidate with the reference's masks (same
+    drop seed) and the reference's order.  This is the +-0.2 % gate on the path bench.py and the search actually run."""
+    torch = pytest.importorskip("torch")
+    import mfas_amd as M
+    r, order, init_seed, drop_seed, snr = g18c()
+    ttr, tdv = O.synth_table(10000, 1, snr=snr, quant="bf16"), O.synth_table(5600, 2, snr=snr, quant="bf16")
+    dev = torch.device("cuda:0")
+    ta, tb = M.FeatureTable.from_numpy(ttr, dev, torch.bfloat16), M.FeatureTable.from_numpy(tdv, dev, torch.bfloat16)
+    dorder = torch.from_numpy(order.astype(np.int32)).to(dev)
+    base = O.init_params(CONF, HP_DROP, init_seed)
+    rows = []
+    for grp in range(G18C_ENGINE_STARTS // 128):
+        pop = M.Population(engine_hyper(HP_DROP), [CONF] * 128, dev, drop_seeds=[drop_seed] * 128)
+        for j in range(128):
+            pop.set_state_dict(j, O.perturb_params(base, 128 * grp + j))
+        stats, status = pop.train(ta, tb, 3, etas_for(HP_DROP, 10000), order=dorder)
+        assert not status.any()
+        rows += [row_of(s["train_loss_sum"] / 10000, s["train_corrects"] / 10000, s["dev_loss_sum"] / 5600,
+                        s["dev_corrects"] / 5600, M.best_dev_accuracy(s, 5600)) for s in stats]
+        pop.close()
+    rows = np.array(rows)
+    check_ensemble(rows, r)
+    se = np.sqrt(r[:, 12].std(ddof=1) ** 2 / len(r) + rows[:, 12].std(ddof=1) ** 2 / len(rows))
+    assert abs(rows[:, 12].mean() - r[:, 12].mean()) <= 3.0 * se + TOL <= 0.002      # the gate that was asked for
+
+
 @pytest.mark.gpu
 def test_engine_bench_workload_vs_reference():
     """G15: BASELINE configs[1] exactly as bench.py runs it (conf 4, R=128, BN, drpt 0.5, shuffled, B=16, E=10,
-    N=10,000/5,600, bf16-rounded taps; snr 0.10 so that the best dev accuracy sits at 0.66) through the unchanged reference
-    for 16 seeds (train_searchable/ntu.py:14-89).  The engine's dropout and shuffle streams are its own, so the gate is
-    statistical: mean best dev accuracy over 64 engine seeds (4 populations of 16, each with its own epoch orders; the
-    first 16 initial states are the reference's own) within 3 s.e. + 0.1 %; the per-epoch dev accuracies likewise."""
+    N=10,000/5,600, bf16-rounded taps at snr 0.12 — bench.py's tables) through the unchanged reference with its OWN dropout
+    (Philox) and shuffle streams for 64 seeds (train_searchable/ntu.py:14-89).  The engine's streams are its own, so the gate
+    is statistical: mean best dev accuracy over 256 engine seeds (16 populations of 16, each with its own epoch orders; the
+    first 64 initial states are the reference's own) within 3 s.e. + 0.1 %; the per-epoch dev accuracies likewise.  (The
+    pointwise pin of the dropout path is G18a/b/c, where the reference runs with the engine's masks.)"""
     torch = pytest.importorskip("torch")
     import mfas_amd as M
     g = golden("g15_bench_workload.npz")
     N, Nd, snr, R, B, E, bn, drpt = g["meta"]
     N, Nd, R, B, E = int(N), int(Nd), int(R), int(B), int(E)
+    assert float(snr) == 0.12 and len(g["best_acc"]) >= 64 and E == 10     # the bench workload, not a neighbour of it
     hp = O.Hyper(R=R, B=B, bn=bool(bn), drpt=float(drpt), epochs=E)
     ttr, tdv = O.synth_table(N, 1, snr=float(snr), quant="bf16"), O.synth_table(Nd, 2, snr=float(snr), quant="bf16")
     dev = torch.device("cuda:0")
     ta, tb = M.FeatureTable.from_numpy(ttr, dev, torch.bfloat16), M.FeatureTable.from_numpy(tdv, dev, torch.bfloat16)
     best, per_epoch = [], []
-    for grp in range(4):
+    for grp in range(16):
         seeds = list(range(16 * grp, 16 * grp + 16))
         pop = M.Population(engine_hyper(hp), [CONF] * 16, dev, drop_seeds=[7000 + s for s in seeds])
         pop.init([3000 + 10 * s for s in seeds])          # == O.init_params(conf, hp, 3000 + 10 * seed): the reference's starts
@@ -144,7 +215,7 @@ def test_engine_bench_workload_vs_reference():
     best, per_epoch = np.array(best), np.array(per_epoch)
     ref_best = g["best_acc"]
     ref_epoch = g["hist"][:, 1::2, 2]                      # [seed][epoch] dev accuracy as printed (4 decimals)
-    assert 0.5 < ref_best.mean() < 0.8                     # mid-range: the regime where accuracy is sensitive
+    assert 0.5 < ref_best.mean() < 0.9                     # not saturated
 
     def iqr(x):
         return float(np.subtract(*np.percentile(x, [75, 25])))
@@ -160,10 +231,10 @@ def test_engine_bench_workload_vs_reference():
         assert iqr(mine) <= 2.5 * iqr(ref) + 2e-3, (what, "spread", iqr(mine), iqr(ref))
         far = np.abs(mine - ref.mean()) > 6.0 * ref.std(ddof=1) + TOL
         outliers.append((what, int(far.sum())))
-        assert far.sum() <= 2, (what, "outliers", mine[far])
+        assert far.sum() <= 2 * (len(mine) // 64), (what, "outliers", mine[far])
 
     gate(best, ref_best, "best dev acc")
     for e in range(E):
         gate(per_epoch[:, e], ref_epoch[:, e], f"dev acc epoch {e}")
     assert outliers[0][1] == 0                      # the returned quantity itself has no stragglers
-    assert sum(n for _, n in outliers) <= 4, outliers
+    assert sum(n for _, n in outliers) <= 4 * (len(best) // 64), outliers

@@ -169,6 +169,90 @@ def test_multitask_and_alphas_runs(golden_dir):
     np.testing.assert_allclose(got, g["alpha_final"], rtol=2e-3, atol=1e-6)
 
 
+# ------------------------------------------------------------------ G18 train-mode dropout, pinned pointwise (mask injection)
+G18A_KW = {"bndrop": dict(bn=True, drpt=0.5), "drop": dict(bn=False, drpt=0.5),
+           "bndrop04": dict(bn=True, drpt=0.4), "drop04": dict(bn=False, drpt=0.4)}
+G18B_CASES = {"search": ("c4", 16, False, 0.5, 20, 120, 60, 1.0), "search_l3": ("l3", 16, False, 0.5, 20, 130, 70, 1.0),
+              "bench": ("c4", 128, True, 0.5, 16, 64, 48, 0.3), "bench16": ("l2", 16, True, 0.4, 16, 64, 48, 0.3)}
+
+
+def g18b_order(tag, E, N):
+    rng = np.random.default_rng(1800 + sum(map(ord, tag)))
+    return np.stack([rng.permutation(N) for _ in range(E)])
+
+
+def test_dropout_train_forward_loss_grads(golden_dir):
+    """G18a: the reference's train-mode forward/backward with its nn.Dropout instances replaced by the shared hash mask
+    (tests/golden/make_golden.py::HashDropout) — [Linear, nl, BN, Dropout] and [Linear, nl, Dropout] (ntu_searchable.py:275-282),
+    nl in {ReLU, Sigmoid, LeakyReLU}, p in {0.5, 0.4}, full and ragged batches, two positions of the mask stream."""
+    g = load(golden_dir, "g18a_dropout_forward_backward.npz")
+    t = O.synth_table(16, 11, snr=0.3, with_logits=True)
+    seen = set()
+    for name in g["names"]:
+        cname, vname, R, rows, step, seed = str(name).split("/")
+        R, rows, step, seed = int(R), int(rows), int(step), int(seed)
+        hp = O.Hyper(R=R, B=16, **G18A_KW[vname])
+        conf = np.array(CONFS[cname])
+        params = O.init_params(conf, hp, seed, perturb_bn=True)
+        feats = {k: v[:rows] for k, v in t.items() if k != "label"}
+        pre = f"{cname}/{vname}/{R}/{rows}/"
+        logits, cache = O.forward(params, conf, hp, feats, True, seed=seed + 5, step=step)
+        np.testing.assert_allclose(logits, g[pre + "logits"], rtol=2e-4, atol=2e-5, err_msg=pre)
+        loss, dlog, preds = O.ce_loss(logits, t["label"][:rows])
+        np.testing.assert_allclose(loss, g[pre + "loss"], rtol=1e-5)
+        assert np.array_equal(preds, g[pre + "preds"]), pre
+        for k, v in O.backward(params, hp, cache, dlog).items():
+            check(g, pre + "grad/" + k, v, rtol=2e-3, atol=2e-7, scale_atol=1e-3)
+        if hp.bn:
+            O.bn_update_running(params, hp, cache)
+            for i in range(len(conf)):
+                for s in ("running_mean", "running_var"):
+                    k = f"fusion_layers.{i}.2.{s}"
+                    np.testing.assert_allclose(params[k], g[pre + "after/" + k], rtol=1e-5, atol=1e-6)
+        seen.update((vname, int(c[2])) for c in conf)
+    assert len(g["names"]) >= 40
+    assert seen >= {(v, nl) for v in G18A_KW for nl in (0, 1, 2)}       # every legal dropout cell x every non-linearity
+
+
+@pytest.mark.parametrize("tag", list(G18B_CASES))
+def test_dropout_trajectory(golden_dir, tag):
+    """G18b: W / m / v after 1, 2, 10 Adam steps and the 3-epoch trajectory of the unchanged train_sampled_models with dropout
+    ON (injected masks) and a shuffled fixed order — the search default (R=16, no BN, B=20) and the bench cell (R=128, BN, B=16)."""
+    g = load(golden_dir, "g18b_dropout_trajectory.npz")
+    cname, R, bn, drpt, B, N, Nd, snr = G18B_CASES[tag]
+    assert np.array_equal(g[tag + "/meta"], np.array([R, int(bn), drpt, B, N, Nd, snr]))
+    ttr, tdv = O.synth_table(N, 21, snr=snr), O.synth_table(Nd, 22, snr=snr)
+    conf = np.array(CONFS[cname])
+    hp = O.Hyper(R=R, B=B, bn=bn, drpt=drpt, epochs=3)
+    order = g18b_order(tag, 3, N)
+    params = O.init_params(conf, hp, 5)
+    pre = tag + "/"
+    losses = []
+
+    def on_step(gstep, p, st, loss):
+        losses.append(loss)
+        step = gstep + 1
+        if step in (1, 2, 10):
+            for k, v in p.items():
+                if k.startswith("alphas") or (not bn and ".2." in k):
+                    continue
+                # (running statistics are an EMA of batch moments of activations that already carry the weights' 1e-4)
+                check(g, pre + f"step{step}/p/" + k, v, rtol=1e-3 if "running" in k else 1e-4, atol=2e-6 * step, loose_atol=1e-3 * step)
+            for k in st.m:
+                check(g, pre + f"step{step}/m/" + k, st.m[k], rtol=2e-3, atol=1e-9, scale_atol=2e-3, loose_atol=1.0)
+                check(g, pre + f"step{step}/v/" + k, st.v[k], rtol=4e-3, atol=1e-14, scale_atol=2e-3, loose_atol=1.0)
+
+    hist = []
+    best = O.train_candidate(conf, hp, params, ttr, tdv, order=order, seed=40, history=hist, on_step=on_step)
+    np.testing.assert_allclose(losses, g[pre + "losses"], rtol=5e-4)
+    ghist = g[pre + "hist"]
+    for ep, h in enumerate(hist):
+        tr_row, dv_row = ghist[2 * ep], ghist[2 * ep + 1]
+        assert abs(h["train_loss"] - tr_row[1]) < 3e-4 and abs(h["train_acc"] - tr_row[2]) < 1e-4
+        assert abs(h["dev_loss"] - dv_row[1]) < 3e-4 and abs(h["dev_acc"] - dv_row[2]) < 1e-4      # exact dev counts
+    assert best == pytest.approx(float(g[pre + "best_acc"]), abs=1e-12)
+
+
 # ------------------------------------------------------------------ G8
 def test_layer_configurations(golden_dir):
     g = load(golden_dir, "g8_controller.npz")
