@@ -891,17 +891,13 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     // weight tiles of every product (all waves fetch them — 11 KiB, uniform control flow; wave 0 / waves < ncb use them)
     f32x4 tP[MFAS_MAX_CELLS], tT[MFAS_MAX_CELLS], tHT[4], tH;   // prev-out tile of cell i, its transpose, head^T, head
     tP[0] = z4; tT[0] = z4;
-    if constexpr (RES) {   // the chain owns these weights: LDS-resident images (slot i-1: OUT_i, slot 3+u: head block u)
-        const float* ownW = ll.own;
-        const float* ownT = ll.own + 3 * LEAN_OWN_TILES * 256;
+    if constexpr (RES) {   // the chain owns these weights: LDS-resident images (slot i-1: OUT_i, slot 3+u: head block u), read where
+                           // they are used (an LDS read costs ~100 cycles; 13 tiles held from entry cost 52 VGPRs and spilled)
 #pragma unroll
-        for (int i = 1; i < MFAS_MAX_CELLS; ++i) {
-            tP[i] = *reinterpret_cast<const f32x4*>(ownW + ((i - 1) << 8) + lane * 4);
-            tT[i] = *reinterpret_cast<const f32x4*>(ownT + ((i - 1) << 8) + lane * 4);
-        }
+        for (int i = 1; i < MFAS_MAX_CELLS; ++i) { tP[i] = z4; tT[i] = z4; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) tHT[u] = *reinterpret_cast<const f32x4*>(ownT + ((3 + u) << 8) + lane * 4);
-        tH = *reinterpret_cast<const f32x4*>(ownW + ((3 + (wave < ncb ? wave : 0)) << 8) + lane * 4);
+        for (int u = 0; u < 4; ++u) tHT[u] = z4;
+        tH = z4;
     } else {
 #pragma unroll
         for (int i = 1; i < MFAS_MAX_CELLS; ++i) {
@@ -1009,7 +1005,9 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                     acc = acc * sgS + yv * sgV;
                 }
                 if (i > 0) {
-                    const f32x4 w = pick4(tP, i);
+                    f32x4 w;
+                    if constexpr (RES) w = *reinterpret_cast<const f32x4*>(ll.own + ((i - 1) << 8) + lane * 4);
+                    else w = pick4(tP, i);
                     const f32x4 x4 = *reinterpret_cast<const f32x4*>(xo_l + (i - 1) * Bp * SX + (emb * 16 + l15) * SX + 4 * lg);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], w[q], acc);
@@ -1074,6 +1072,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
         if (wave < ncb) {
             const int c = wave * 16 + l15;
             const float bias = vecW[g.vec_head + c];
+            if constexpr (RES) tH = *reinterpret_cast<const f32x4*>(ll.own + ((3 + wave) << 8) + lane * 4);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 f32x4 acc = z4;
@@ -1123,15 +1122,20 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                     for (int u = 0; u < 4; ++u)
                         if (u < ncb) {
                             const f32x4 x4 = *reinterpret_cast<const f32x4*>(lg_l + (emb * 16 + l15) * SC + u * 16 + 4 * lg);
+                            f32x4 wt4;
+                            if constexpr (RES) wt4 = *reinterpret_cast<const f32x4*>(ll.own + ((3 * LEAN_OWN_TILES + 3 + u) << 8) + lane * 4);
+                            else wt4 = tHT[u];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                if (u & 1) acc2 = MFMA16(x4[q], tHT[u][q], acc2);
-                                else acc = MFMA16(x4[q], tHT[u][q], acc);
+                                if (u & 1) acc2 = MFMA16(x4[q], wt4[q], acc2);
+                                else acc = MFMA16(x4[q], wt4[q], acc);
                             }
                         }
                     acc += acc2;
                 } else {
-                    const f32x4 w = pick4(tT, i + 1);
+                    f32x4 w;
+                    if constexpr (RES) w = *reinterpret_cast<const f32x4*>(ll.own + ((3 * LEAN_OWN_TILES + i) << 8) + lane * 4);
+                    else w = pick4(tT, i + 1);
                     const f32x4 x4 = *reinterpret_cast<const f32x4*>(dy_l + (i + 1) * Bp * SX + (emb * 16 + l15) * SX + 4 * lg);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], w[q], acc);

@@ -151,7 +151,10 @@ struct mfas_population {
     int nres = 0;                   // resident feature units (one workgroup each, W/m/v in registers): the first nres persistent units
     SegDesc* d_pdescs = nullptr;    // persistent schedule's unit list: [resident feature units | streamed units]
     int n_pdescs = 0;
-    size_t lds_persist = 0;
+    size_t lds_persist = 0;         // streaming form (k_persist)
+    size_t lds_pchain = 0, lds_punits = 0;   // resident form: k_pchain / k_punits
+    hipStream_t stream2 = nullptr;  // resident form: the feature units' launch runs beside the chains' launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t* d_sync = nullptr;     // [K] flags | [K] counters | abort word (zeroed before every launch)
     int32_t* d_need = nullptr;      // [K] sweep units per candidate
     float* d_scal = nullptr;        // device copy of the step scalars
@@ -249,7 +252,9 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                                      + (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.MB * 256 + (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp)
                                      + LEAN_SCR + 8) * 4;
     const bool lean_ok_early = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean_bytes_early <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
-    bool plan_res = want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT") && (lean_ok_early || force_persist);
+    // (resident units exist only together with the resident lean chain — k_pchain + k_punits; everything else that is forced
+    //  persistent runs the streaming form)
+    bool plan_res = want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT") && !getenv("MFAS_PERSIST_NO_RES_CHAIN") && lean_ok_early;
     auto count_feat_units = [&](int cc_target) {
         int64_t n = 0;
         for (int k = 0; k < K; ++k)
@@ -267,7 +272,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     };
     auto res_fits = [&](int cc, int nu, int64_t units) {
         return (cc <= 128 * PERSIST_NTR || (hp->tap_bits == 16 && nu == 1 && cc <= 128 * PERSIST_NTR16)) &&
-               res_lds(cc, nu) <= 160 * 1024 && K + (units + nu - 1) / nu + (lean_ok_early ? 0 : 1) <= p->n_cus;   // (+1: a streaming workgroup for OUT / HEAD when the chain does not own them)
+               res_lds(cc, nu) <= 160 * 1024 && K + (units + nu - 1) / nu <= p->n_cus;
     };
     int target = chunk_cols;
     int plan_nu = 1;
@@ -466,9 +471,15 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         // statistics in its own — element-parallel — order, so lean and general chains agree to rounding, not bit for bit)
         p->lean_chain = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
         if (p->lean_chain) { p->lds_chain = lean; p->lds_step = std::max(p->lds_step, lean); }
-        p->res_chain = res_ok && p->lean_chain && !getenv("MFAS_PERSIST_NO_RES_CHAIN");
+        p->res_chain = res_ok && p->lean_chain;
+        if (res_ok && !p->lean_chain) {   // (cannot happen while lean_ok_early mirrors the formula above)
+            delete p;
+            return MFAS_RETRY_NO_PERSIST;
+        }
         const size_t lds_rchain = p->res_chain ? p->lds_chain + 16 + 4 * (size_t)LeanLds<1>::own_floats() : 0;
-        p->lds_persist = ((std::max(std::max(std::max(p->lds_step, p->lds_chain), res_ok ? lds_res : (size_t)0), lds_rchain) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
+        p->lds_persist = ((std::max(p->lds_step, p->lds_chain) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
+        p->lds_pchain = ((lds_rchain + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
+        p->lds_punits = ((lds_res + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
     }
     p->nrbw = (g.nrb + 3) / 4;
     if (p->nrbw == 3) p->nrbw = 4;
@@ -517,7 +528,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
         {   // persistent step loop: small populations (one workgroup per CU must hold every chain + a useful number of sweep workgroups)
             const bool want = want_persist;
-            const int64_t n_stream = p->res_chain ? 0 : (int64_t)p->descs.size() - p->nres;   // (a resident lean chain owns OUT / HEAD)
+            const int64_t n_stream = p->res_chain ? 0 : (int64_t)p->descs.size();   // (a resident lean chain owns OUT / HEAD)
             const bool fits = K <= p->n_cus / 4 && g.MB != 4 && K + p->nres_wg + (n_stream > 0 ? 1 : 0) <= p->n_cus &&
                               n_stream <= (int64_t)PERSIST_MAX_UNITS * (p->n_cus - K - p->nres_wg) &&
                               (double)p->plane_stride * 4.0 < 3.9e9 && (double)step_off * 4.0 < 3.9e9 && (double)wt_off * 4.0 < 3.9e9;
@@ -646,8 +657,8 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         {   // unit list of the persistent schedule: resident feature units first, then the streamed units (largest first)
             std::vector<SegDesc> res, rest;
             for (const SegDesc& d : p->descs) {
-                if (p->nres > 0 && d.kind <= KIND_V) res.push_back(d);
-                else if (!p->res_chain) rest.push_back(d);     // (a resident lean chain updates OUT / HEAD itself)
+                if (p->res_chain) { if (d.kind <= KIND_V) res.push_back(d); }     // (a resident lean chain updates OUT / HEAD itself)
+                else rest.push_back(d);
             }
             std::stable_sort(rest.begin(), rest.end(), [](const SegDesc& x, const SegDesc& y) { return x.cc * x.rows_p > y.cc * y.rows_p; });
             res.insert(res.end(), rest.begin(), rest.end());
@@ -665,10 +676,23 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             CREATE_CHK(hipMalloc(&p->d_trace, sizeof(unsigned long long) * 256));
             CREATE_CHK(hipMemset(p->d_trace, 0, sizeof(unsigned long long) * 256));
         }
-        CREATE_CHK(set_lds((k_persist<1, false, 2>), p->lds_persist));
-        CREATE_CHK(set_lds((k_persist<2, false, 2>), p->lds_persist));
-        CREATE_CHK(set_lds((k_persist<1, true, 2>), p->lds_persist));
-        CREATE_CHK(set_lds((k_persist<2, true, 2>), p->lds_persist));
+        if (p->res_chain) {
+            CREATE_CHK(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+            CREATE_CHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            CREATE_CHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+            CREATE_CHK(set_lds((k_pchain<1>), p->lds_pchain));
+            CREATE_CHK(set_lds((k_pchain<2>), p->lds_pchain));
+#define SET_UNITS(M) CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR, false, 1>), p->lds_punits)); CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR, false, 2>), p->lds_punits)); \
+                     CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR16, true, 1>), p->lds_punits)); CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR, true, 1>), p->lds_punits)); \
+                     CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR, true, 2>), p->lds_punits))
+            SET_UNITS(1); SET_UNITS(2);
+#undef SET_UNITS
+        } else {
+            CREATE_CHK(set_lds((k_persist<1, false, 2>), p->lds_persist));
+            CREATE_CHK(set_lds((k_persist<2, false, 2>), p->lds_persist));
+            CREATE_CHK(set_lds((k_persist<1, true, 2>), p->lds_persist));
+            CREATE_CHK(set_lds((k_persist<2, true, 2>), p->lds_persist));
+        }
     }
     // W/m/v beyond what the 256 MiB Infinity Cache can keep between steps are streamed nontemporally
     p->nontemporal = (double)p->plane_stride * 12.0 > 200.0 * 1024 * 1024;
@@ -691,6 +715,9 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     hipSetDevice(p->device);
     hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->ev) hipEventDestroy(e);
+    if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
+    if (p->ev_fork) hipEventDestroy(p->ev_fork);
+    if (p->ev_join) hipEventDestroy(p->ev_join);
     hipFree(p->plane); hipFree(p->wt); hipFree(p->stepbuf); hipFree(p->best);
     for (auto& gr : p->groups) { hipFree(gr.d_descs); hipFree(gr.d_taps); }
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
@@ -951,10 +978,10 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         pa.N = N; pa.pos0 = (int64_t)ep * N;
         pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);
         pa.scal = p->d_scal; pa.sync = p->d_sync; pa.need = p->d_need; pa.trace = p->d_trace;
-        const int n_stream = pa.nitems - pa.nres;
-        const unsigned grid = (unsigned)(K + pa.nres_wg + (n_stream > 0 ? std::max(1, std::min(n_stream, p->n_cus - K - pa.nres_wg)) : 0));
+        const int n_stream = p->res_chain ? 0 : pa.nitems;
+        const unsigned grid = (unsigned)(K + pa.nres_wg + (n_stream > 0 ? std::max(1, std::min(n_stream, p->n_cus - K)) : 0));
         const int ldsw = (int)(p->lds_persist / 4) - PERSIST_LDS_WORDS;
-        if ((n_stream > 0 && n_stream > PERSIST_MAX_UNITS * (int)(grid - K - pa.nres_wg)) || (int)grid > p->n_cus) return hipErrorInvalidConfiguration;
+        if ((n_stream > 0 && n_stream > PERSIST_MAX_UNITS * (int)(grid - K)) || (int)grid > p->n_cus) return hipErrorInvalidConfiguration;
         const bool prof = p->profiling;
         if (prof) {
             if (p->ev.size() < ev_used + 2) {
@@ -964,11 +991,36 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             }
             hipEventRecord(p->ev[ev_used], p->stream);
         }
+        if (p->res_chain) {
+            // resident form: the chains' launch on the caller's stream, the feature units' launch beside it on stream2 (fork / join
+            // through events: stream2 starts after everything queued so far, the caller's stream continues after both)
+            e = hipEventRecord(p->ev_fork, p->stream);
+            if (e != hipSuccess) return e;
+            e = hipStreamWaitEvent(p->stream2, p->ev_fork, 0);
+            if (e != hipSuccess) return e;
+            const int lw_c = (int)(p->lds_pchain / 4) - PERSIST_LDS_WORDS, lw_u = (int)(p->lds_punits / 4) - PERSIST_LDS_WORDS;
+            if (g.MB == 1) hipLaunchKernelGGL((k_pchain<1>), dim3(K), dim3(STEP_THREADS), p->lds_pchain, p->stream, pa, lw_c);
+            else hipLaunchKernelGGL((k_pchain<2>), dim3(K), dim3(STEP_THREADS), p->lds_pchain, p->stream, pa, lw_c);
+#define UNITS_LAUNCH(M, NTR, X, NU) hipLaunchKernelGGL((k_punits<M, NTR, X, NU>), dim3(pa.nres_wg), dim3(STEP_THREADS), p->lds_punits, p->stream2, pa, lw_u)
+#define UNITS_PICK(M) do { if (train->dtype == MFAS_DT_F32) { if (pa.res_nu == 2) UNITS_LAUNCH(M, PERSIST_NTR, false, 2); else UNITS_LAUNCH(M, PERSIST_NTR, false, 1); } \
+                           else if (pa.res_wide) UNITS_LAUNCH(M, PERSIST_NTR16, true, 1); \
+                           else if (pa.res_nu == 2) UNITS_LAUNCH(M, PERSIST_NTR, true, 2); else UNITS_LAUNCH(M, PERSIST_NTR, true, 1); } while (0)
+            if (g.MB == 1) UNITS_PICK(1); else UNITS_PICK(2);
+#undef UNITS_PICK
+#undef UNITS_LAUNCH
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            e = hipEventRecord(p->ev_join, p->stream2);
+            if (e != hipSuccess) return e;
+            e = hipStreamWaitEvent(p->stream, p->ev_join, 0);
+            if (e != hipSuccess) return e;
+        } else {
 #define PERSIST_LAUNCH(M, F) hipLaunchKernelGGL((k_persist<M, F, 2>), dim3(grid), dim3(STEP_THREADS), p->lds_persist, p->stream, pa, ldsw)
         if (p->lean_chain) { if (g.MB == 1) PERSIST_LAUNCH(1, true); else PERSIST_LAUNCH(2, true); }
         else if (g.MB == 1) PERSIST_LAUNCH(1, false);
         else PERSIST_LAUNCH(2, false);
 #undef PERSIST_LAUNCH
+        }
         if (prof) {
             hipEventRecord(p->ev[ev_used + 1], p->stream);
             ev_used += 2;

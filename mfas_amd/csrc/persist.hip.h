@@ -115,8 +115,10 @@ struct ResUnit {              // wave-uniform constants of one resident unit
     int64_t part, dyo, gsco;  // step-buffer indices: partial slot, dy_i, alpha scale
     float *Wp, *Mp, *Vp;
     uint32_t *flag, *cnt;
-    int32_t xbo[2];           // the two staged batches in LDS (word offsets: a pointer picked at run time would be a flat pointer)
+    int32_t xb0, xbw;         // the two staged batches in LDS: word offsets xb0 and xb0 + xbw (a pointer picked at run time would be a
+                              // flat pointer; a two-element ARRAY indexed at run time parks the whole record in scratch memory)
 };
+__device__ __forceinline__ int res_xbo(const ResUnit& un, int which) { return un.xb0 + (which ? un.xbw : 0); }
 
 template <int MB, int NTR, bool X16, int NU>
 __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int wg, const int nwg, float* lds, int* ldsw) {
@@ -153,8 +155,8 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         U[u].Vp = U[u].Mp + sa.plane_stride;
         U[u].flag = PERSIST_FLAG(a.sync, d.cand);
         U[u].cnt = PERSIST_CNT(a.sync, d.cand);
-        U[u].xbo[0] = (2 * u) * a.res_buf_words;
-        U[u].xbo[1] = (2 * u + 1) * a.res_buf_words;
+        U[u].xb0 = (2 * u) * a.res_buf_words;
+        U[u].xbw = a.res_buf_words;
         cur[u] = 0;
         // the unit's state: wave w owns k-blocks w, w + 8, ... (as sweep_body's k-split)
 #pragma unroll
@@ -210,7 +212,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         if (U[u].valid) {            // (wave-uniform, workgroup-uniform)
-            stage(U[u], lds + U[u].xbo[0], 0);
+            stage(U[u], lds + res_xbo(U[u], 0), 0);
             __syncthreads();
             f32x4 yacc[MB];
 #pragma unroll
@@ -221,14 +223,14 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 if (kb < U[u].nkb) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
-                        const f32x4 x4 = x4of(lds + U[u].xbo[0], U[u].S, mb * 16 + l15, kb * 16 + 4 * lg);
+                        const f32x4 x4 = x4of(lds + res_xbo(U[u], 0), U[u].S, mb * 16 + l15, kb * 16 + 4 * lg);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][s][q], yacc[mb]);
                     }
                 }
             }
             reduce_publish(U[u], yacc);
-            if (1 < a.T) stage(U[u], lds + U[u].xbo[1], 1);
+            if (1 < a.T) stage(U[u], lds + res_xbo(U[u], 1), 1);
         }
     }
     if (tid == 0) {
@@ -279,8 +281,8 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
             if (pick == u) {
                 const ResUnit& un = U[u];
                 const bool fwd = t + 1 < a.T;
-                const float* xt = lds + un.xbo[cur[u]];
-                const float* xn = lds + un.xbo[cur[u] ^ 1];
+                const float* xt = lds + res_xbo(un, cur[u]);
+                const float* xn = lds + res_xbo(un, cur[u] ^ 1);
                 const bool tr_on = un.index == 0 && tid == 0 && t >= 8 && t < 16;
                 const int tr_base = (t - 8) * 8 + 4;
                 PTRACE(1);
@@ -334,7 +336,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 if (tid == 0) nxt[u] = t + 1;
                 cur[u] ^= 1;
                 // batch t+2 into the buffer batch t just vacated: it lands while this unit's chain runs step t+1
-                if (t + 2 < a.T) stage(un, lds + un.xbo[cur[u] ^ 1], t + 2);
+                if (t + 2 < a.T) stage(un, lds + res_xbo(un, cur[u] ^ 1), t + 2);
             }
         }
     }
@@ -359,31 +361,25 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
 #define PERSIST_NTR 4                   // resident units, f32 staging: tiles per wave (cc <= 512 columns)
 #define PERSIST_NTR16 8                 // resident units, 16-bit staging: cc <= 1024 columns
 
-template <int MB, bool LEAN, int U>
-__global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a, const int lds_word) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
-    const int bid = (int)blockIdx.x, tid = threadIdx.x;
-    const int K = a.nchain;
-    uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
-
-    // Roll call: the loop below is only deadlock-free when EVERY workgroup of the grid is resident at the same time.  That holds
-    // when the process owns the GPU (grid <= #CUs, one workgroup per CU); when another process's kernels hold CUs, part of the
-    // grid may be waiting for a slot that the resident part — spinning on it — never frees.  So nobody touches any state before
-    // all workgroups have checked in; if that does not happen within ~5 ms the resident ones leave (abort code 2), the late ones
-    // see the code and leave too, and the host relaunches the epoch.
-    // (count and verdict live in ONE word, so "everybody is here" and "somebody gave up" cannot both be observed)
-    if (tid == 0) {
-        uint32_t* roll = PERSIST_ROLL(a.sync, K);
+// Roll call: the loops below are only deadlock-free when EVERY workgroup of the schedule is resident at the same time.  That holds
+// when the process owns the GPU (workgroups <= #CUs, one per CU); when another process's kernels hold CUs (or a tool serialises
+// the launches of the resident schedule's two kernels), part of the workgroups may be waiting for a slot that the resident part —
+// spinning on it — never frees.  So nobody touches any state before all `total` workgroups have checked in; if that does not
+// happen within ~5 ms the resident ones leave (abort code 2), the late ones see the code and leave too, and the host relaunches
+// the epoch (or falls back to the launch-per-phase schedule).
+// (count and verdict live in ONE word, so "everybody is here" and "somebody gave up" cannot both be observed)
+__device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, const uint32_t total, int* ldsw) {
+    if (threadIdx.x == 0) {
+        uint32_t* roll = PERSIST_ROLL(sync, K);
+        uint32_t* abortw = sync + (size_t)K * PERSIST_SYNC_STRIDE;
         constexpr uint32_t GAVE_UP = 0x80000000u;
-        const uint32_t G = gridDim.x;
         int ok = -1;
         if (__hip_atomic_fetch_add(roll, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & GAVE_UP) ok = 0;
         uint32_t spins = 0;
         while (ok < 0) {
             const uint32_t v = ld_u32_relaxed(roll);
             if (v & GAVE_UP) ok = 0;
-            else if (v >= G) ok = 1;
+            else if (v >= total) ok = 1;
             else if (++spins > PERSIST_ROLL_LIMIT) {
                 uint32_t expect = v;
                 if (__hip_atomic_compare_exchange_strong(roll, &expect, v | GAVE_UP, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -395,42 +391,79 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
         ldsw[1] = ok;
     }
     __syncthreads();
-    if (!ldsw[1]) return;
+    return ldsw[1] != 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The RESIDENT schedule (the default for small populations at R <= 16) is TWO kernels launched together on two streams of the
+// process, one per role, so that each role is compiled against its own register budget (as one kernel holding the resident
+// chain, the resident units and the streaming units, every instantiation paid for the union: 256 VGPRs, 256-384 B of scratch
+// and ~650 spilled SGPRs, round 2): k_pchain — K workgroups, the resident lean chain of candidate blockIdx.x — and
+// k_punits<NTR, X16, NU> — nres_wg workgroups of resident feature units.  They synchronise through the same per-candidate flag /
+// counter records; co-residency of ALL workgroups of both launches is what the roll call establishes (total = K + nres_wg).
+// ------------------------------------------------------------------------------------------------
+template <int MB>
+__global__ void __launch_bounds__(STEP_THREADS, 2) k_pchain(const PersistArgs a, const int lds_word) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
+    const int bid = (int)blockIdx.x, tid = threadIdx.x;
+    const int K = a.nchain;
+    uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
+    if (!persist_roll_call(a.sync, K, (uint32_t)(K + a.nres_wg), ldsw)) return;
+    const uint32_t need = (uint32_t)a.need[bid];
+    LeanRes rs;
+    lean_res_load<MB>(a.ca, bid, lds, rs);
+    for (int t = 0; t < a.T; ++t) {
+        const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
+        const int tr_base = (t - 8) * 8;
+        PTRACE(0);
+        if (!wg_wait_ge(PERSIST_CNT(a.sync, bid), need * (uint32_t)(t + 1), abortw, ldsw)) return;
+        PTRACE(1);
+        ChainStep cs;
+        cs.pos_t = a.pos0 + (int64_t)t * a.B;
+        cs.base_t = t * a.B;
+        cs.nvalid = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
+        cs.gstep = a.gstep0 + t;
+        cs.epoch = a.epoch;
+        cs.ss = a.scal[2 * (int64_t)cs.gstep];
+        cs.bc2s = a.scal[2 * (int64_t)cs.gstep + 1];
+        chain_lean<MB, 2>(a.ca, cs, bid, lds, &rs);
+        PTRACE(2);
+        wg_publish_barrier();
+        if (tid == 0 && !(bid == 0 && t == a.lose_step))
+            __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PTRACE(3);
+        chain_lean_tail<MB, 2>(a.ca, cs, bid, lds, &rs);   // statistics + vector-parameter Adam, after dy is out
+        lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the feature units run
+    }
+    lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs);
+}
+
+template <int MB, int NTR, bool X16, int NU>
+__global__ void __launch_bounds__(STEP_THREADS, 2) k_punits(const PersistArgs a, const int lds_word) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
+    if (!persist_roll_call(a.sync, a.nchain, (uint32_t)(a.nchain + a.nres_wg), ldsw)) return;
+    sweep_resident<MB, NTR, X16, NU>(a, (int)blockIdx.x, a.nres_wg, lds, ldsw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_persist — the STREAMING form (any R; forced only, MFAS_PERSIST=1: measured slower than launch-per-phase): blocks [0, K) run
+// the chains (lean MODE 1 or the general chain_body, everything exchanged through memory), the remaining blocks own the sweep
+// units (unit i -> workgroup i mod G, fixed for the launch) and stream their W/m/v like k_step.
+// ------------------------------------------------------------------------------------------------
+template <int MB, bool LEAN, int U>
+__global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a, const int lds_word) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
+    const int bid = (int)blockIdx.x, tid = threadIdx.x;
+    const int K = a.nchain;
+    uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
+    if (!persist_roll_call(a.sync, K, gridDim.x, ldsw)) return;
 
     if (bid < K) {
         // ------------------------------------------------------------------ chain workgroup of candidate `bid`
         const uint32_t need = (uint32_t)a.need[bid];
-        if constexpr (LEAN) {
-            if (a.res_chain) {   // resident lean chain: see chain.hip.h (MODE 2)
-                LeanRes rs;
-                lean_res_load<MB>(a.ca, bid, lds, rs);
-                for (int t = 0; t < a.T; ++t) {
-                    const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
-                    const int tr_base = (t - 8) * 8;
-                    PTRACE(0);
-                    if (!wg_wait_ge(PERSIST_CNT(a.sync, bid), need * (uint32_t)(t + 1), abortw, ldsw)) return;
-                    PTRACE(1);
-                    ChainStep cs;
-                    cs.pos_t = a.pos0 + (int64_t)t * a.B;
-                    cs.base_t = t * a.B;
-                    cs.nvalid = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
-                    cs.gstep = a.gstep0 + t;
-                    cs.epoch = a.epoch;
-                    cs.ss = a.scal[2 * (int64_t)cs.gstep];
-                    cs.bc2s = a.scal[2 * (int64_t)cs.gstep + 1];
-                    chain_lean<MB, 2>(a.ca, cs, bid, lds, &rs);
-                    PTRACE(2);
-                    wg_publish_barrier();
-                    if (tid == 0 && !(bid == 0 && t == a.lose_step))
-                        __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    PTRACE(3);
-                    chain_lean_tail<MB, 2>(a.ca, cs, bid, lds, &rs);   // statistics + vector-parameter Adam, after dy is out
-                    lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the sweep units run
-                }
-                lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs);
-                return;
-            }
-        }
         for (int t = 0; t < a.T; ++t) {
             const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
             const int tr_base = (t - 8) * 8;
@@ -449,7 +482,8 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
             else chain_body<MB, true, true>(a.ca, cs, bid, lds);
             PTRACE(2);
             wg_publish_barrier();
-            if (tid == 0) __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(bid == 0 && t == a.lose_step))
+                __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             PTRACE(3);
             if constexpr (LEAN) chain_lean_tail<MB, 1>(a.ca, cs, bid, lds);
         }
@@ -460,27 +494,14 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
     // ever re-read by the same CU, so they stay coherent without any fence.  A workgroup that owns several units serves
     // whichever of them is ready (its candidate's chain has published the step the unit is waiting for): units of different
     // candidates never block each other (in-order service convoys all candidates behind the slowest chain).
-    if (bid < K + a.nres_wg) {
-        const int rw = bid - K;
-        if (a.sa.tab.dtype == MFAS_DT_F32) {
-            if (a.res_nu == 2) sweep_resident<MB, PERSIST_NTR, false, 2>(a, rw, a.nres_wg, lds, ldsw);
-            else sweep_resident<MB, PERSIST_NTR, false, 1>(a, rw, a.nres_wg, lds, ldsw);
-        } else if (a.res_wide) {
-            sweep_resident<MB, PERSIST_NTR16, true, 1>(a, rw, a.nres_wg, lds, ldsw);
-        } else {
-            if (a.res_nu == 2) sweep_resident<MB, PERSIST_NTR, true, 2>(a, rw, a.nres_wg, lds, ldsw);
-            else sweep_resident<MB, PERSIST_NTR, true, 1>(a, rw, a.nres_wg, lds, ldsw);
-        }
-        return;
-    }
-    const int G = (int)gridDim.x - K - a.nres_wg, wg = bid - K - a.nres_wg;
-    const int n_gen = a.nitems - a.nres;      // units served by the generic (streaming) workgroups: [nres, nitems)
+    const int G = (int)gridDim.x - K, wg = bid - K;
+    const int n_gen = a.nitems;
     const int n_my = wg < n_gen ? (n_gen - wg + G - 1) / G : 0;   // <= PERSIST_MAX_UNITS (host)
     int* nxt = ldsw + 8;                     // next step of my j-th unit (-1 = the epoch's prologue: forward of batch 0, no update)
     int* cnd = ldsw + 8 + PERSIST_MAX_UNITS; // its candidate
     if (tid < n_my) {
         nxt[tid] = -1;
-        cnd[tid] = a.sa.desc[a.nres + wg + tid * G].cand;
+        cnd[tid] = a.sa.desc[wg + tid * G].cand;
     }
     __syncthreads();
     int last = n_my - 1;
@@ -510,7 +531,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a
         __syncthreads();
         const int pick = ldsw[0];
         if (pick < 0) return;
-        const int t = nxt[pick], cand = cnd[pick], it = a.nres + wg + pick * G;
+        const int t = nxt[pick], cand = cnd[pick], it = wg + pick * G;
         __syncthreads();   // everyone has read the pick before lane 0 can overwrite it
         last = pick;
         SweepStep st;
