@@ -147,12 +147,23 @@ int mfas_population_sweep_profile(const mfas_population* pop, int64_t* launches,
 int mfas_population_set_profiling(mfas_population* pop, int32_t on);
 
 /* (new) The step schedule this population was laid out for, so that a measurement can name the kernel it
- * timed: info[0] = 1 persistent step loop (k_persist, one launch per epoch) / 0 launch per phase (k_step / k_chain);
+ * timed: info[0] = 1 persistent step loop (k_president resident, or k_persist streaming; one launch per epoch) / 0 launch per phase (k_step / k_chain);
  * info[1] = feature units resident in registers; info[2] = their workgroups; info[3] = units per resident workgroup;
  * info[4] = 1 when the resident lean chain owns OUT/HEAD; info[5] = 1 lean chain (R <= 16); info[6] = candidate groups of the
  * launch-per-phase schedule (2 = fused A/B launches, 1 = chain and sweep back to back, -1 = one launch per step holding the chain
  * AND the sweep of the same candidates, released cell by cell through per-cell flags); info[7] = candidates. */
 int mfas_population_schedule(const mfas_population* pop, int32_t info[8]);
+
+/* (new, round 3) The same decision WITHOUT creating a population — a pure query, nothing is allocated or launched: would
+ * mfas_population_create(hp, confs, n_cells, ..., K, device, ..., chunk_cols) take the resident persistent schedule (every
+ * chain and every feature unit resident on its own CU slot, W/m/v in registers, one launch per epoch)?  The host plans
+ * resident ROUNDS with it (a share of a train_sampled_models call — /root/reference/models/search/ntu_searchable.py:38-94 trains
+ * the configurations one after the other — that is too large for one resident population is trained as several).
+ * info[0] = 1 resident persistent schedule / 0 launch per phase; info[1] = resident feature units; info[2] = their workgroups;
+ * info[3] = units per resident workgroup; info[4] = feature-column chunk; info[5] = 1 lean chain (R <= 16, C <= 64, B <= 32);
+ * info[6] = compute units of the device; info[7] = K. */
+int mfas_population_plan(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells, int32_t K, int32_t device,
+                         int32_t chunk_cols, int32_t info[8]);
 
 /* (new) Streaming ceiling of this device for the sweep's access pattern: three planes of `bytes_per_plane` are
  * read-modify-written in 1 KiB tiles with nontemporal 16 B/lane accesses and no compute; returns GB/s (read + write). */

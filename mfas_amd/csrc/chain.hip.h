@@ -1302,7 +1302,7 @@ __device__ __forceinline__ void lean_res_load(const ChainArgs& a, const int bid,
         if (live) t = *reinterpret_cast<const f32x4*>(a.wt + lean_own_toff(cd, s) + lane * 4);
         *reinterpret_cast<f32x4*>(ll.own + (3 * LEAN_OWN_TILES + s) * 256 + lane * 4) = t;
     }
-    rs.loss = 0.0; rs.corr = 0; rs.bad = 0;
+    if (tid == CHAIN_THREADS - 64) { rs.loss = 0.0; rs.corr = 0; rs.bad = 0; }     // (rs may live in LDS: one writer, the lane that accumulates)
     __syncthreads();
 }
 

@@ -152,9 +152,9 @@ struct mfas_population {
     SegDesc* d_pdescs = nullptr;    // persistent schedule's unit list: [resident feature units | streamed units]
     int n_pdescs = 0;
     size_t lds_persist = 0;         // streaming form (k_persist)
-    size_t lds_pchain = 0, lds_punits = 0;   // resident form: k_pchain / k_punits
-    hipStream_t stream2 = nullptr;  // resident form: the feature units' launch runs beside the chains' launch
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    size_t lds_president = 0;       // resident form (k_president)
+    int chunk_cols_req = 0;         // chunk_cols the caller asked for at creation (the fallback layout is built with the same request)
+    int fell_back = 0;              // the resident schedule was given up for launch-per-phase inside a train() call (roll call never complete)
     uint32_t* d_sync = nullptr;     // [K] flags | [K] counters | abort word (zeroed before every launch)
     int32_t* d_need = nullptr;      // [K] sweep units per candidate
     float* d_scal = nullptr;        // device copy of the step scalars
@@ -184,6 +184,113 @@ static hipError_t set_lds(KT kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Layout plan: which column chunk the feature segments are cut into and whether the population takes the RESIDENT persistent
+// schedule (k_president: every chain and every feature unit resident, W/m/v in registers) — a pure function of the
+// geometry, the configurations and the CU count; no allocation.  create_impl() lays the population out from it and
+// mfas_population_plan() answers it on its own (the host's capacity planning, ntu_searchable._plan_rounds).
+// ------------------------------------------------------------------------------------------------
+struct LayoutPlan {
+    bool want_persist = false, force_persist = false;
+    int target = 0, nu = 1;          // feature-column chunk (0: the launch-per-phase heuristics of create_impl decide), units per resident workgroup
+    bool plan_res = false;           // the chunk was chosen for the resident schedule
+    int nfeat = 0, max_fcc = 0;      // feature units and the widest of them at that chunk
+    bool res_ok = false, res_wide = false, lean_ok = false;
+    int nres_wg = 0;
+    bool resident = false;           // the resident persistent schedule runs (before the byte-size limits, which no resident population reaches)
+};
+
+static size_t plan_res_lds(const mfas_hyper* hp, const Geo& g, int cc, int nu) {
+    // LDS of a resident workgroup: nu units x 2 staged batches (raw 16-bit rows when the caller promised 16-bit taps, f32 rows
+    // otherwise) + the cross-wave reduction slabs + the loop's own words
+    const size_t batch = hp->tap_bits == 16 ? (size_t)g.Bp * (cc + 8) * 2 : (size_t)g.Bp * (cc + 4) * 4;
+    return (size_t)nu * 2 * batch + (size_t)STEP_NW * g.MB * 256 * 4 + 4 * PERSIST_LDS_WORDS + 64;
+}
+
+static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs, const int32_t* n_cells, int K, int chunk_cols,
+                        int n_cus, bool allow_persist, LayoutPlan& lp) {
+    // A workgroup should stream >= ~64 tiles (amortises staging / reduction and keeps the number of partial-sum chunks the
+    // chain has to reduce small), the launch should still have a few hundred workgroups, and x_t / x_{t+1} for the chunk must
+    // fit the LDS budget.
+    // Persistent step loop (persist.hip.h): with one row block (R <= 16) the feature units become RESIDENT (one workgroup per
+    // unit, or two units per workgroup; W/m/v in registers): the column chunk is then the smallest of 128 / 256 / 512 / 1024
+    // columns with which every chain and every unit workgroup gets a CU of its own.
+    // Default (measured, profiles/r02_popsweep_*.log): ON where the resident form fits (x1.6-2.1 over the launch-per-phase
+    // schedule at 4..28 candidates per GPU); the streaming form (larger R, or units that do not fit) is slower than
+    // launch-per-phase (x0.8-0.9) and only runs when forced.  MFAS_PERSIST=1/0 overrides.
+    lp.want_persist = allow_persist;
+    if (const char* e = getenv("MFAS_PERSIST")) { lp.want_persist = allow_persist && atoi(e) != 0; lp.force_persist = lp.want_persist; }
+    // (lean-chain feasibility, same formula as the LDS budget in create_impl: resident units exist only together with the resident
+    // lean chain — k_president; everything else that is forced persistent runs the streaming form)
+    const size_t lean_bytes = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
+                               + (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.MB * 256 + (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp)
+                               + LEAN_SCR + 8) * 4;
+    lp.lean_ok = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean_bytes <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
+    lp.plan_res = lp.want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT") && !getenv("MFAS_PERSIST_NO_RES_CHAIN") && lp.lean_ok;
+    auto feat_units = [&](int cc_target, int* max_cc) {
+        int64_t n = 0;
+        int mx = 0;
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < n_cells[k] && i < MFAS_MAX_CELLS; ++i) {
+                const int sw = ceil16(hp->s_sizes[confs[(k * 4 + i) * 3] & 7]), vw = ceil16(hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 7]);
+                const int cs = pick_chunk(sw, cc_target), cv = pick_chunk(vw, cc_target);
+                n += sw / cs + vw / cv;
+                mx = std::max(mx, std::max(cs, cv));
+            }
+        if (max_cc) *max_cc = mx;
+        return n;
+    };
+    auto res_fits = [&](int cc, int nu, int64_t units) {
+        return (cc <= 128 * PERSIST_NTR || (hp->tap_bits == 16 && nu == 1 && cc <= 128 * PERSIST_NTR16)) &&
+               plan_res_lds(hp, g, cc, nu) <= 160 * 1024 && K + (units + nu - 1) / nu <= n_cus;
+    };
+    lp.target = chunk_cols;
+    lp.nu = 1;
+    if (lp.plan_res && lp.target <= 0) {
+        // smallest units first (fewest tiles per wave on the critical path); two units per workgroup before 1024-column units
+        // (measured: 16 candidates, 1024-column units: 34.8 us per step)
+        // (two 256-column units per workgroup before one 512-column unit: 9..15 candidates 15.7-16.2 vs 18.0-18.7 us per step)
+        const int opts[6][2] = {{128, 1}, {256, 1}, {256, 2}, {512, 1}, {512, 2}, {1024, 1}};
+        int pick = -1;
+        for (int o = 0; o < 6 && pick < 0; ++o)
+            if (res_fits(opts[o][0], opts[o][1], feat_units(opts[o][0], nullptr))) pick = o;
+        if (pick >= 0) { lp.target = opts[pick][0]; lp.nu = opts[pick][1]; }
+        else lp.plan_res = false;
+    } else if (lp.plan_res) {
+        const int64_t units = feat_units(lp.target, nullptr);
+        if (res_fits(lp.target, 1, units)) lp.nu = 1;
+        else if (res_fits(lp.target, 2, units)) lp.nu = 2;
+        else lp.plan_res = false;
+    }
+    if (lp.target <= 0) {
+        double tot_cols = 0;
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < n_cells[k] && i < MFAS_MAX_CELLS; ++i)
+                tot_cols += ceil16(hp->s_sizes[confs[(k * 4 + i) * 3] & 7]) + ceil16(hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 7]);
+        int lds_max = 64;                                   // largest power of two with Bp*(2cc+20)*4 <= 72 KiB
+        while ((size_t)g.Bp * (8 * lds_max + 20) * 4 <= 72 * 1024 && lds_max < 1024) lds_max <<= 1;   // test the doubled size
+        int target = 64;
+        while (target * g.nrb < 64 * 16 && target < lds_max) target <<= 1;      // >= 64 tiles per workgroup
+        while (target > 64 && tot_cols / target < 320.0) target >>= 1;           // ... but keep >= ~320 workgroups
+        // R >= 128, measured on MI355X (DESIGN.md §5): 64-column chunks (finer, better-balanced workgroups) win once
+        // the chain is hidden under the other group's sweep (K >= 20); below that fewer partial chunks matter more
+        // (round 2: with reduce-in-sweep the number of partial slabs no longer loads the chain; 256-column chunks stay best up
+        // to ~28 candidates, 64 beyond — profiles/r02_popsweep_r128.log)
+        if (g.nrb >= 8) target = std::min(target, K >= 28 ? 64 : 256);
+        lp.target = target;
+    }
+    lp.target = std::max(16, (lp.target / 16) * 16);
+    {
+        int mx = 0;
+        lp.nfeat = (int)feat_units(lp.target, &mx);
+        lp.max_fcc = mx;
+    }
+    lp.res_ok = lp.plan_res && res_fits(lp.max_fcc, lp.nu, lp.nfeat);
+    lp.res_wide = lp.res_ok && lp.max_fcc > 128 * PERSIST_NTR;      // 16-bit staging only
+    lp.nres_wg = lp.res_ok ? (lp.nfeat + lp.nu - 1) / lp.nu : 0;
+    lp.resident = lp.want_persist && lp.res_ok && K <= n_cus / 4 && g.MB != 4 && K + lp.nres_wg <= n_cus;
+}
+
 #define MFAS_RETRY_NO_PERSIST 12345   // internal: the layout was planned for the resident persistent schedule, which then did not fit
 
 static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells,
@@ -209,6 +316,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     p->K = K;
     p->device = device;
     p->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    p->chunk_cols_req = chunk_cols;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete p; return fail(MFAS_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
 
@@ -230,84 +338,17 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     g.f1_th = (float)hp->f1_threshold;
     const int vec_size = (g.vec_head + g.Cp + 63) & ~63;
 
-    // ---- column chunk per workgroup.  A workgroup should stream >= ~64 tiles (amortises staging / reduction and
-    // keeps the number of partial-sum chunks the chain has to reduce small), the launch should still have a few
-    // hundred workgroups, and x_t / x_{t+1} for the chunk must fit the LDS budget.
-    // ---- persistent step loop (persist.hip.h): wanted?  With one row block (R <= 16) the feature units become RESIDENT
-    // (one workgroup per unit, W/m/v in registers): the column chunk is then the smallest of 128 / 256 / 512 columns with
-    // which every chain, every unit and one streaming workgroup per candidate (OUT / HEAD) get a CU of their own.
-    // Default (measured, profiles/r02_popsweep_*.log): ON where the resident form fits (R <= 16, every chain and feature unit on
-    // its own CU: x1.14-1.3 over the launch-per-phase schedule at 4..12 candidates per GPU); the streaming form (larger R, or
-    // units that do not fit) is slower than launch-per-phase (x0.8-0.9) and only runs when forced.  MFAS_PERSIST=1/0 overrides.
-    bool want_persist = allow_persist, force_persist = false;
-    if (const char* e = getenv("MFAS_PERSIST")) { want_persist = allow_persist && atoi(e) != 0; force_persist = want_persist; }
+    // ---- column chunk per workgroup and the schedule (plan_layout: the same pure decision mfas_population_plan answers)
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
         p->n_cus = ncu;
     }
-    // (lean-chain feasibility, same formula as the LDS budget below: the resident form is only planned by default when the
-    // resident lean chain will run with it, otherwise the unit size chosen for it would be wrong for the fallback schedule)
-    const size_t lean_bytes_early = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
-                                     + (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.MB * 256 + (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp)
-                                     + LEAN_SCR + 8) * 4;
-    const bool lean_ok_early = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean_bytes_early <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
-    // (resident units exist only together with the resident lean chain — k_pchain + k_punits; everything else that is forced
-    //  persistent runs the streaming form)
-    bool plan_res = want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT") && !getenv("MFAS_PERSIST_NO_RES_CHAIN") && lean_ok_early;
-    auto count_feat_units = [&](int cc_target) {
-        int64_t n = 0;
-        for (int k = 0; k < K; ++k)
-            for (int i = 0; i < n_cells[k] && i < MFAS_MAX_CELLS; ++i) {
-                const int sw = ceil16(hp->s_sizes[confs[(k * 4 + i) * 3] & 7]), vw = ceil16(hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 7]);
-                n += sw / pick_chunk(sw, cc_target) + vw / pick_chunk(vw, cc_target);
-            }
-        return n;
-    };
-    // LDS of a resident workgroup: nu units x 2 staged batches (raw 16-bit rows when the caller promised 16-bit taps, f32 rows
-    // otherwise) + the cross-wave reduction slabs + the loop's own words
-    auto res_lds = [&](int cc, int nu) {
-        const size_t batch = hp->tap_bits == 16 ? (size_t)g.Bp * (cc + 8) * 2 : (size_t)g.Bp * (cc + 4) * 4;
-        return (size_t)nu * 2 * batch + (size_t)STEP_NW * g.MB * 256 * 4 + 4 * PERSIST_LDS_WORDS + 64;
-    };
-    auto res_fits = [&](int cc, int nu, int64_t units) {
-        return (cc <= 128 * PERSIST_NTR || (hp->tap_bits == 16 && nu == 1 && cc <= 128 * PERSIST_NTR16)) &&
-               res_lds(cc, nu) <= 160 * 1024 && K + (units + nu - 1) / nu <= p->n_cus;
-    };
-    int target = chunk_cols;
-    int plan_nu = 1;
-    if (plan_res && target <= 0) {
-        // smallest units first (fewest tiles per wave on the critical path); two units per workgroup before 1024-column units
-        // (measured: 16 candidates, 1024-column units: 34.8 us per step)
-        // (two 256-column units per workgroup before one 512-column unit: 9..15 candidates 15.7-16.2 vs 18.0-18.7 us per step)
-        const int opts[6][2] = {{128, 1}, {256, 1}, {256, 2}, {512, 1}, {512, 2}, {1024, 1}};
-        int pick = -1;
-        for (int o = 0; o < 6 && pick < 0; ++o)
-            if (res_fits(opts[o][0], opts[o][1], count_feat_units(opts[o][0]))) pick = o;
-        if (pick >= 0) { target = opts[pick][0]; plan_nu = opts[pick][1]; }
-        else plan_res = false;
-    } else if (plan_res) {
-        const int64_t units = count_feat_units(target);
-        if (res_fits(target, 1, units)) plan_nu = 1;
-        else if (res_fits(target, 2, units)) plan_nu = 2;
-        else plan_res = false;
-    }
-    if (target <= 0) {
-        double tot_cols = 0;
-        for (int k = 0; k < K; ++k)
-            for (int i = 0; i < n_cells[k]; ++i)
-                tot_cols += ceil16(hp->s_sizes[confs[(k * 4 + i) * 3] & 7]) + ceil16(hp->v_sizes[confs[(k * 4 + i) * 3 + 1] & 7]);
-        int lds_max = 64;                                   // largest power of two with Bp*(2cc+20)*4 <= 72 KiB
-        while ((size_t)g.Bp * (8 * lds_max + 20) * 4 <= 72 * 1024 && lds_max < 1024) lds_max <<= 1;   // test the doubled size
-        target = 64;
-        while (target * g.nrb < 64 * 16 && target < lds_max) target <<= 1;      // >= 64 tiles per workgroup
-        while (target > 64 && tot_cols / target < 320.0) target >>= 1;           // ... but keep >= ~320 workgroups
-        // R >= 128, measured on MI355X (DESIGN.md §5): 64-column chunks (finer, better-balanced workgroups) win once
-        // the chain is hidden under the other group's sweep (K >= 20); below that fewer partial chunks matter more
-        // (round 2: with reduce-in-sweep the number of partial slabs no longer loads the chain; 256-column chunks stay best up
-        // to ~28 candidates, 64 beyond — profiles/r02_popsweep_r128.log)
-        if (g.nrb >= 8) target = std::min(target, K >= 28 ? 64 : 256);
-    }
+    LayoutPlan lp;
+    plan_layout(hp, g, confs, n_cells, K, chunk_cols, p->n_cus, allow_persist, lp);
+    const bool want_persist = lp.want_persist, force_persist = lp.force_persist;
+    int target = lp.target;
+    const int plan_nu = lp.nu;
     target = std::max(16, (target / 16) * 16);
     p->cands.resize(K);
     p->desc_start.assign(K + 1, 0);
@@ -439,13 +480,13 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         int nfeat = 0, max_fcc = 0;
         for (const SegDesc& d : p->descs)
             if (d.kind <= KIND_V) { ++nfeat; max_fcc = std::max(max_fcc, d.cc); }
-        const bool wide = max_fcc > 128 * PERSIST_NTR;      // 16-bit staging only
-        const size_t lds_res = res_lds(max_fcc, plan_nu);
-        const bool res_ok = plan_res && res_fits(max_fcc, plan_nu, nfeat);
-        p->res_wide = res_ok && wide;
+        if (nfeat != lp.nfeat || max_fcc != lp.max_fcc) { delete p; return fail(MFAS_EINVAL, "internal: layout plan and descriptors disagree"); }
+        const size_t lds_res = plan_res_lds(hp, g, max_fcc, plan_nu);
+        const bool res_ok = lp.res_ok;
+        p->res_wide = lp.res_wide;
         p->nres = res_ok ? nfeat : 0;
         p->res_nu = plan_nu;
-        p->nres_wg = res_ok ? (nfeat + plan_nu - 1) / plan_nu : 0;
+        p->nres_wg = lp.nres_wg;
         p->res_buf_words = (int)((hp->tap_bits == 16 ? (size_t)g.Bp * (max_fcc + 8) * 2 : (size_t)g.Bp * (max_fcc + 4) * 4) / 4);
         size_t ls = 0;
         for (const SegDesc& d : p->descs) {
@@ -478,8 +519,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         }
         const size_t lds_rchain = p->res_chain ? p->lds_chain + 16 + 4 * (size_t)LeanLds<1>::own_floats() : 0;
         p->lds_persist = ((std::max(p->lds_step, p->lds_chain) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
-        p->lds_pchain = ((lds_rchain + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
-        p->lds_punits = ((lds_res + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
+        p->lds_president = ((std::max(lds_rchain, lds_res) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
     }
     p->nrbw = (g.nrb + 3) / 4;
     if (p->nrbw == 3) p->nrbw = 4;
@@ -677,16 +717,11 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             CREATE_CHK(hipMemset(p->d_trace, 0, sizeof(unsigned long long) * 256));
         }
         if (p->res_chain) {
-            CREATE_CHK(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
-            CREATE_CHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-            CREATE_CHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-            CREATE_CHK(set_lds((k_pchain<1>), p->lds_pchain));
-            CREATE_CHK(set_lds((k_pchain<2>), p->lds_pchain));
-#define SET_UNITS(M) CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR, false, 1>), p->lds_punits)); CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR, false, 2>), p->lds_punits)); \
-                     CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR16, true, 1>), p->lds_punits)); CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR, true, 1>), p->lds_punits)); \
-                     CREATE_CHK(set_lds((k_punits<M, PERSIST_NTR, true, 2>), p->lds_punits))
-            SET_UNITS(1); SET_UNITS(2);
-#undef SET_UNITS
+#define SET_RES(M) CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 1>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 2>), p->lds_president)); \
+                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR16, true, 1>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 1>), p->lds_president)); \
+                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2>), p->lds_president))
+            SET_RES(1); SET_RES(2);
+#undef SET_RES
         } else {
             CREATE_CHK(set_lds((k_persist<1, false, 2>), p->lds_persist));
             CREATE_CHK(set_lds((k_persist<2, false, 2>), p->lds_persist));
@@ -710,14 +745,37 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
     return rc;
 }
 
+// The layout / schedule decision of mfas_population_create for these configurations WITHOUT creating anything (no allocation, no
+// launch): the host's capacity planning (how many candidates one resident round can hold) asks this instead of building and
+// destroying populations.
+extern "C" int mfas_population_plan(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells, int32_t K, int32_t device,
+                                    int32_t chunk_cols, int32_t info[8]) {
+    if (!hp || !confs || !n_cells || !info || K <= 0) return fail(MFAS_EINVAL, "null argument or K <= 0");
+    if (hp->R < 1 || hp->R > 512 || hp->C < 1 || hp->C > 256 || hp->B < 2 || hp->B > 64) return fail(MFAS_EINVAL, "R / C / batchsize out of range");
+    Geo g;
+    memset(&g, 0, sizeof(g));
+    g.R = hp->R; g.C = hp->C; g.Rp = ceil16(hp->R); g.Cp = ceil16(hp->C);
+    g.nrb = g.Rp / 16; g.ncb = g.Cp / 16; g.B = hp->B;
+    g.MB = (hp->B + 15) / 16; if (g.MB == 3) g.MB = 4;
+    g.Bp = g.MB * 16;
+    g.alphas = hp->alphas != 0;
+    g.vec_cell_stride = 5 * g.Rp + 16;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+    LayoutPlan lp;
+    plan_layout(hp, g, confs, n_cells, K, chunk_cols, ncu, true, lp);
+    if (!lp.resident && lp.plan_res)      // the resident chunking does not stand: what create would fall back to (launch per phase)
+        plan_layout(hp, g, confs, n_cells, K, chunk_cols, ncu, false, lp);
+    info[0] = lp.resident ? 1 : 0; info[1] = lp.resident ? lp.nfeat : 0; info[2] = lp.resident ? lp.nres_wg : 0; info[3] = lp.nu;
+    info[4] = lp.target; info[5] = lp.lean_ok ? 1 : 0; info[6] = ncu; info[7] = K;
+    return MFAS_OK;
+}
+
 extern "C" void mfas_population_destroy(mfas_population* p) {
     if (!p) return;
     hipSetDevice(p->device);
     hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->ev) hipEventDestroy(e);
-    if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
-    if (p->ev_fork) hipEventDestroy(p->ev_fork);
-    if (p->ev_join) hipEventDestroy(p->ev_join);
     hipFree(p->plane); hipFree(p->wt); hipFree(p->stepbuf); hipFree(p->best);
     for (auto& gr : p->groups) { hipFree(gr.d_descs); hipFree(gr.d_taps); }
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
@@ -809,6 +867,75 @@ static hipError_t launch_eval(mfas_population* p, const EvalArgs& a, int ncand, 
     return hipErrorInvalidValue;
 }
 
+// The resident persistent schedule needs every workgroup of its two launches on the GPU at the same time.  When that cannot be
+// had — another process keeps CUs busy for good, the device is CU-masked, a tool serialises the two launches — the roll call fails
+// BEFORE anything of the epoch has run (abort code 2), so the state in memory is that of the last completed epoch: rebuild the
+// population in its launch-per-phase layout, carry W / m / v (+ the best-epoch snapshot) across through the reference's flat
+// parameter order, and go on from the same epoch.  The handle keeps its identity: the two records swap contents.
+static int persist_fallback(mfas_population* p) {
+    const int K = p->K;
+    std::vector<int32_t> confs((size_t)K * 12, 0), ncells(K);
+    std::vector<uint32_t> seeds(K);
+    int64_t maxp = 0;
+    for (int k = 0; k < K; ++k) {
+        const CandDev& c = p->cands[k];
+        ncells[k] = c.L;
+        seeds[k] = c.drop_seed;
+        for (int i = 0; i < c.L; ++i)
+            for (int j = 0; j < 3; ++j) confs[(k * 4 + i) * 3 + j] = c.conf[i][j];
+        maxp = std::max(maxp, p->nparams[k]);
+    }
+    mfas_population* q = nullptr;
+    int rc = create_impl(&p->hp, confs.data(), ncells.data(), seeds.data(), K, p->device, p->stream, p->chunk_cols_req, &q, false);
+    if (rc) return rc;
+    float* flat = nullptr;
+    hipError_t e = hipMalloc(&flat, sizeof(float) * (size_t)maxp);
+    if (e != hipSuccess) { mfas_population_destroy(q); return fail(MFAS_ENOMEM, "persist_fallback: scratch"); }
+    if (p->best && !q->best) {
+        e = hipMalloc(&q->best, sizeof(float) * (size_t)q->plane_stride);
+        if (e == hipSuccess) e = hipMemsetAsync(q->best, 0, sizeof(float) * (size_t)q->plane_stride, p->stream);
+        if (e != hipSuccess) { hipFree(flat); mfas_population_destroy(q); return fail(MFAS_ENOMEM, "persist_fallback: snapshot"); }
+    }
+    auto move = [&](int k, float* src_plane, int src_sel, float* dst_plane, int dst_sel, int mode, bool with_wt) {
+        PackArgs a = pack_args(p, PK_GET, src_sel, flat);
+        a.plane = src_plane;
+        a.desc = p->d_descs + p->desc_start[k];
+        hipMemsetAsync(flat, 0, sizeof(float) * p->nparams[k], p->stream);
+        hipLaunchKernelGGL(k_pack, dim3(p->desc_start[k + 1] - p->desc_start[k]), dim3(256), 0, p->stream, a);
+        hipLaunchKernelGGL(k_vec, dim3(1), dim3(256), 0, p->stream, a, k);
+        PackArgs b = pack_args(q, mode, dst_sel, flat);
+        b.plane = dst_plane;
+        if (!with_wt) b.wt = nullptr;
+        b.desc = q->d_descs + q->desc_start[k];
+        hipLaunchKernelGGL(k_pack, dim3(q->desc_start[k + 1] - q->desc_start[k]), dim3(256), 0, p->stream, b);
+        hipLaunchKernelGGL(k_vec, dim3(1), dim3(256), 0, p->stream, b, k);
+    };
+    for (int k = 0; k < K; ++k) {
+        move(k, p->plane, 0, q->plane, 0, PK_SET, true);        // W (+ transposed OUT / HEAD images), zeroes m / v
+        move(k, p->plane, 1, q->plane, 1, PK_PUT, false);       // Adam first moment
+        move(k, p->plane, 2, q->plane, 2, PK_PUT, false);       // Adam second moment
+        if (p->best) move(k, p->best, 0, q->best, 0, PK_PUT, false);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(q->d_posw, p->d_posw, sizeof(float) * p->g.Cp, hipMemcpyDeviceToDevice, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(q->d_status, p->d_status, sizeof(int32_t) * K, hipMemcpyDeviceToDevice, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    hipFree(flat);
+    if (e != hipSuccess) { mfas_population_destroy(q); return fail(MFAS_EHIP, std::string("persist_fallback: ") + hipGetErrorString(e)); }
+    std::swap(q->d_stats, p->d_stats);
+    std::swap(q->stats_cap, p->stats_cap);
+    std::swap(q->d_scal, p->d_scal);
+    std::swap(q->scal_cap, p->scal_cap);
+    q->best_threshold = p->best_threshold;
+    q->profiling = p->profiling;
+    q->prof_every = p->prof_every;
+    q->ev.swap(p->ev);
+    q->fell_back = 1;
+    std::swap(*p, *q);
+    mfas_population_destroy(q);      // the resident layout
+    return MFAS_OK;
+}
+
 extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train, const mfas_table* dev,
                                      const int32_t* order, const float* step_scalars, int32_t epochs,
                                      int64_t max_steps, int32_t snapshot_best, mfas_epoch_stats* stats,
@@ -852,19 +979,25 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     ac.eps = (float)hp.adam_eps; ac.wd = (float)hp.wd; ac.ss = 0.f; ac.bc2s = 1.f;
 
     // Candidate groups A/B: every launch pairs the sweep of one group with the chain of the other (k_step).
-    const int NG = (int)p->groups.size();
+    int NG = 0;
     StepArgs st;
-    memset(&st, 0, sizeof(st));
-    st.sa.cands = p->d_cands; st.sa.plane = p->plane; st.sa.plane_stride = p->plane_stride; st.sa.wt = p->wt;
-    st.sa.stepbuf = p->stepbuf; st.sa.tab = *train; st.sa.order = order; st.sa.g = g; st.sa.ac = ac;
-    st.ca.plane = p->plane; st.ca.plane_stride = p->plane_stride; st.ca.wt = p->wt; st.ca.stepbuf = p->stepbuf;
-    st.ca.tab = *train; st.ca.order = order; st.ca.E = epochs; st.ca.g = g; st.ca.stats = p->d_stats;
-    st.ca.status = p->d_status; st.ca.ac = ac; st.ca.yf_in_lds = p->yf_in_lds ? 1 : 0; st.ca.pos_w = p->d_posw;
-    st.ca.vec_in_lds = p->vec_in_lds ? 1 : 0;
-    st.sa.red_cnt = p->red_in_sweep ? p->d_red_cnt : nullptr;
-    st.ca.yf_reduced = p->red_in_sweep ? 1 : 0;
-    if (p->red_in_sweep) HIPCHK(hipMemsetAsync(p->d_red_cnt, 0, sizeof(uint32_t) * K * MFAS_MAX_CELLS, p->stream));
-    if (p->same_group) HIPCHK(hipMemsetAsync(p->d_cellflag, 0, sizeof(uint32_t) * K * CELLFLAG_STRIDE, p->stream));
+    auto init_args = [&]() -> hipError_t {     // (again after persist_fallback: the population's buffers and layout have changed)
+        NG = (int)p->groups.size();
+        memset(&st, 0, sizeof(st));
+        st.sa.cands = p->d_cands; st.sa.plane = p->plane; st.sa.plane_stride = p->plane_stride; st.sa.wt = p->wt;
+        st.sa.stepbuf = p->stepbuf; st.sa.tab = *train; st.sa.order = order; st.sa.g = p->g; st.sa.ac = ac;
+        st.ca.plane = p->plane; st.ca.plane_stride = p->plane_stride; st.ca.wt = p->wt; st.ca.stepbuf = p->stepbuf;
+        st.ca.tab = *train; st.ca.order = order; st.ca.E = epochs; st.ca.g = p->g; st.ca.stats = p->d_stats;
+        st.ca.status = p->d_status; st.ca.ac = ac; st.ca.yf_in_lds = p->yf_in_lds ? 1 : 0; st.ca.pos_w = p->d_posw;
+        st.ca.vec_in_lds = p->vec_in_lds ? 1 : 0;
+        st.sa.red_cnt = p->red_in_sweep ? p->d_red_cnt : nullptr;
+        st.ca.yf_reduced = p->red_in_sweep ? 1 : 0;
+        hipError_t e_ = hipSuccess;
+        if (p->red_in_sweep) e_ = hipMemsetAsync(p->d_red_cnt, 0, sizeof(uint32_t) * K * MFAS_MAX_CELLS, p->stream);
+        if (e_ == hipSuccess && p->same_group) e_ = hipMemsetAsync(p->d_cellflag, 0, sizeof(uint32_t) * K * CELLFLAG_STRIDE, p->stream);
+        return e_;
+    };
+    HIPCHK(init_args());
 
     const int elt = train->dtype == MFAS_DT_F32 ? 4 : 2;
     p->prof_launches = 0; p->prof_ms = 0.0; p->prof_bytes = 0.0;
@@ -963,7 +1096,10 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         HIPCHK(hipMemcpyAsync(p->d_scal, step_scalars, sizeof(float) * have, hipMemcpyHostToDevice, p->stream));
     }
     // one persistent launch = all train steps of one epoch (persist.hip.h)
+    const int test_not_resident = getenv("MFAS_PERSIST_TEST_NOT_RESIDENT") ? atoi(getenv("MFAS_PERSIST_TEST_NOT_RESIDENT")) : -1;   // test hook: from
+                                                                           // this epoch on every roll call "fails" (nothing is launched)
     auto persist_epoch_once = [&](int ep, int64_t T) -> hipError_t {
+        if (test_not_resident >= 0 && ep >= test_not_resident) { aborts[ep] = PERSIST_ABORT_NOT_RESIDENT; return hipSuccess; }
         hipError_t e = hipMemsetAsync(p->d_sync, 0, sizeof(uint32_t) * ((size_t)K * PERSIST_SYNC_STRIDE + 64), p->stream);
         if (e != hipSuccess) return e;
         PersistArgs pa;
@@ -991,29 +1127,15 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             }
             hipEventRecord(p->ev[ev_used], p->stream);
         }
-        if (p->res_chain) {
-            // resident form: the chains' launch on the caller's stream, the feature units' launch beside it on stream2 (fork / join
-            // through events: stream2 starts after everything queued so far, the caller's stream continues after both)
-            e = hipEventRecord(p->ev_fork, p->stream);
-            if (e != hipSuccess) return e;
-            e = hipStreamWaitEvent(p->stream2, p->ev_fork, 0);
-            if (e != hipSuccess) return e;
-            const int lw_c = (int)(p->lds_pchain / 4) - PERSIST_LDS_WORDS, lw_u = (int)(p->lds_punits / 4) - PERSIST_LDS_WORDS;
-            if (g.MB == 1) hipLaunchKernelGGL((k_pchain<1>), dim3(K), dim3(STEP_THREADS), p->lds_pchain, p->stream, pa, lw_c);
-            else hipLaunchKernelGGL((k_pchain<2>), dim3(K), dim3(STEP_THREADS), p->lds_pchain, p->stream, pa, lw_c);
-#define UNITS_LAUNCH(M, NTR, X, NU) hipLaunchKernelGGL((k_punits<M, NTR, X, NU>), dim3(pa.nres_wg), dim3(STEP_THREADS), p->lds_punits, p->stream2, pa, lw_u)
-#define UNITS_PICK(M) do { if (train->dtype == MFAS_DT_F32) { if (pa.res_nu == 2) UNITS_LAUNCH(M, PERSIST_NTR, false, 2); else UNITS_LAUNCH(M, PERSIST_NTR, false, 1); } \
-                           else if (pa.res_wide) UNITS_LAUNCH(M, PERSIST_NTR16, true, 1); \
-                           else if (pa.res_nu == 2) UNITS_LAUNCH(M, PERSIST_NTR, true, 2); else UNITS_LAUNCH(M, PERSIST_NTR, true, 1); } while (0)
-            if (g.MB == 1) UNITS_PICK(1); else UNITS_PICK(2);
-#undef UNITS_PICK
-#undef UNITS_LAUNCH
-            e = hipGetLastError();
-            if (e != hipSuccess) return e;
-            e = hipEventRecord(p->ev_join, p->stream2);
-            if (e != hipSuccess) return e;
-            e = hipStreamWaitEvent(p->stream, p->ev_join, 0);
-            if (e != hipSuccess) return e;
+        if (p->res_chain) {      // resident form: one instantiation per unit form
+            const int lw = (int)(p->lds_president / 4) - PERSIST_LDS_WORDS;
+#define RES_LAUNCH(M, NTR, X, NU) hipLaunchKernelGGL((k_president<M, NTR, X, NU>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw)
+#define RES_PICK(M) do { if (train->dtype == MFAS_DT_F32) { if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, false, 2); else RES_LAUNCH(M, PERSIST_NTR, false, 1); } \
+                         else if (pa.res_wide) RES_LAUNCH(M, PERSIST_NTR16, true, 1); \
+                         else if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, true, 2); else RES_LAUNCH(M, PERSIST_NTR, true, 1); } while (0)
+            if (g.MB == 1) RES_PICK(1); else RES_PICK(2);
+#undef RES_PICK
+#undef RES_LAUNCH
         } else {
 #define PERSIST_LAUNCH(M, F) hipLaunchKernelGGL((k_persist<M, F, 2>), dim3(grid), dim3(STEP_THREADS), p->lds_persist, p->stream, pa, ldsw)
         if (p->lean_chain) { if (g.MB == 1) PERSIST_LAUNCH(1, true); else PERSIST_LAUNCH(2, true); }
@@ -1031,16 +1153,19 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         if (e != hipSuccess) return e;
         return hipMemcpyAsync(&aborts[ep], p->d_sync + (size_t)K * PERSIST_SYNC_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
     };
-    // The launch is only valid when its whole grid is resident at once (roll call in k_persist).  When another process holds
+    // The launch is only valid when its whole grid is resident at once (roll call, persist.hip.h).  When another process holds
     // part of the GPU the roll call fails BEFORE anything is modified (abort code 2): wait a little (jittered, so that two
-    // processes that collided do not collide again in lockstep) and launch the epoch again.
+    // processes that collided do not collide again in lockstep) and launch the epoch again — up to PERSIST_MAX_RELAUNCHES times
+    // (~0.3 s of trying); after that the caller gives the resident schedule up for this population (persist_fallback).
     auto persist_epoch = [&](int ep, int64_t T) -> hipError_t {
         for (int attempt = 0;; ++attempt) {
             hipError_t e = persist_epoch_once(ep, T);
             if (e != hipSuccess) return e;
             e = hipStreamSynchronize(p->stream);
             if (e != hipSuccess) return e;
-            if (aborts[ep] != PERSIST_ABORT_NOT_RESIDENT || attempt >= 400) {
+            if (getenv("MFAS_PERSIST_VERBOSE") && atoi(getenv("MFAS_PERSIST_VERBOSE")) >= 2)
+                fprintf(stderr, "[persist] epoch %d attempt %d: abort word %u\n", ep, attempt, aborts[ep]);
+            if (aborts[ep] != PERSIST_ABORT_NOT_RESIDENT || attempt >= PERSIST_MAX_RELAUNCHES || test_not_resident >= 0) {
                 if (attempt && getenv("MFAS_PERSIST_VERBOSE")) fprintf(stderr, "[persist] epoch %d: grid not resident at once, relaunched %d time(s)\n", ep, attempt);
                 return hipSuccess;
             }
@@ -1057,7 +1182,20 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         if (T <= 0) break;
         if (p->persist) {
             HIPCHK(persist_epoch(ep, T));
-        } else {
+            if (aborts[ep] == PERSIST_ABORT_NOT_RESIDENT) {
+                // every attempt failed its roll call: nothing of this epoch has run.  Train it — and the rest — launch per phase.
+                if (getenv("MFAS_PERSIST_VERBOSE")) fprintf(stderr, "[persist] epoch %d: the resident grid never became resident; falling back to launch-per-phase\n", ep);
+                rc = persist_fallback(p);
+                if (rc) return rc;
+                HIPCHK(init_args());
+                aborts[ep] = 0;
+            } else if (aborts[ep]) {
+                HIPCHK(hipStreamSynchronize(p->stream));
+                return fail(MFAS_EHIP, "persistent step loop: a workgroup timed out waiting for its dependency (abort code 1: the epoch was "
+                                       "abandoned half way, this population's parameters are not usable)");
+            }
+        }
+        if (!p->persist) {
         for (int gi = 0; gi < NG; ++gi) step(gi, 0, 1, ep, 0, -1, 0);   // prologue: forward sums of batch 0
         if (NG == 1 && p->same_group) {
             for (int64_t t = 0; t < T; ++t) step(0, 1, (t + 1 < T) ? 1 : 0, ep, t, 0, t);
@@ -1110,7 +1248,8 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipGetLastError());
     for (uint32_t ab : aborts)
-        if (ab) return fail(MFAS_EHIP, "persistent step loop: a workgroup timed out waiting for its dependency (launch aborted)");
+        if (ab) return fail(MFAS_EHIP, ab == PERSIST_ABORT_NOT_RESIDENT ? "persistent step loop: the grid never became resident (abort code 2)"
+                                                                         : "persistent step loop: a workgroup timed out waiting for its dependency (abort code 1)");
     for (int32_t sv : hstatus)
         if (sv == 2) return fail(MFAS_EHIP, "same-group fused launch: a sweep unit timed out waiting for its cell's dy");
     if (p->d_trace && p->persist) {

@@ -8,6 +8,8 @@
 #define PK_GET 1
 #define PK_INIT 2
 #define PK_WT 3     // re-derive the transposed OUT / HEAD tiles (wt arena) from plane 0
+#define PK_PUT 4    // write ONE plane (sel_plane) from flat, leaving the other planes alone (state transfer between two layouts of the
+                    // same population: PK_SET plane 0, then PK_PUT the Adam moments); the wt arena follows plane 0 unless a.wt is null
 
 struct PackArgs {
     const SegDesc* desc;
@@ -50,6 +52,10 @@ __global__ void __launch_bounds__(256) k_pack(const PackArgs a) {
         float val = 0.f;
         if (a.mode == PK_WT) {
             val = Wp[e];
+        } else if (a.mode == PK_PUT) {
+            if (ok) val = a.flat[d.src_off + fidx];
+            Wp[a.sel_plane * a.plane_stride + e] = val;
+            if (a.sel_plane != 0 || !a.wt) continue;
         } else {
             if (ok) {
                 if (a.mode == PK_SET) val = a.flat[d.src_off + fidx];
@@ -75,27 +81,29 @@ __global__ void __launch_bounds__(256) k_vec(const PackArgs a, int cand_fixed) {
     float* P0 = a.plane + cd.vec_off;
     const int tid = threadIdx.x;
     const int nvec = MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp;
-    if (a.mode != PK_GET)
+    if (a.mode != PK_GET && a.mode != PK_PUT)
         for (int e = tid; e < nvec; e += 256) {   // zero everything first (padding, Adam state)
             P0[e] = 0.f;
             P0[a.plane_stride + e] = 0.f;
             P0[2 * a.plane_stride + e] = 0.f;
         }
     __syncthreads();
-    float* P = P0 + (a.mode == PK_GET ? a.sel_plane * a.plane_stride : 0);
+    float* P = P0 + ((a.mode == PK_GET || a.mode == PK_PUT) ? a.sel_plane * a.plane_stride : 0);
     const uint32_t seed = a.mode == PK_INIT ? a.seeds[cand] : 0;
     for (int i = 0; i < cd.L; ++i) {
         float* vb = P + i * g.vec_cell_stride;
         const float bound = (float)(1.0 / sqrt((double)cd.K_in[i]));
         const uint32_t hb = d_hash_h0(d_param_seed(seed, 2 * i + 1));
         for (int r = tid; r < g.R; r += 256) {
-            if (a.mode == PK_SET) {
+            if (a.mode == PK_SET || a.mode == PK_PUT) {
                 vb[VEC_B * g.Rp + r] = a.flat[cd.f_b[i] + r];
                 if (g.bn) {
                     vb[VEC_G * g.Rp + r] = a.flat[cd.f_bn[i] + r];
                     vb[VEC_BE * g.Rp + r] = a.flat[cd.f_bn[i] + g.R + r];
-                    vb[VEC_RM * g.Rp + r] = a.flat[cd.f_bn[i] + 2 * g.R + r];
-                    vb[VEC_RV * g.Rp + r] = a.flat[cd.f_bn[i] + 3 * g.R + r];
+                    if (a.mode == PK_SET || a.sel_plane == 0) {      // running stats exist only in plane 0
+                        vb[VEC_RM * g.Rp + r] = a.flat[cd.f_bn[i] + 2 * g.R + r];
+                        vb[VEC_RV * g.Rp + r] = a.flat[cd.f_bn[i] + 3 * g.R + r];
+                    }
                 }
             } else if (a.mode == PK_GET) {
                 a.flat[cd.f_b[i] + r] = vb[VEC_B * g.Rp + r];
@@ -115,7 +123,7 @@ __global__ void __launch_bounds__(256) k_vec(const PackArgs a, int cand_fixed) {
             }
         }
         if (tid == 0) {
-            if (a.mode == PK_SET) vb[5 * g.Rp] = a.flat[cd.f_alpha + i];
+            if (a.mode == PK_SET || a.mode == PK_PUT) vb[5 * g.Rp] = a.flat[cd.f_alpha + i];
             else if (a.mode == PK_GET) a.flat[cd.f_alpha + i] = vb[5 * g.Rp];
             else if (g.alphas) {
                 const uint32_t ha = d_hash_h0(d_param_seed(seed, 40 + i));
@@ -129,7 +137,7 @@ __global__ void __launch_bounds__(256) k_vec(const PackArgs a, int cand_fixed) {
         const float bound = (float)(1.0 / sqrt((double)g.R));
         const uint32_t hh = d_hash_h0(d_param_seed(seed, 11));
         for (int c = tid; c < g.C; c += 256) {
-            if (a.mode == PK_SET) hb_[c] = a.flat[cd.f_bc + c];
+            if (a.mode == PK_SET || a.mode == PK_PUT) hb_[c] = a.flat[cd.f_bc + c];
             else if (a.mode == PK_GET) a.flat[cd.f_bc + c] = hb_[c];
             else hb_[c] = (d_hash_u01(hh, (uint32_t)c) * 2.0f - 1.0f) * bound;
         }

@@ -47,10 +47,16 @@ struct PersistArgs {
 #define PERSIST_CNT(sync, c) ((sync) + (size_t)(c) * PERSIST_SYNC_STRIDE + 32)
 #define PERSIST_MAX_UNITS 8             // sweep units one workgroup may own
 #define PERSIST_LDS_WORDS 32            // LDS words the loop itself uses (behind the bodies' LDS)
+// step-phase timestamps (profiles/r02_persist_trace_k6_r16.log; MFAS_PERSIST_TRACE=1 in the environment allocates the buffer).
+// (Round 3 tried compiling these out of production builds: the streaming k_persist then hung on the device at its first launch —
+//  same source otherwise, same launch parameters; with the run-time branches back it runs.  Not understood; the branches cost a
+//  pointer and a compare per site, so they stay.)
 #define PTRACE(slot) do { if (a.trace && tr_on) a.trace[tr_base + (slot)] = wall_clock64(); } while (0)
+#define PTRACE_UNIT(base) do { if (a.trace && un.cand == 0 && t == 12 && tid == 0 && un.index < 64) a.trace[(base) + un.index] = wall_clock64(); } while (0)
 #define PERSIST_SPIN_LIMIT (1u << 22)   // a few seconds of s_sleep polls: only a lost workgroup or a bug gets here
 #define PERSIST_ROLL_LIMIT 6000u        // roll call at launch start: ~5 ms of polls for every workgroup of the grid to be resident
 #define PERSIST_ROLL(sync, K) ((sync) + (size_t)(K) * PERSIST_SYNC_STRIDE + 32)   // workgroups that have started (own cache line)
+#define PERSIST_MAX_RELAUNCHES 40       // host: relaunches of an epoch whose roll call failed before the resident schedule is given up
 #define PERSIST_ABORT_NOT_RESIDENT 2u   // abort code of a failed roll call: nothing has been modified, the host may simply relaunch
 
 // Workgroup-wide wait until *p >= target: lane 0 polls (relaxed, sc1), everyone else parks at the barrier.
@@ -286,7 +292,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 const bool tr_on = un.index == 0 && tid == 0 && t >= 8 && t < 16;
                 const int tr_base = (t - 8) * 8 + 4;
                 PTRACE(1);
-                if (a.trace && un.cand == 0 && t == 12 && tid == 0 && un.index < 64) a.trace[64 + un.index] = wall_clock64();    // saw the flag
+                PTRACE_UNIT(64);    // saw the flag
                 float dyf[MB * 4];
 #pragma unroll
                 for (int j = 0; j < MB * 4; ++j) dyf[j] = ldc1<true>(sa.stepbuf + un.dyo + (4 * j + lg) * 16 + l15);
@@ -324,7 +330,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     }
                 }
                 PTRACE(2);
-                if (a.trace && un.cand == 0 && t == 12 && tid == 0 && un.index < 64) a.trace[128 + un.index] = wall_clock64();   // compute done
+                PTRACE_UNIT(128);   // compute done
                 if (fwd) {
                     reduce_publish(un, yacc);
                 } else {
@@ -332,7 +338,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     if (tid == 0) __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 PTRACE(3);
-                if (a.trace && un.cand == 0 && t == 12 && tid == 0 && un.index < 64) a.trace[192 + un.index] = wall_clock64();   // arrived
+                PTRACE_UNIT(192);   // arrived
                 if (tid == 0) nxt[u] = t + 1;
                 cur[u] ^= 1;
                 // batch t+2 into the buffer batch t just vacated: it lands while this unit's chain runs step t+1
@@ -362,11 +368,11 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
 #define PERSIST_NTR16 8                 // resident units, 16-bit staging: cc <= 1024 columns
 
 // Roll call: the loops below are only deadlock-free when EVERY workgroup of the schedule is resident at the same time.  That holds
-// when the process owns the GPU (workgroups <= #CUs, one per CU); when another process's kernels hold CUs (or a tool serialises
-// the launches of the resident schedule's two kernels), part of the workgroups may be waiting for a slot that the resident part —
+// when the process owns the GPU (workgroups <= #CUs, one per CU); when another process's kernels hold CUs (or the device is CU-masked),
+// part of the workgroups may be waiting for a slot that the resident part —
 // spinning on it — never frees.  So nobody touches any state before all `total` workgroups have checked in; if that does not
 // happen within ~5 ms the resident ones leave (abort code 2), the late ones see the code and leave too, and the host relaunches
-// the epoch (or falls back to the launch-per-phase schedule).
+// the epoch (and, when that keeps failing, falls back to the launch-per-phase schedule: mfas_hip.hip::persist_fallback).
 // (count and verdict live in ONE word, so "everybody is here" and "somebody gave up" cannot both be observed)
 __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, const uint32_t total, int* ldsw) {
     if (threadIdx.x == 0) {
@@ -395,23 +401,31 @@ __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// The RESIDENT schedule (the default for small populations at R <= 16) is TWO kernels launched together on two streams of the
-// process, one per role, so that each role is compiled against its own register budget (as one kernel holding the resident
-// chain, the resident units and the streaming units, every instantiation paid for the union: 256 VGPRs, 256-384 B of scratch
-// and ~650 spilled SGPRs, round 2): k_pchain — K workgroups, the resident lean chain of candidate blockIdx.x — and
-// k_punits<NTR, X16, NU> — nres_wg workgroups of resident feature units.  They synchronise through the same per-candidate flag /
-// counter records; co-residency of ALL workgroups of both launches is what the roll call establishes (total = K + nres_wg).
+// k_president<MB, NTR, X16, NU> — the RESIDENT schedule (the default for small populations at R <= 16): ONE launch per epoch,
+// blocks [0, K) = the resident lean chain of candidate blockIdx.x, blocks [K, K + nres_wg) = workgroups of resident feature
+// units.  One instantiation per unit form (staging width, tiles per wave, units per workgroup): an instantiation carries exactly
+// the two bodies its grid runs — the streaming units, the non-resident chains and the run-time dispatch over unit forms live in
+// k_persist below.  (Round 3 also ran the two roles as two kernels on two streams, each with its own register budget — the unit
+// kernels then need 109-184 VGPRs and no scratch, the chain kernel 231-255: the step time did not move (15.4-15.5 us at 4-8
+// candidates, profiles/r03_popsweep_split_kernels.log), and co-residency of two launches depends on the streams landing on different
+// hardware queues, which HIP does not promise: after a few hundred stream creations in one process the second launch queued
+// behind the first and every roll call failed.  One launch cannot be split by the runtime.)
 // ------------------------------------------------------------------------------------------------
-template <int MB>
-__global__ void __launch_bounds__(STEP_THREADS, 2) k_pchain(const PersistArgs a, const int lds_word) {
+template <int MB, int NTR, bool X16, int NU>
+__global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs a, const int lds_word) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
     const int bid = (int)blockIdx.x, tid = threadIdx.x;
     const int K = a.nchain;
+    if (!persist_roll_call(a.sync, K, gridDim.x, ldsw)) return;
+    if (bid >= K) {
+        sweep_resident<MB, NTR, X16, NU>(a, bid - K, a.nres_wg, lds, ldsw);
+        return;
+    }
     uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
-    if (!persist_roll_call(a.sync, K, (uint32_t)(K + a.nres_wg), ldsw)) return;
     const uint32_t need = (uint32_t)a.need[bid];
-    LeanRes rs;
+    LeanRes& rs = *reinterpret_cast<LeanRes*>(ldsw + 16);   // the epoch's running statistics: LDS words 16..21 (as registers of one lane
+                                                             // they were live across the whole step loop in every wave, and spilled)
     lean_res_load<MB>(a.ca, bid, lds, rs);
     for (int t = 0; t < a.T; ++t) {
         const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
@@ -437,14 +451,6 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_pchain(const PersistArgs a,
         lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the feature units run
     }
     lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs);
-}
-
-template <int MB, int NTR, bool X16, int NU>
-__global__ void __launch_bounds__(STEP_THREADS, 2) k_punits(const PersistArgs a, const int lds_word) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
-    if (!persist_roll_call(a.sync, a.nchain, (uint32_t)(a.nchain + a.nres_wg), ldsw)) return;
-    sweep_resident<MB, NTR, X16, NU>(a, (int)blockIdx.x, a.nres_wg, lds, ldsw);
 }
 
 // ------------------------------------------------------------------------------------------------

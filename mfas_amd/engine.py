@@ -427,6 +427,28 @@ class Population:
 F1_FIXED_POINT = float(1 << 32)
 
 
+def plan_population(hp: Hyper, confs: Sequence[np.ndarray], device, chunk_cols: int = 0) -> Dict[str, int]:
+    """mfas_population_plan: the schedule mfas_population_create would lay these configurations out for — a pure query (nothing
+    is allocated or launched).  Keys as Population.schedule() where they apply."""
+    lib = _lib.lib()
+    confs = [np.asarray(c, dtype=np.int64).reshape(-1, 3) for c in confs]
+    cf = np.zeros((len(confs), 4, 3), np.int32)
+    nc = np.zeros(len(confs), np.int32)
+    for k, c in enumerate(confs):
+        if not 1 <= len(c) <= 4:
+            raise ValueError("a configuration has 1..4 fusion cells")
+        cf[k, :len(c)] = c
+        nc[k] = len(c)
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    info = np.zeros(8, np.int32)
+    hc = hp.to_c()
+    _lib.check(lib.mfas_population_plan(C.byref(hc), cf.ctypes.data, nc.ctypes.data, len(confs), int(idx), int(chunk_cols), info.ctypes.data))
+    return {"persistent": bool(info[0]), "resident_units": int(info[1]), "resident_workgroups": int(info[2]),
+            "units_per_workgroup": int(info[3]), "chunk_cols": int(info[4]), "lean_chain": bool(info[5]), "compute_units": int(info[6]),
+            "candidates": int(info[7])}
+
+
 def best_dev_f1(stats_row, status_nan: bool, n_dev: int, init_f1: float = 0.0):
     """train_mmimdb_track_f1's bookkeeping (train_searchable/mmimdb.py:18-137): best F1-samples over the epochs,
     strict '>' from init_f1; a NaN train-epoch loss ends the run with the best so far; a NaN best becomes 0."""

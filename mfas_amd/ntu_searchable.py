@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import population as popmod
 from .engine import (S_SIZES, V_SIZES, FeatureLoader, FeatureTable, Hyper, Population, best_dev_accuracy,
-                     best_dev_f1, flat_layout)
+                     best_dev_f1, flat_layout, plan_population)
 from .scheduler import LRCosineAnnealingScheduler
 
 
@@ -345,15 +345,15 @@ def initial_flat_params(args, conf, hp=None) -> torch.Tensor:
 
 
 ROUNDS_MIN_CANDIDATES = 16         # (a share that does not fit the resident schedule has at least ~29 conf-4-sized candidates, or ~50 shallow ones)
-_ROUND_CAPACITY = {}               # (geometry) -> candidates the resident schedule held the last time it was probed
 
 
-def _plan_rounds(hp, confs, mine, cost_of, device, seed_base, chunk_cols):
+def _plan_rounds(hp, confs, mine, device, seed_base, chunk_cols):
     """The rank's share as ONE population, or as several trained one after the other when the share is too large for the
-    persistent resident schedule (parameters in registers, one launch per epoch: <= ~28 conf-4-sized candidates at R <= 16):
+    persistent resident schedule (parameters in registers, one launch pair per epoch: <= ~28 conf-4-sized candidates at R <= 16):
     every round but the last is filled to the resident capacity (a resident round costs 15-21 us per train step almost
-    independently of its size), found by bisection on the engine's own layout decision.  Measured at R=16, B=20 on MI355X:
-    29...56 candidates take 38-55 us per train step with launches, 36-41 us as two resident rounds.  Candidates are
+    independently of its size), found by bisection on the engine's own layout decision — asked as a pure query
+    (mfas_population_plan: nothing is allocated; only the populations that train are ever created).  Measured at R=16, B=20 on
+    MI355X: 29...56 candidates take 38-55 us per train step with launches, 36-41 us as two resident rounds.  Candidates are
     independent and carry their own seeds, so the split changes nothing but the column-chunk summation order (as any change
     of population size does).  Yields (indices, Population)."""
     if not mine:
@@ -363,57 +363,41 @@ def _plan_rounds(hp, confs, mine, cost_of, device, seed_base, chunk_cols):
         return Population(hp, [confs[i] for i in idx], device, drop_seeds=[(seed_base * 7 + i) & 0xFFFFFFFF for i in idx],
                           chunk_cols=chunk_cols)
 
-    full = make(mine)
-    if (full.schedule()["persistent"] or hp.R > 16 or len(mine) < ROUNDS_MIN_CANDIDATES or os.environ.get("MFAS_NO_ROUNDS")):
-        yield mine, full
+    def resident(idx):
+        return plan_population(hp, [confs[i] for i in idx], device, chunk_cols)["persistent"]
+
+    if (hp.R > 16 or len(mine) < ROUNDS_MIN_CANDIDATES or os.environ.get("MFAS_NO_ROUNDS") or resident(mine)):
+        yield mine, make(mine)
         return
-    key = (hp.R, hp.B, hp.C, bool(hp.bn), bool(hp.alphas), hp.tap_bits, chunk_cols, max(len(confs[i]) for i in mine))
     rounds, rest = [], list(mine)
     while rest and len(rounds) < 4:
-        whole = make(rest)
-        if whole.schedule()["persistent"]:
-            rounds.append((rest, whole))
+        if resident(rest):
+            rounds.append(rest)
             rest = []
             break
-        whole.close()
-        # largest resident prefix of `rest`: bisection, started at the capacity the last call with this geometry found
-        lo, hi, best = 1, len(rest) - 1, None
-        cached = _ROUND_CAPACITY.get(key)
-        nxt = cached
+        lo, hi, best = 1, len(rest) - 1, 0          # largest resident prefix of `rest`
         while lo <= hi:
-            mid = nxt if nxt is not None and lo <= nxt <= hi else (lo + hi) // 2
-            nxt = None
-            p = make(rest[:mid])
-            if p.schedule()["persistent"]:
-                if best is not None:
-                    best[1].close()
-                best, lo = (mid, p), mid + 1
-                if mid == cached:
-                    nxt = mid + 1          # the neighbour is expected to fail: two probes in the common case
+            mid = (lo + hi) // 2
+            if resident(rest[:mid]):
+                best, lo = mid, mid + 1
             else:
-                p.close()
                 hi = mid - 1
-        if best is None:
+        if best == 0:
             break
         if not rounds:
-            _ROUND_CAPACITY[key] = best[0]
-            nr = -(-len(rest) // best[0])
-            last = len(rest) - (nr - 1) * best[0]
+            nr = -(-len(rest) // best)
+            last = len(rest) - (nr - 1) * best
             # three or four rounds only pay when the last one is reasonably full (measured: 64 candidates as 28 + 28 + 8: 210 vs
             # 234 cand/s with launches; 84 as 3 x 28: 255 vs 238)
-            if nr > 4 or (nr >= 3 and last < 0.6 * best[0]):
-                best[1].close()
+            if nr > 4 or (nr >= 3 and last < 0.6 * best):
                 break
-        rounds.append((rest[:best[0]], best[1]))
-        rest = rest[best[0]:]
-    if rest:                                            # no resident layout for what is left: one launch-per-phase population
-        for _, p in rounds:
-            p.close()
-        yield mine, full
+        rounds.append(rest[:best])
+        rest = rest[best:]
+    if rest or not rounds:                              # no resident layout for what is left: one launch-per-phase population
+        yield mine, make(mine)
         return
-    full.close()
-    for g, p in rounds:
-        yield g, p
+    for g in rounds:
+        yield g, make(g)
 
 
 def train_sampled_models(sampled_configurations, searchable_type, dataloaders, args, device,
@@ -455,15 +439,14 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
 
     rank, world = popmod.dist_info()
     costs = [popmod.candidate_cost(confs[i], hp.R, hp.s_sizes, hp.v_sizes, hp.C) for i in wanted]
-    owner, cap = popmod.shard(costs, world)
+    owner, cap = popmod.shard(costs, world, None if getattr(args, "engine_all_ranks", False) else hp.R)
     mine = [i for i, o in zip(wanted, owner) if o == rank]
 
     local_acc_by_idx, models = {}, {}
     sched = LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, num_batches_per_epoch)
     etas = sched.eta_table(E * nb)
     order = make_order(N_tr, E, train_l.shuffle, seed_base + 1, device) if mine else None
-    for group, pop in _plan_rounds(hp, confs, mine, dict(zip(wanted, costs)), device, seed_base,
-                                   int(getattr(args, "engine_chunk_cols", 0))):
+    for group, pop in _plan_rounds(hp, confs, mine, device, seed_base, int(getattr(args, "engine_chunk_cols", 0))):
         if _pos_weight is not None:
             pop.set_pos_weight(_pos_weight)
         mods = {}
@@ -482,19 +465,21 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
             nthreads = torch.get_num_threads()
             if nthreads > 4:
                 torch.set_num_threads(4)
-            for j, i in enumerate(group):
-                with torch.random.fork_rng(devices=[]):
-                    torch.manual_seed(seed_base + 2 + i)   # world-size independent per-candidate stream
-                    if return_model or searchable_type is not Searchable_Skeleton_Image_Net:
-                        m = searchable_type(args, confs[i])
-                        if return_model:
-                            mods[i] = m
-                        flat0 = m.flat_params()
-                    else:   # same numbers, without the module objects (initial_flat_params)
-                        flat0 = initial_flat_params(args, confs[i], hp)
-                pop.set_params(j, flat0)
-            if nthreads > 4:
-                torch.set_num_threads(nthreads)
+            try:
+                for j, i in enumerate(group):
+                    with torch.random.fork_rng(devices=[]):
+                        torch.manual_seed(seed_base + 2 + i)   # world-size independent per-candidate stream
+                        if return_model or searchable_type is not Searchable_Skeleton_Image_Net:
+                            m = searchable_type(args, confs[i])
+                            if return_model:
+                                mods[i] = m
+                            flat0 = m.flat_params()
+                        else:   # same numbers, without the module objects (initial_flat_params)
+                            flat0 = initial_flat_params(args, confs[i], hp)
+                    pop.set_params(j, flat0)
+            finally:
+                if nthreads > 4:
+                    torch.set_num_threads(nthreads)
         if getattr(args, "verbose", False):
             print("Now training: ")
             for i in group:

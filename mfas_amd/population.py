@@ -82,10 +82,51 @@ def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: i
     return out
 
 
-def shard(costs: Sequence[int], world: int):
-    """owner per candidate (assign) and the largest per-rank share (the all_gather's row count), both computed locally
-    and identically on every rank."""
-    owner = assign(costs, world)
+# Step-time model of ONE rank's share (microseconds per lock-step train step), from the measured sweeps in DESIGN.md §5a
+# (profiles/r02_popsweep*.log, r03_popsweep_split_kernels.log).  Strong scaling of a small population is LATENCY-bound: with the
+# resident persistent schedule (R <= 16) a step costs the same for 1...8 candidates, so giving a rank fewer candidates than that
+# buys nothing — the model is what lets the sharder see it.
+RESIDENT_STEP_US = ((8, 15.5), (16, 16.5), (28, 20.5))      # R <= 16: (largest share, us per step) of the resident schedule
+STREAM_BYTES_PER_US = 5.5e6                                   # what the sweep streams at (24 B per parameter and step)
+
+
+def predicted_step_us(share_costs: Sequence[int], R: int) -> float:
+    """Predicted duration of one lock-step train step of a rank that holds the candidates with these costs."""
+    n = len(share_costs)
+    if n == 0:
+        return 0.0
+    bytes_us = 24.0 * float(sum(share_costs)) / STREAM_BYTES_PER_US
+    if R <= 16:
+        for cap, us in RESIDENT_STEP_US:
+            if n <= cap:
+                return us
+        if n <= 2 * RESIDENT_STEP_US[-1][0]:      # two resident rounds, one after the other (ntu_searchable._plan_rounds)
+            return 2.0 * RESIDENT_STEP_US[-1][1]
+        return max(38.0, 12.0 + bytes_us)         # launch-per-phase, lean chain
+    return max(52.0 * min(1.0, R / 128.0) + 15.0, 35.0 + bytes_us)     # general chain: its latency, or the stream
+
+
+def choose_ranks(costs: Sequence[int], world: int, R: int, tolerance: float = 0.03) -> int:
+    """Number of ranks a call should really use: the SMALLEST w <= world whose predicted call time (the slowest rank's step
+    time under assign()) is within `tolerance` of the best over 1..world.  Ranks beyond w train nothing in this call."""
+    if world <= 1 or not costs:
+        return max(1, min(world, 1))
+    times = []
+    for w in range(1, world + 1):
+        owner = assign(costs, w)
+        times.append(max(predicted_step_us([c for c, o in zip(costs, owner) if o == r], R) for r in range(w)))
+    best = min(times)
+    for w, t in enumerate(times, 1):
+        if t <= best * (1.0 + tolerance):
+            return w
+    return world
+
+
+def shard(costs: Sequence[int], world: int, R: int | None = None):
+    """owner per candidate and the largest per-rank share (the all_gather's row count), both computed locally and identically
+    on every rank.  With R given, the call uses only as many ranks as the step-time model says pay (choose_ranks)."""
+    used = choose_ranks(costs, world, R) if R is not None else world
+    owner = assign(costs, used)
     counts = [0] * world
     for o in owner:
         counts[o] += 1

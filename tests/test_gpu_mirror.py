@@ -172,12 +172,19 @@ import numpy as np, torch, torch.distributed as dist
 from types import SimpleNamespace
 import mfas_amd as M
 world = int(os.environ.get("WORLD_SIZE", "1"))
+backend = os.environ.get("MFAS_TEST_BACKEND", "gloo")
+rank = int(os.environ.get("RANK", "0"))
+dev = torch.device("cuda", rank if backend == "nccl" else 0)      # nccl (= RCCL): one GPU per rank; gloo: both ranks on cuda:0
+torch.cuda.set_device(dev)
 if world > 1:
-    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=world)
-dev = torch.device("cuda:0")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 args = SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=0.5, inner_representation_size=16, batchnorm=True,
                        alphas=False, multitask=False, weightsharing=False, batchsize=16, eta_max=1e-3, eta_min=1e-6,
-                       Ti=1, Tm=2, use_dataparallel=False, verbose=False, epochs=2, engine_init="device")
+                       Ti=1, Tm=2, use_dataparallel=False, verbose=False, epochs=2, engine_init="device",
+                       engine_all_ranks=bool(int(os.environ.get("MFAS_TEST_ALL_RANKS", "1"))))
 tr = M.FeatureTable.synthetic(512, 1, dev, torch.bfloat16, snr=0.5)
 dv = M.FeatureTable.synthetic(256, 2, dev, torch.bfloat16, snr=0.5)
 ld = {{"train": M.FeatureLoader(tr, 16, shuffle=True), "dev": M.FeatureLoader(dv, 16, shuffle=False)}}
@@ -185,7 +192,11 @@ rng = np.random.default_rng(0)
 confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in (1, 2, 3, 4, 4, 2, 1)]
 torch.manual_seed(5)
 accs = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev)
+from mfas_amd import population as P
+costs = [P.candidate_cost(c, 16, M.engine.S_SIZES, M.engine.V_SIZES, 60) for c in confs]
+owner, _ = P.shard(costs, world, None if args.engine_all_ranks else 16)
 print("RESULT", json.dumps(accs), flush=True)
+print("SHARE", json.dumps([owner.count(r) for r in range(world)]), "BACKEND", dist.get_backend() if world > 1 else "none", flush=True)
 if world > 1:
     dist.destroy_process_group()
 """
@@ -203,21 +214,49 @@ def test_population_sharding_two_ranks_matches_single(dev, tmp_path):
     script = tmp_path / "w.py"
     script.write_text(DIST_WORKER.format(root=root))
 
-    def run(world):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE=str(world))
-        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                                  stderr=subprocess.STDOUT) for r in range(world)]
-        outs = []
-        for p in procs:
-            out, _ = p.communicate(timeout=600)
-            assert p.returncode == 0, out.decode()[-2000:]
-            line = [l for l in out.decode().splitlines() if l.startswith("RESULT")][-1]
-            outs.append(json.loads(line[len("RESULT "):]))
-        return outs
-
-    single = run(1)[0]
-    two = run(2)
+    single = _run_dist(script, 1)[0][0]
+    two, shares = _run_dist(script, 2)
     assert two[0] == two[1] == single and len(single) == 7
+    assert shares[0][0] == [4, 3] or sorted(shares[0][0]) == [3, 4]          # really sharded (engine_all_ranks)
+    # the sharder's own policy: 7 search-sized candidates cost one rank the same step time as 4 + 3 on two (a latency-bound
+    # step is flat up to 8 resident candidates, mfas_amd/population.py) -> the call uses ONE rank, the other only joins the gather
+    lazy, shares = _run_dist(script, 2, MFAS_TEST_ALL_RANKS="0")
+    assert lazy[0] == lazy[1] == single and shares[0][0] == [7, 0]
+
+
+def _run_dist(script, world, **extra):
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs, shares = [], []
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out.decode()[-2000:]
+        lines = out.decode().splitlines()
+        line = [l for l in lines if l.startswith("RESULT")][-1]
+        outs.append(json.loads(line[len("RESULT "):]))
+        sh = [l for l in lines if l.startswith("SHARE")][-1].split(" BACKEND ")
+        shares.append((json.loads(sh[0][len("SHARE "):]), sh[1].strip()))
+    return outs, shares
+
+
+def test_population_sharding_two_ranks_rccl(dev, tmp_path):
+    """The same over RCCL (torch.distributed backend "nccl"), one GPU per rank: runs wherever the box has >= 2 GPUs (the driver's
+    8-GPU node); skipped on the 1-GPU boxes the builder gets."""
+    import os
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL: one process per GPU)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(DIST_WORKER.format(root=root))
+    single = _run_dist(script, 1)[0][0]
+    two, shares = _run_dist(script, 2, MFAS_TEST_BACKEND="nccl")
+    assert two[0] == two[1] == single
+    assert shares[0][1] == "nccl" and sorted(shares[0][0]) == [3, 4]
 
 
 def test_global_pooling_kernel(dev):

@@ -873,6 +873,54 @@ print("DIGEST", hashlib.sha256(stats.tobytes()).hexdigest(), flush=True)
 """
 
 
+def test_resident_schedule_falls_back_to_launch_per_phase_when_never_resident(dev, monkeypatch):
+    """The resident schedule's two launches must be co-resident; when the roll call keeps failing (another tenant holds CUs for good,
+    a CU mask, a tool that serialises launches) nothing of the epoch has run, and train() rebuilds the population in its
+    launch-per-phase layout, carries W / m / v across and goes on (mfas_hip.hip::persist_fallback).  The hook
+    MFAS_PERSIST_TEST_NOT_RESIDENT=e makes every roll call from epoch e on fail.  On the same unit decomposition (chunk_cols
+    fixed, per-segment units) every schedule gives the same bits, so a run that switches after epoch 0 or 1 must equal the run
+    that never switches — statistics, parameters and both Adam moments."""
+    from mfas_amd import FeatureTable, Hyper, Population
+    hp = Hyper(R=16, C=60, B=20, bn=True, drpt=0.5, alphas=True, tap_bits=16)
+    rng = np.random.default_rng(11)
+    K = 5
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in (4, 2, 3, 1, 4)]
+    tr = FeatureTable.synthetic(900, 1, dev, torch.bfloat16, snr=0.5)
+    dv = FeatureTable.synthetic(300, 2, dev, torch.bfloat16, snr=0.5)
+    E, nb = 3, 45
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, 900 / 20, E * nb)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    order = torch.stack([torch.randperm(900, generator=g, device=dev) for _ in range(E)]).to(torch.int32)
+    monkeypatch.setenv("MFAS_NO_TAP_MAJOR", "1")
+
+    def run(fail_from, snapshot):
+        if fail_from is None:
+            monkeypatch.delenv("MFAS_PERSIST_TEST_NOT_RESIDENT", raising=False)
+        else:
+            monkeypatch.setenv("MFAS_PERSIST_TEST_NOT_RESIDENT", str(fail_from))
+        pop = Population(hp, confs, dev, drop_seeds=list(range(70, 70 + K)), chunk_cols=256)
+        assert pop.schedule()["persistent"]
+        pop.init(list(range(1, K + 1)))
+        stats, status = pop.train(tr, dv, E, etas, order=order, snapshot_best=snapshot)
+        planes = [[pop.get_params(k, pl).cpu().numpy() for pl in range(3)] for k in range(K)]
+        sched = pop.schedule()
+        pop.close()
+        assert not status.any()
+        return stats, planes, sched
+
+    for snapshot in (False, True):
+        ref_stats, ref_planes, ref_sched = run(None, snapshot)
+        assert ref_sched["persistent"]
+        for fail_from in (0, 1, 2):
+            stats, planes, sched = run(fail_from, snapshot)
+            assert not sched["persistent"], fail_from                      # the handle now holds the launch-per-phase layout
+            assert stats.tobytes() == ref_stats.tobytes(), (snapshot, fail_from)
+            for k in range(K):
+                for pl in range(3):
+                    assert np.array_equal(planes[k][pl], ref_planes[k][pl]), (snapshot, fail_from, k, pl)
+
+
 def test_two_processes_share_the_gpu_with_persistent_grids(dev, tmp_path):
     """Two processes whose persistent grids (one workgroup per CU each, > half the chip) cannot be resident together train on
     the same GPU at the same time: the roll call at the start of every launch detects a partially resident grid before anything

@@ -196,6 +196,27 @@ def test_assignment_is_balanced_and_deterministic():
         assert own2 == own and cap == max(own.count(r) for r in range(world))
 
 
+def test_sharder_uses_only_the_ranks_that_pay():
+    """The step-time model behind shard(costs, world, R) (mfas_amd/population.py): strong scaling of a search-sized population is
+    latency-bound — a resident step costs the same for 1..8 candidates — so a call takes only as many ranks as shorten it."""
+    from mfas_amd import population as P
+    c16 = P.candidate_cost(CONFS["c4"], 16, O.S_SIZES, O.V_SIZES)
+    c128 = P.candidate_cost(CONFS["c4"], 128, O.S_SIZES, O.V_SIZES)
+    assert P.predicted_step_us([c16] * 1, 16) == P.predicted_step_us([c16] * 8, 16) < P.predicted_step_us([c16] * 9, 16)
+    assert P.choose_ranks([c16] * 6, 8, 16) == 1                    # 6 candidates: one GPU is as fast as eight
+    assert P.choose_ranks([c16] * 16, 2, 16) == 2                   # BASELINE configs[2]: 16.5 -> 15.5 us per step, worth 6 %
+    assert P.choose_ranks([c16] * 50, 8, 16) == 7                   # configs[3]: shares of <= 8 already with 7 ranks
+    assert P.choose_ranks([c128] * 1024, 8, 128) == 8               # the weak-scaling headline (128 per rank) uses every rank
+    assert P.choose_ranks([c128] * 6, 8, 128) == 1
+    for world, K, R, c in ((2, 16, 16, c16), (8, 50, 16, c16), (8, 6, 16, c16), (4, 64, 128, c128)):
+        owner, cap = P.shard([c] * K, world, R)
+        used = P.choose_ranks([c] * K, world, R)
+        assert sorted(set(owner)) == list(range(used)) and cap == max(owner.count(r) for r in range(world))
+        assert len(owner) == K
+    owner, cap = P.shard([c16] * 6, 8)                                # without a model: every rank, as before
+    assert sorted(set(owner)) == list(range(6))
+
+
 WORKER = r"""
 import os, sys
 sys.path.insert(0, {root!r})
