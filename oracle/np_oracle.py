@@ -453,11 +453,13 @@ def _batch(table, idx):
 
 
 def train_candidate(conf, hp: Hyper, params, train, dev, order=None, seed=0, etas=None,
-                    history=None, on_step=None):
+                    history=None, on_step=None, restore_best=False):
     """train_ntu_track_acc (train_searchable/ntu.py:14-89) for one candidate on feature tables.
 
     order: (epochs, N_train) int array of sample indices (None = sequential, i.e. shuffle off).
     Returns best dev accuracy (float64 = corrects / N_dev, max over epochs, strict >, from 0).
+    restore_best: leave `params` at the best epoch's weights — best_model_sd starts as a copy of the INITIAL state (:17), is
+    replaced on every strict improvement (:82-84) and loaded back at the end (:86).
     """
     hp.check()
     conf = np.asarray(conf)
@@ -472,6 +474,7 @@ def train_candidate(conf, hp: Hyper, params, train, dev, order=None, seed=0, eta
     st = AdamState()
     best = 0.0
     gstep = 0
+    best_sd = {k: v.copy() for k, v in params.items()} if restore_best else None
     if hp.loss_mode == 1:
         return _train_candidate_multilabel(conf, hp, params, train, dev, order, seed, etas, history, keys, st)
     for ep in range(hp.epochs):
@@ -524,6 +527,11 @@ def train_candidate(conf, hp: Hyper, params, train, dev, order=None, seed=0, eta
                                 dev_margins=np.sort(np.concatenate(margins))[:8]))
         if dev_acc > best:
             best = dev_acc
+            if restore_best:
+                best_sd = {k: v.copy() for k, v in params.items()}
+    if restore_best:
+        for k, v in best_sd.items():
+            params[k] = v
     return best
 
 

@@ -279,9 +279,18 @@ def test_multitask_and_alphas_vs_reference(dev):
     pop = mk_pop(ohp, [conf], dev)
     pop.set_state_dict(0, O.init_params(conf, ohp, 13))
     stats, _ = pop.train(table(ttr, dev), table(tdv, dev), 3, etas_for(ohp, 256))
-    assert abs(best_dev_accuracy(stats[0], 128) - float(g["mt_acc"])) <= 1.0 / 128 + 1e-9
+    # dev counts against the oracle's multitask run (== the reference's printed accuracies, tests/test_oracle_golden.py), which may
+    # differ only where a dev sample is a numerical tie in the oracle run (margin of the summed-logit decision < 5e-3)
+    hist = []
+    obest = O.train_candidate(conf, ohp, O.init_params(conf, ohp, 13), ttr, tdv, history=hist)
+    assert obest == pytest.approx(float(g["mt_acc"]), abs=1e-12)
+    for e, h in enumerate(hist):
+        ties = int((h["dev_margins"] < 5e-3).sum())
+        assert ties <= 3, (e, h["dev_margins"])                 # of 128 dev samples
+        assert abs(int(stats["dev_corrects"][0, e]) - h["dev_corrects"]) <= ties, (e, int(stats["dev_corrects"][0, e]), h["dev_corrects"])
+    if all(int((h["dev_margins"] < 5e-3).sum()) == 0 for h in hist):
+        assert best_dev_accuracy(stats[0], 128) == float(g["mt_acc"])
     for e in range(3):
-        assert abs(stats["dev_corrects"][0, e] / 128 - g["mt_hist"][2 * e + 1][2]) <= 1.0 / 128 + 1e-4
         # 3-term multitask loss as the reference prints it (train_searchable/ntu.py:60-61,72-75)
         assert abs(stats["train_loss_sum"][0, e] / 256 - g["mt_hist"][2 * e][1]) < 2e-3
         assert abs(stats["dev_loss_sum"][0, e] / 128 - g["mt_hist"][2 * e + 1][1]) < 2e-3
@@ -292,7 +301,13 @@ def test_multitask_and_alphas_vs_reference(dev):
     pop.set_state_dict(0, O.init_params(conf, ohp, 21))
     t1, t2 = O.synth_table(256, 31, snr=0.5), O.synth_table(128, 32, snr=0.5)
     stats, _ = pop.train(table(t1, dev), table(t2, dev), 3, etas_for(ohp, 256))
-    assert abs(best_dev_accuracy(stats[0], 128) - float(g["alpha_acc"])) <= 1.0 / 128 + 1e-9
+    hist = []
+    obest = O.train_candidate(conf, ohp, O.init_params(conf, ohp, 21), t1, t2, history=hist)
+    assert obest == pytest.approx(float(g["alpha_acc"]), abs=1e-12)
+    for e, h in enumerate(hist):
+        ties = int((h["dev_margins"] < 5e-3).sum())
+        assert ties <= 3, (e, h["dev_margins"])
+        assert abs(int(stats["dev_corrects"][0, e]) - h["dev_corrects"]) <= ties, (e, int(stats["dev_corrects"][0, e]), h["dev_corrects"])
     got = pop.get_state_dict(0)
     al = [float(got[f"alphas.{i}.alpha_x"][0]) for i in range(3)]
     np.testing.assert_allclose(al, g["alpha_final"], rtol=3e-2, atol=5e-4)   # scalar fed by a cancelling S-V sum; 48 Adam steps at lr<=1e-3

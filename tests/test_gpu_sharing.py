@@ -52,6 +52,45 @@ def close(got, want, wsum, steps, what, lr=1e-3):
     assert np.abs(got - want).max() <= lr * steps + 1e-6, (what, np.abs(got - want).max())
 
 
+CELL_KEYS = ("0.weight", "0.bias", "2.weight", "2.bias", "2.running_mean", "2.running_var")
+ACT = {0: "relu", 1: "sigmoid", 2: "lrelu"}
+TIE = 5e-3      # a dev sample whose decision margin in the ORACLE run is below this may fall on either side on the GPU
+
+
+def share_name(i, conf, hp):
+    """ntu_searchable.py:133,147,173: "{idx}.L_{in}_{out}.A_{act}"."""
+    return f"{i}.L_{O.cell_in_features(conf, i, hp)}_{hp.R}.A_{ACT[int(conf[i][2])]}"
+
+
+def oracle_weightsharing(confs, hp, ttr, tdv, seed0):
+    """train_sampled_models with --weightsharing (ntu_searchable.py:74-75,91-92,123-174) in the numpy oracle: candidate i starts from
+    init_params(seed0 + i) overwritten by every published cell whose key it shares, trains, is left at its best epoch (:86) and
+    publishes all its cells.  Returns (accuracies, per-candidate per-epoch history with dev counts and decision margins)."""
+    shared, accs, hists = {}, [], []
+    for i, conf in enumerate(confs):
+        params = O.init_params(conf, hp, seed0 + i)
+        for c in range(len(conf)):
+            name = share_name(c, conf, hp)
+            if name in shared:
+                for sub in CELL_KEYS:
+                    params[f"fusion_layers.{c}.{sub}"] = shared[name][sub].copy()
+        hist = []
+        accs.append(O.train_candidate(conf, hp, params, ttr, tdv, history=hist, restore_best=True))
+        for c in range(len(conf)):
+            shared[share_name(c, conf, hp)] = {sub: params[f"fusion_layers.{c}.{sub}"].copy() for sub in CELL_KEYS}
+        hists.append(hist)
+    return accs, hists
+
+
+def counts_within_ties(got_counts, hist, what):
+    """Per-epoch dev correct COUNTS equal the oracle's (which equal the reference's) except where a dev sample is a numerical tie
+    in the oracle run: a count may differ by at most the number of samples with margin < TIE in that epoch, and those are few."""
+    for e, h in enumerate(hist):
+        ties = int((h["dev_margins"] < TIE).sum())
+        assert ties <= 3, (what, e, h["dev_margins"])           # of 128 dev samples
+        assert abs(int(got_counts[e]) - h["dev_corrects"]) <= ties, (what, e, int(got_counts[e]), h["dev_corrects"], h["dev_margins"][:3])
+
+
 class Factory:
     """searchable_type stand-in (a plain callable in the reference, ntu_searchable.py:44): builds the module and loads the
     hash-generated parameters the golden run used (seed0 + index)."""
@@ -90,12 +129,22 @@ def test_weightsharing_vs_reference():
     # which cells were published, in the reference's key format "{idx}.L_{in}_{out}.A_{act}"
     ref_keys = sorted({str(e[1]) for e in g["events"]})
     assert sorted(shared) == ref_keys, (sorted(shared), ref_keys)
-    # accuracies: candidates 1 and 3 START from cells candidate 0 / 1 trained — a wrong sharing rule changes them grossly
-    np.testing.assert_allclose(accs, g["accs"], atol=2.0 / 128 + 1e-9)
+    # accuracies: candidates 1 and 3 START from cells candidate 0 / 1 trained — a wrong sharing rule changes them grossly.
+    # The oracle's weight-sharing run reproduces the reference's accuracies EXACTLY; the engine's per-epoch dev counts may differ
+    # from it only on proven numerical ties (margins of the oracle run), not by a blanket allowance.
+    ohp = O.Hyper(R=16, C=60, B=16, bn=True, drpt=0.0, epochs=3)
+    oaccs, ohists = oracle_weightsharing(confs, ohp, O.synth_table(256, 41, snr=1.5), O.synth_table(128, 42, snr=1.5), 50)
+    np.testing.assert_allclose(oaccs, g["accs"], atol=1e-12)
     hist = parse_hist(buf.getvalue())
     assert hist.shape == g["hist"].shape
     np.testing.assert_allclose(hist[:, 1], g["hist"][:, 1], atol=5e-3)          # losses as printed
-    np.testing.assert_allclose(hist[:, 2], g["hist"][:, 2], atol=2.0 / 128 + 1e-4)   # accuracies as printed
+    for i in range(4):                                                            # rows: per candidate 3 x (train, dev)
+        dev_acc = hist[6 * i + 1:6 * i + 6:2, 2]
+        np.testing.assert_allclose([h["dev_acc"] for h in ohists[i]], g["hist"][6 * i + 1:6 * i + 6:2, 2], atol=1e-4)    # oracle == reference, per epoch
+        counts_within_ties(np.round(dev_acc * 128), ohists[i], f"weightsharing candidate {i}")
+        if all(int((h["dev_margins"] < TIE).sum()) == 0 for h in ohists[i]):
+            assert accs[i] == float(g["accs"][i]), (i, accs[i])
+    np.testing.assert_allclose(hist[0::2, 2], g["hist"][0::2, 2], atol=2.0 / 256 + 1e-4)   # train accuracies as printed (train-mode BN statistics)
     steps = 3 * 16
     for name in ref_keys:                # the published state_dict after the last candidate
         for sub in ("0.weight", "0.bias", "2.weight", "2.bias", "2.running_mean", "2.running_var"):
@@ -133,12 +182,36 @@ def test_found_two_phase_vs_reference(mt):
     np.testing.assert_allclose(hist[:, 1], want[:, 1], atol=6e-3)                 # 3-term loss when multitask
     tr, dv = hist[:, 0] == 0, hist[:, 0] == 1
     np.testing.assert_allclose(hist[tr, 2], want[tr, 2], atol=2.0 / 256 + 1e-4)
-    np.testing.assert_allclose(hist[dv, 2], want[dv, 2], atol=2.0 / 128 + 1e-4)
+    # dev counts: the two-phase schedule in the oracle (phase 1 = one epoch, phase 2 = args.epochs from the phase-1 best weights,
+    # each a fresh Adam + scheduler, main_found_ntu.py:108-135) reproduces the reference's printed dev accuracies exactly; the
+    # engine may differ from it only on proven numerical ties
+    ohp = O.Hyper(R=16, C=60, B=16, bn=True, drpt=0.0, multitask=mt)
+    params = O.init_params(conf, ohp, 70)
+    ohist = []
+    for ep in (1, 3):
+        ohp.epochs = ep
+        h = []
+        obest = O.train_candidate(conf, ohp, params, tabs["train"], tabs["dev"], history=h, restore_best=True)
+        ohist += h
+    np.testing.assert_allclose([h["dev_acc"] for h in ohist], want[dv, 2], atol=1e-4)
+    counts_within_ties(np.round(hist[dv, 2] * 128), ohist, "two-phase " + pre)
+    no_ties = all(int((h["dev_margins"] < TIE).sum()) == 0 for h in ohist)
     interm = float(re.search(r"Intermediate val accuracy: (?:tensor\()?([0-9.]+)", text).group(1))
     final = float(re.search(r"Final val accuracy: (?:tensor\()?([0-9.]+)", text).group(1))
-    assert abs(interm - float(g[pre + "interm"])) <= 2.0 / 128 + 1e-4
-    assert abs(final - float(g[pre + "final"])) <= 2.0 / 128 + 1e-4
-    assert abs(float(acc) - float(g[pre + "test_acc"])) <= 2.0 / 96 + 1e-9
+    assert abs(interm - float(g[pre + "interm"])) <= (1e-4 if no_ties else 2.0 / 128 + 1e-4)
+    assert abs(final - float(g[pre + "final"])) <= (1e-4 if no_ties else 2.0 / 128 + 1e-4)
+    assert abs(obest - float(g[pre + "final"])) <= 1e-4
+    # test split: one eval pass of the best weights; margins of the oracle's forward over the 96 test rows
+    tl, _ = O.forward(params, conf, ohp, {k: v for k, v in tabs["test"].items() if k != "label"}, False)
+    dec = tl + tabs["test"]["vlogit"] + tabs["test"]["slogit"] if mt else tl
+    d = np.array(dec, np.float64)
+    lab = tabs["test"]["label"]
+    own = d[np.arange(96), lab].copy()
+    d[np.arange(96), lab] = -np.inf
+    test_ties = int((np.abs(own - d.max(1)) < TIE).sum())
+    otest = float((O.predict(dec) == lab).mean())
+    assert abs(otest - float(g[pre + "test_acc"])) <= 1e-12
+    assert test_ties <= 2 and abs(float(acc) - otest) <= test_ties / 96.0 + 1e-9
     sd = {k: v.detach().cpu().numpy() for k, v in rmode.state_dict().items()}
     for k in sd:
         if "num_batches" in k or k.startswith("alphas"):
