@@ -53,7 +53,10 @@ typedef struct mfas_hyper {
                           * layout north_star prescribes; 32: f32; 0: unknown = any).  With 16 the engine may size resident
                           * feature units for 16-bit staging (up to 1024 columns each); training such a population on f32
                           * tables is refused with MFAS_EINVAL. */
-    int32_t _pad;
+    int32_t order_per_candidate; /* 0: one sample order per epoch shared by the whole population (lockstep: `order` of
+                          * mfas_population_train holds [epochs][N_train]); 1: every candidate walks its OWN permutations — the
+                          * reference draws a fresh DataLoader(shuffle=True) order per candidate and epoch
+                          * (models/searchable.py:248-250, train_searchable/ntu.py:35) — `order` then holds [K][epochs][N_train]. */
 } mfas_hyper;
 
 /* Pooled feature table = what Visual/Skeleton.forward + GlobalPooling2D hand to the fusion net

@@ -50,6 +50,9 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--random_search", action="store_true", default=False)
     p.add_argument("--engine_init", default="torch", choices=["torch", "device"])
+    p.add_argument("--engine_order", default="shared", choices=["shared", "per_candidate"],
+                   help="shared: one shuffled order per epoch for the whole call (lockstep); per_candidate: every candidate draws its own "
+                        "permutations, as the reference's per-candidate DataLoader(shuffle=True) does (models/searchable.py:248-250)")
     p.add_argument("--surrogate_device", default="cpu", choices=["cpu", "gpu"],
                    help="where the 81k-parameter LSTM surrogate trains (the reference puts it on its training device).  gpu: train steps "
                         "replayed as HIP graphs (0.87 ms instead of the CPU path's 1.9 ms per step; device GEMM numerics, so sampled "

@@ -19,7 +19,7 @@ class mfas_hyper(C.Structure):
                 ("wd", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
                 ("adam_eps", C.c_double), ("bn_eps", C.c_double), ("bn_momentum", C.c_double),
                 ("s_sizes", C.c_int32 * MAX_TAPS), ("v_sizes", C.c_int32 * MAX_TAPS), ("loss_mode", C.c_int32),
-                ("allow_plain_cell", C.c_int32), ("f1_threshold", C.c_double), ("tap_bits", C.c_int32), ("_pad", C.c_int32)]
+                ("allow_plain_cell", C.c_int32), ("f1_threshold", C.c_double), ("tap_bits", C.c_int32), ("order_per_candidate", C.c_int32)]
 
 
 class mfas_table(C.Structure):

@@ -199,7 +199,7 @@ template <int LPR> __device__ __forceinline__ void row_argmax(float& bv, int& bi
 // red[b] and its top-1 hit in red[Bp + b] (multitask: argmax of central + visual + skeleton logits).
 template <int MB, int NC>
 __device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, const ChainStep& cs, float* lg_l, const int SC, float* red_l,
-                                                const int* lab_l, const int nvalid, const float nf, const int tid) {
+                                                const int* lab_l, const int nvalid, const float nf, const int tid, const int32_t* ord) {
     constexpr int Bp = MB * 16;
     constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
     const Geo& g = a.g;
@@ -233,7 +233,7 @@ __device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, const ChainS
     const float* vl = nullptr;
     const float* sl = nullptr;
     if (g.multitask && ok) {
-        const int64_t grow = a.order ? (int64_t)a.order[cs.pos_t + b] : (int64_t)(cs.base_t + b);
+        const int64_t grow = ord ? (int64_t)ord[cs.pos_t + b] : (int64_t)(cs.base_t + b);
         vl = a.tab.vlogit + grow * C;
         sl = a.tab.slogit + grow * C;
     }
@@ -272,11 +272,11 @@ __device__ __forceinline__ void softmax_rows_nc(const ChainArgs& a, const ChainS
 
 template <int MB>
 __device__ __forceinline__ void softmax_rows(const ChainArgs& a, const ChainStep& cs, float* lg_l, const int SC, float* red_l,
-                                             const int* lab_l, const int nvalid, const float nf, const int tid) {
+                                             const int* lab_l, const int nvalid, const float nf, const int tid, const int32_t* ord) {
     constexpr int Bp = MB * 16;
     constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
-    if (a.g.Cp <= 4 * LPR) softmax_rows_nc<MB, 4>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
-    else softmax_rows_nc<MB, 8>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+    if (a.g.Cp <= 4 * LPR) softmax_rows_nc<MB, 4>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, ord);
+    else softmax_rows_nc<MB, 8>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, ord);
 }
 
 #ifdef MFAS_CHAIN_TIMING
@@ -359,7 +359,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     if (tid < Bp) {
         int lab = 0;
         if (tid < nvalid) {
-            const int64_t row = a.order ? (int64_t)a.order[cs.pos_t + tid] : (int64_t)(cs.base_t + tid);
+            const int32_t* ord = cand_order(a.order, g, cd.gidx);
+            const int64_t row = ord ? (int64_t)ord[cs.pos_t + tid] : (int64_t)(cs.base_t + tid);
             lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
         }
         lab_l[tid] = lab;
@@ -590,7 +591,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
     } else if (tid < LPR * Bp) {
-        softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+        softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
     }
     lds_barrier();
     if (tid == CHAIN_THREADS - 64) {   // last wave: keeps the read-modify-write of the statistics off wave 0
@@ -944,7 +945,8 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     // forward pass
     int lab = 0;
     if (wave == 1 && lane < nvalid) {
-        const int64_t row = a.order ? (int64_t)a.order[cs.pos_t + lane] : (int64_t)(cs.base_t + lane);
+        const int32_t* ord = cand_order(a.order, g, cgidx);
+        const int64_t row = ord ? (int64_t)ord[cs.pos_t + lane] : (int64_t)(cs.base_t + lane);
         lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
     }
     const float* vecW = vec_l;
@@ -1098,7 +1100,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
     } else if (tid < LPR * Bp) {
-        softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
+        softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
     }
     lds_barrier();
     CT_STAMP(7);

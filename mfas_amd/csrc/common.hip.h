@@ -100,6 +100,7 @@ struct Geo {             // geometry shared by all candidates of a population
     int32_t sw[MFAS_MAX_TAPS], vw[MFAS_MAX_TAPS];   // table row strides of the taps (width padded to 16)
     int32_t loss_mode;         // 0 softmax CE + accuracy, 1 weighted BCE + F1-samples
     float f1_th;
+    int64_t order_stride;      // elements between two candidates' sample-order tables (0: one order shared by the population)
 };
 
 // vector block of a candidate (inside every plane): per cell [b | gamma | beta | rm | rv | alpha(16)], then bc[Cp]
@@ -108,6 +109,11 @@ struct Geo {             // geometry shared by all candidates of a population
 #define VEC_BE 2
 #define VEC_RM 3
 #define VEC_RV 4
+
+// the sample-order table candidate `gidx` walks (models/searchable.py:248-250: the reference shuffles per candidate and epoch)
+__device__ __forceinline__ const int32_t* cand_order(const int32_t* order, const Geo& g, int gidx) {
+    return order ? order + (int64_t)gidx * g.order_stride : nullptr;
+}
 
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16;

@@ -614,7 +614,9 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             // small R (1, 2 or 4 row blocks): feature segments are regrouped tap-major (sweep_tap_body)
             std::vector<SegDesc> sorted;
             std::vector<TapDesc> taps;
-            const bool tap_major = (g.nrb == 1 || g.nrb == 2 || g.nrb == 4) && !getenv("MFAS_NO_TAP_MAJOR") && !p->persist && !p->same_group;
+            // (tap-major workgroups stage a batch's rows ONCE for several candidates: not with per-candidate sample orders)
+            const bool tap_major = (g.nrb == 1 || g.nrb == 2 || g.nrb == 4) && !getenv("MFAS_NO_TAP_MAJOR") && !p->persist && !p->same_group &&
+                                   !hp->order_per_candidate;
             if (tap_major) {
                 const int per_wg = STEP_NW / g.nrb;
                 std::vector<const SegDesc*> feat;
@@ -983,6 +985,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     StepArgs st;
     auto init_args = [&]() -> hipError_t {     // (again after persist_fallback: the population's buffers and layout have changed)
         NG = (int)p->groups.size();
+        p->g.order_stride = (p->hp.order_per_candidate && order) ? (int64_t)epochs * N : 0;    // order: [K][epochs][N_train]
         memset(&st, 0, sizeof(st));
         st.sa.cands = p->d_cands; st.sa.plane = p->plane; st.sa.plane_stride = p->plane_stride; st.sa.wt = p->wt;
         st.sa.stepbuf = p->stepbuf; st.sa.tab = *train; st.sa.order = order; st.sa.g = p->g; st.sa.ac = ac;

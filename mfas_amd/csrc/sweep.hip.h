@@ -156,11 +156,11 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
 
     if (upd && feat) {
         const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
-        stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, st.pos_t, st.base_t, st.nvalid_t, Bp, tid, STEP_THREADS);
+        stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, cand_order(a.order, a.g, cd.gidx), st.pos_t, st.base_t, st.nvalid_t, Bp, tid, STEP_THREADS);
     }
     if (fwd) {
         const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
-        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, st.pos_n, st.base_n, st.nvalid_n, Bp, tid, STEP_THREADS);
+        stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, cand_order(a.order, a.g, cd.gidx), st.pos_n, st.base_n, st.nvalid_n, Bp, tid, STEP_THREADS);
     }
     if constexpr (COH) {
         if (upd && a.cellflag) {   // the table rows above are in flight while the chain of this launch gets to this cell's dy

@@ -43,6 +43,7 @@ class Hyper:
     f1_threshold: float = 0.3   # th_fscore, train_searchable/mmimdb.py:16
     allow_plain_cell: bool = False   # [Linear, nl] cells are legal (AV-MNIST, avmnist_searchable.py:276-285)
     tap_bits: int = 0           # element size of the feature tables to come (16 / 32; 0 = unknown): lets the engine size its units
+    order_per_candidate: bool = False   # every candidate walks its own per-epoch permutations (order [K][E][N]) instead of sharing one
 
     @classmethod
     def from_args(cls, args) -> "Hyper":
@@ -70,6 +71,7 @@ class Hyper:
         h.allow_plain_cell = int(self.allow_plain_cell)
         h.f1_threshold = float(self.f1_threshold)
         h.tap_bits = int(self.tap_bits)
+        h.order_per_candidate = int(bool(self.order_per_candidate))
         return h
 
 
@@ -355,7 +357,8 @@ class Population:
         sc = np.ascontiguousarray(adam_step_scalars(etas, self.hp.beta1, self.hp.beta2))
         if order is not None:
             order = order.to(device=self.device, dtype=torch.int32).contiguous()
-            assert order.numel() >= epochs * len(train)
+            assert order.numel() >= epochs * len(train) * (self.K if self.hp.order_per_candidate else 1), \
+                "order: [epochs][N_train] (shared) or [K][epochs][N_train] (Hyper.order_per_candidate)"
         if self.hp.loss_mode == 0:      # CrossEntropyLoss raises on a target outside [0, C); the kernels index by it
             for t in (train, dev):
                 if t is not None:

@@ -301,6 +301,20 @@ def make_order(N, epochs, shuffle, seed, device):
     return torch.stack([torch.randperm(N, generator=gen, device=device) for _ in range(epochs)]).to(torch.int32)
 
 
+def make_order_per_candidate(N, epochs, shuffle, seed, device, indices):
+    """args.engine_order = "per_candidate": the reference's behaviour — every candidate iterates its OWN freshly shuffled
+    DataLoader each epoch (models/searchable.py:248-250, train_searchable/ntu.py:35).  Candidate i's permutations are seeded by
+    (seed, i), so they do not depend on the world size or on which round / rank trains it.  Returns int32 [len(indices)][E][N]."""
+    if not shuffle:
+        return None
+    out = []
+    for i in indices:
+        gen = torch.Generator(device=device)
+        gen.manual_seed(int(seed) + 1000003 * (int(i) + 1))
+        out.append(torch.stack([torch.randperm(N, generator=gen, device=device) for _ in range(epochs)]))
+    return torch.stack(out).to(torch.int32)
+
+
 def initial_flat_params(args, conf, hp=None) -> torch.Tensor:
     """The flat parameter vector `Searchable_Skeleton_Image_Net(args, conf).flat_params()` would hold right after
     construction — same draws from torch's global RNG in the same order (per cell Linear weight: kaiming_uniform_(a=sqrt(5)),
@@ -420,6 +434,10 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
     hp = _hp if _hp is not None else Hyper.from_args(args)
     hp.multitask = False    # ntu_searchable.py:82-84 never forwards multitask to the train loop
     hp.tap_bits = 8 * train_l.table.elem_size() if train_l.table.dtype == dev_l.table.dtype else 0
+    per_cand = getattr(args, "engine_order", "shared") == "per_candidate"      # the reference's independent shuffles (default: lockstep order)
+    if getattr(args, "engine_order", "shared") not in ("shared", "per_candidate"):
+        raise ValueError("args.engine_order must be 'shared' or 'per_candidate'")
+    hp.order_per_candidate = per_cand
     if getattr(args, "multitask", False) and _hp is None:
         raise TypeError("max() received an invalid combination of arguments: the searchable returns a tuple "
                         "with --multitask in search mode (reference behaviour, train_searchable/ntu.py:54)")
@@ -445,7 +463,7 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
     local_acc_by_idx, models = {}, {}
     sched = LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, num_batches_per_epoch)
     etas = sched.eta_table(E * nb)
-    order = make_order(N_tr, E, train_l.shuffle, seed_base + 1, device) if mine else None
+    order = make_order(N_tr, E, train_l.shuffle, seed_base + 1, device) if (mine and not per_cand) else None
     for group, pop in _plan_rounds(hp, confs, mine, device, seed_base, int(getattr(args, "engine_chunk_cols", 0))):
         if _pos_weight is not None:
             pop.set_pos_weight(_pos_weight)
@@ -486,6 +504,8 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
                 print(confs[i])
         if getattr(args, "engine_profile", False):
             pop.set_profiling(True)
+        if per_cand:
+            order = make_order_per_candidate(N_tr, E, train_l.shuffle, seed_base + 1, device, group)
         stats, status = pop.train(train_l.table, dev_l.table, E, etas, order=order,
                                   snapshot_best=bool(return_model))
         if getattr(args, "engine_profile", False):
