@@ -9,8 +9,10 @@ the sharp statement is distributional: the reference, the oracle and the engine,
 agree in the MEAN of every epoch statistic within the standard error (accuracies: + the north_star's 0.1 %).
 The remedy for chaos is samples, not a wider gate: G14 holds 64 starts of the reference and the engine runs all 64
 (3 s.e. = 0.05 % on the best dev accuracy, so the gate is +-0.15 %); G14m repeats the experiment in the SENSITIVE regime
-(snr 0.10: dev accuracy 0.69 instead of a saturated 0.98), and G15 is the bench workload itself (dropout 0.5, shuffled,
-E=10) gated on the mean best dev accuracy over 64 engine seeds vs 16 reference seeds."""
+(snr 0.10: dev accuracy 0.69 instead of a saturated 0.98); G18c is the same experiment WITH dropout 0.5 (the reference's dropout
+modules swapped for the engine's masks, shuffled fixed order, bench.py's snr 0.12): 512 reference starts against 2,048 engine
+starts, gate 3 s.e. + 0.1 % <= 0.2 %; and G15 is the bench workload itself with the reference's OWN dropout / shuffle streams
+(E=10, snr 0.12) gated on the mean best dev accuracy over 256 engine seeds vs 64 reference seeds."""
 import numpy as np
 import pytest
 
