@@ -310,7 +310,7 @@ def main():
         # process.  When the committed passes of exactly this workload exist they are quoted WITH their source; else null.
         traffic = mfma = traffic_src = mfma_src = None
         headline = a.total_pop == 0 and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1 and not a.mixed_confs
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
             if headline and traffic is None and os.path.exists(tp):
                 try:

@@ -55,7 +55,7 @@ def main():
 
 def small(outdir):
     """Small-population regime (bench.py --workload c2: 16 sampled L=4 confs, R=16, B=20, one epoch of 100 steps): HBM bytes per
-    train step of the whole population, persistent resident schedule (k_persist, one launch) against launch-per-phase
+    train step of the whole population, persistent resident schedule (k_president, one launch) against launch-per-phase
     (k_step + k_chain), next to the algorithmic 24 B/param + taps of a streaming schedule."""
     outdir = os.path.abspath(outdir)
     os.makedirs(outdir, exist_ok=True)
@@ -69,7 +69,7 @@ def small(outdir):
         tot = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             rows = collect(outdir, f"small_{mode}_{counter}", counter, cmd)
-            ks = [r for r in rows if r["Kernel_Name"].startswith(("void k_persist", "void k_step", "void k_chain"))]
+            ks = [r for r in rows if r["Kernel_Name"].startswith(("void k_president", "void k_persist", "void k_step", "void k_chain"))]
             tot[counter] = sum(float(r["Counter_Value"]) for r in ks) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
             tot["kernels"] = sorted({r["Kernel_Name"].split("(")[0] for r in ks})
             tot["dispatches"] = len(ks)

@@ -17,6 +17,7 @@ Ks = [int(x) for x in sys.argv[5].split(",")]
 mixed = "mixed" in sys.argv
 cc = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("cc=")), 0)
 nums = [int(a) for a in sys.argv[6:] if a.isdigit()]
+E_show = E
 N, Nd = (nums + [10000, 5600])[:2] if len(nums) >= 2 else (10000, 5600)
 dev = torch.device("cuda:0")
 tr = M.FeatureTable.synthetic(N, 1, dev, torch.bfloat16, snr=0.12)
@@ -36,6 +37,8 @@ for K in Ks:
     for mode in ("0", "1"):          # "1" = the engine's default policy (persistent where the resident form fits), "0" = forced off
         if mode == "0":
             os.environ["MFAS_PERSIST"] = "0"
+        elif "force" in sys.argv:            # A/B: the persistent schedule wherever it can be laid out (streaming form beyond R = 16)
+            os.environ["MFAS_PERSIST"] = "1"
         else:
             os.environ.pop("MFAS_PERSIST", None)
         best = None
