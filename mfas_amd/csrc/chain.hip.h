@@ -55,21 +55,24 @@ __device__ __forceinline__ bool drop_keep(uint32_t h0, int cell, uint32_t idx, u
 }
 
 // acc[mb] += X[b][0..16*nk) . tile(k)   (X in LDS row-major with stride sx; tiles: 256 floats each, stride tstride)
-template <int MB, bool COH>
+// TW = weight tiles requested before the first is consumed (a batch of TW x 4 VGPRs; even TW keeps the even / odd pairing, so
+// the arithmetic does not depend on it): 8, or 4 in the 128-VGPR builds of the two-batch-block chain, which spilled 15-31 registers
+template <int MB, bool COH, int TW = 8>
 __device__ __forceinline__ void lds_x_times_tiles(f32x4 (&acc)[MB], const float* X, int sx, const float* tbase, int64_t tidx,
                                                   int64_t tstride, int nk, int lane) {
     // same arithmetic as mma_tiles: even / odd k-blocks in two independent chains, summed at the end
+    static_assert(TW % 2 == 0, "even / odd chains are paired by the position inside a batch");
     const int l15 = lane & 15, lg = lane >> 4;
     f32x4 acc2[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc2[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < nk; k0 += 8) {
-        f32x4 w8[8];
+    for (int k0 = 0; k0 < nk; k0 += TW) {
+        f32x4 w8[TW];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < TW; ++u)
             if (k0 + u < nk) w8[u] = ldc4<COH>(tbase, tidx + (int64_t)(k0 + u) * tstride + lane * 4);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < TW; ++u)
             if (k0 + u < nk) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
@@ -295,6 +298,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     constexpr int Bp = MB * 16;
+    // (co-scheduled builds of the two-batch-block chain live in 128 VGPRs: 4 tiles per batch in the same-group launch, where the chain
+    //  is on the critical path, 2 under the other group's sweep — k_step<2,*,4,false> spilled 31 registers with 8, none with 2)
+    constexpr int CHAIN_TW = (MB >= 2 && !PF) ? (COH ? 4 : 2) : 8;
     constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;   // softmax lanes per batch row
     const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
     const int SX = Rp + 4, SC = Cp + 4;
@@ -399,7 +405,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
             const int ns = cd.nch_s[i], nch = ns + cd.nch_v[i];
             const int64_t part = sbo + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8) + it * 4;
             f32x4 accS = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
-            constexpr int PB = PF ? 16 : 8;   // partial-sum loads in flight per thread
+            constexpr int PB = PF ? 16 : (MB >= 2 ? 4 : 8);   // partial-sum loads in flight per thread (128-VGPR builds: fewer)
             for (int ch0 = 0; ch0 < nch; ch0 += PB) {
                 f32x4 p8[PB];
 #pragma unroll
@@ -475,7 +481,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
             }
             if (i > 0) {
                 if (pf) mma_tiles<MB>(acc, xprev, SX, wa, nrb, lane);
-                else lds_x_times_tiles<MB, COH>(acc, xprev, SX, W, cd.seg_off[i][2] + (int64_t)rb * nrb * 256, 256, nrb, lane);
+                else lds_x_times_tiles<MB, COH, CHAIN_TW>(acc, xprev, SX, W, cd.seg_off[i][2] + (int64_t)rb * nrb * 256, 256, nrb, lane);
             }
             float av[MB][4];
             float s = 0.f;
@@ -572,7 +578,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
             const int c = cb * 16 + l15;
             const float bias = vecW[g.vec_head + c];
             if (pf) mma_tiles<MB>(acc, xl, SX, wa, nrb, lane);
-            else lds_x_times_tiles<MB, COH>(acc, xl, SX, W, cd.head_off + (int64_t)cb * nrb * 256, 256, nrb, lane);
+            else lds_x_times_tiles<MB, COH, CHAIN_TW>(acc, xl, SX, W, cd.head_off + (int64_t)cb * nrb * 256, 256, nrb, lane);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -671,7 +677,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (pf) mma_tiles<MB>(acc, src, sstride, wa, nkk, lane);
-            else lds_x_times_tiles<MB, COH>(acc, src, sstride, a.wt, Tidx + (int64_t)rb * nkk * 256, 256, nkk, lane);
+            else lds_x_times_tiles<MB, COH, CHAIN_TW>(acc, src, sstride, a.wt, Tidx + (int64_t)rb * nkk * 256, 256, nkk, lane);
             float dz[MB][4];
             float sdz = 0.f, sdzx = 0.f;
 #pragma unroll
@@ -817,7 +823,7 @@ struct LeanLds {
 // MODE 0: launch-per-phase schedule; 1: persistent, everything exchanged through memory (write-through / sc1);
 // 2: persistent AND resident (LeanRes): vector block, OUT / HEAD weights and statistics live on chip, the chain's only
 // global traffic per step is the sweep's partial sums in and dy (+ alpha scales) out.
-template <int MB, int MODE = 0>
+template <int MB, int MODE = 0, int PB = 16>
 __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds, LeanRes* rs = nullptr) {
     constexpr bool COH = MODE >= 1;
     constexpr bool RES = MODE == 2;
@@ -872,7 +878,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     // that nothing needs before the loss, fetched by wave 1 so that wave 0 never waits for them)
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int per_cell = MB * 64;   // float4 partial-sum items per cell; L * per_cell <= 512: one item per thread
-    constexpr int PB = 16;              // partial-sum chunks requested per thread before any is consumed
+    // PB = partial-sum chunks requested per thread before any is consumed (16; 8 in the 128-VGPR co-scheduled builds of k_step)
     const bool has_item = tid < L * per_cell;
     // (per_cell = MB * 64: the cell index is wave-uniform -> scalar loads of cd.nch_* / part_cell_off)
     const int pi = __builtin_amdgcn_readfirstlane(has_item ? tid / per_cell : 0), pit = tid - pi * per_cell;

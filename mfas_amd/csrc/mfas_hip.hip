@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bid = (int)blockIdx.x;
     if (bid < a.nchain) {
-        if constexpr (LEAN) { chain_lean<MB>(a.ca, chain_step_of(a.ca), bid, lds); chain_lean_tail<MB, 0>(a.ca, chain_step_of(a.ca), bid, lds); }
+        if constexpr (LEAN) { chain_lean<MB, 0, (WPE >= 4 ? 8 : 16)>(a.ca, chain_step_of(a.ca), bid, lds); chain_lean_tail<MB, 0>(a.ca, chain_step_of(a.ca), bid, lds); }
         else chain_body<MB, false>(a.ca, chain_step_of(a.ca), bid, lds);
     }
     else if (bid < a.nchain + a.sa.ntap) sweep_tap_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain, lds);
