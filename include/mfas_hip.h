@@ -142,6 +142,16 @@ int mfas_population_forward(mfas_population* pop, int32_t k, const mfas_table* t
 int mfas_population_forward_train(mfas_population* pop, int32_t k, const mfas_table* tab, int64_t row0, int32_t nrows,
                                   int32_t step_index, float* logits);
 
+/* (new, round 3) The autograd half of that forward: the gradients of an EXTERNAL loss of the same batch with respect to every
+ * central parameter (loss.backward() on the logits of Searchable_Skeleton_Image_Net.forward under model.train(True),
+ * /root/reference/models/search/ntu_searchable.py:206-247, for callers that write their own training loop).  The batch is run
+ * again in train mode with the same dropout stream (`step_index`) and batch statistics, `dlogits` (DEVICE, nrows x C float32
+ * = dL/dlogits) takes the place of the loss gradient, and each parameter's gradient is left in its Adam first-moment slot:
+ * read it with mfas_population_get_params(pop, k, 1, flat).  Parameters are not changed; the second-moment slots and the BN
+ * running statistics are scratch afterwards — call it on a population used for nothing else (the Python mirror clones one). */
+int mfas_population_backward(mfas_population* pop, int32_t k, const mfas_table* table, int64_t row0, int32_t nrows,
+                             int32_t step_index, const float* dlogits);
+
 /* Timing of the dominant kernel (fused cell sweep) over the last train() call, measured with HIP
  * events on the population's stream: number of launches, summed milliseconds, and the algorithmic
  * HBM bytes of one update+forward launch (24*P_tiles + feature bytes). */

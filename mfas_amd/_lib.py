@@ -63,6 +63,7 @@ def lib():
                                         C.c_int64, C.c_int32, P, P]
     L.mfas_population_forward.argtypes = [P, C.c_int32, C.POINTER(mfas_table), C.c_int64, C.c_int64, P, P]
     L.mfas_population_forward_train.argtypes = [P, C.c_int32, C.POINTER(mfas_table), C.c_int64, C.c_int32, C.c_int32, P]
+    L.mfas_population_backward.argtypes = [P, C.c_int32, C.POINTER(mfas_table), C.c_int64, C.c_int32, C.c_int32, P]
     L.mfas_population_sweep_profile.argtypes = [P, P, P, P]
     L.mfas_population_schedule.argtypes = [P, P]
     L.mfas_population_plan.argtypes = [C.POINTER(mfas_hyper), P, P, C.c_int32, C.c_int32, C.c_int32, P]
@@ -79,7 +80,7 @@ EXPORTS = ["mfas_last_error", "mfas_version", "mfas_population_create", "mfas_po
            "mfas_population_init", "mfas_population_train", "mfas_population_forward",
            "mfas_population_sweep_profile", "mfas_population_set_profiling", "mfas_population_set_pos_weight", "mfas_global_pool", "mfas_stream_probe", "mfas_source_digest",
            "mfas_population_set_best_threshold", "mfas_population_forward_train", "mfas_population_schedule",
-           "mfas_population_plan"]
+           "mfas_population_plan", "mfas_population_backward"]
 
 
 def check(rc):

@@ -29,6 +29,8 @@ struct ChainArgs {
     int32_t yf_reduced, _padr;   // the sweep already reduced the partial sums into the step buffer's yf area (sweep.hip.h)
     float* logits_out;           // train-mode FORWARD ONLY (mfas_population_forward_train): write the batch's logits (nvalid x C)
                                  // after the head and stop — batch-statistics BN (running stats updated), dropout stream of `gstep`
+    const float* dlogits_in;     // BACKWARD OF AN EXTERNAL LOSS (mfas_population_backward): dL/dlogits (nvalid x C) given by the caller
+                                 // takes the place of the softmax / BCE gradient; no statistics are accumulated
 };
 
 // what changes from one train step to the next (k_step / k_chain take it from the launch arguments, the persistent loop
@@ -594,13 +596,18 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
         }
         return;
     }
-    if (g.loss_mode == 1) {
+    if (a.dlogits_in) {     // the caller's dL/dlogits instead of the loss gradient (rows / classes beyond the batch: 0)
+        for (int e = tid; e < Bp * Cp; e += CHAIN_THREADS) {
+            const int b = e / Cp, c = e - b * Cp;
+            lg_l[b * SC + c] = (b < nvalid && c < C) ? a.dlogits_in[(int64_t)b * C + c] : 0.f;
+        }
+    } else if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
     } else if (tid < LPR * Bp) {
         softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
     }
     lds_barrier();
-    if (tid == CHAIN_THREADS - 64) {   // last wave: keeps the read-modify-write of the statistics off wave 0
+    if (tid == CHAIN_THREADS - 64 && a.stats) {   // last wave: keeps the read-modify-write of the statistics off wave 0
         float ls = 0.f, ncor = 0.f;
         for (int b = 0; b < Bp; ++b) { ls += red_l[b]; ncor += red_l[Bp + b]; }
         DevStats& st = a.stats[(int64_t)cgidx * a.E + cs.epoch];
@@ -1103,7 +1110,12 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             return;
         }
     }
-    if (g.loss_mode == 1) {
+    if (a.dlogits_in) {     // the caller's dL/dlogits instead of the loss gradient (rows / classes beyond the batch: 0)
+        for (int e = tid; e < Bp * Cp; e += CHAIN_THREADS) {
+            const int b = e / Cp, c = e - b * Cp;
+            lg_l[b * SC + c] = (b < nvalid && c < C) ? a.dlogits_in[(int64_t)b * C + c] : 0.f;
+        }
+    } else if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
     } else if (tid < LPR * Bp) {
         softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
@@ -1230,7 +1242,7 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
         else { a.plane[o] = w; a.plane[a.plane_stride + o] = m; a.plane[2 * a.plane_stride + o] = v; }
     };
     if (a.logits_out) return;       // train-mode forward only: no statistics, no update
-    if (tid == CHAIN_THREADS - 64) {
+    if (tid == CHAIN_THREADS - 64 && (RES || a.stats)) {
         float ls = 0.f, ncor = 0.f;
         for (int b = 0; b < Bp; ++b) { ls += red_l[b]; ncor += red_l[Bp + b]; }
         if constexpr (RES) {   // accumulated in registers for the epoch, flushed by lean_res_store

@@ -1326,9 +1326,12 @@ extern "C" int mfas_population_forward(mfas_population* p, int32_t k, const mfas
     return MFAS_OK;
 }
 
-extern "C" int mfas_population_forward_train(mfas_population* p, int32_t k, const mfas_table* tab, int64_t row0, int32_t nrows,
-                                             int32_t step_index, float* logits) {
-    if (!p || !logits || k < 0 || k >= p->K || row0 < 0) return fail(MFAS_EINVAL, "bad argument");
+// One batch through candidate k in TRAIN mode: forward only (logits out), or forward + backward of an external loss
+// (dlogits in): then every parameter's Adam first-moment slot receives its exact GRADIENT and nothing else changes — the step
+// runs with beta1 = 0 (m <- m + 1 * (g - m) = g), weight decay 0 and learning rate 0 (w <- w - 0 * m / denom = w).
+static int single_batch(mfas_population* p, int32_t k, const mfas_table* tab, int64_t row0, int32_t nrows, int32_t step_index,
+                        float* logits, const float* dlogits) {
+    if (!p || (!logits && !dlogits) || k < 0 || k >= p->K || row0 < 0) return fail(MFAS_EINVAL, "bad argument");
     int rc = check_table(p, tab, false);
     if (rc) return rc;
     const Geo& g = p->g;
@@ -1336,15 +1339,17 @@ extern "C" int mfas_population_forward_train(mfas_population* p, int32_t k, cons
     if (nrows == 1 && g.bn) return fail(MFAS_EINVAL, "train-mode BatchNorm needs more than 1 row (reference: ValueError)");
     if (row0 + nrows > tab->N) return fail(MFAS_EINVAL, "row range outside the table");
     HIPCHK(hipSetDevice(p->device));
+    AdamC ac;
+    ac.w1 = 1.0f; ac.b2 = (float)p->hp.beta2; ac.w2 = (float)(1.0 - p->hp.beta2); ac.eps = (float)p->hp.adam_eps; ac.wd = 0.f; ac.ss = 0.f; ac.bc2s = 1.f;
     StepArgs st;
     memset(&st, 0, sizeof(st));
     st.sa.cands = p->d_cands; st.sa.plane = p->plane; st.sa.plane_stride = p->plane_stride; st.sa.wt = p->wt;
-    st.sa.stepbuf = p->stepbuf; st.sa.tab = *tab; st.sa.order = nullptr; st.sa.g = g;
+    st.sa.stepbuf = p->stepbuf; st.sa.tab = *tab; st.sa.order = nullptr; st.sa.g = g; st.sa.g.order_stride = 0;
     st.sa.desc = p->d_descs + p->desc_start[k]; st.sa.tdesc = nullptr; st.sa.ntap = 0;
     st.sa.do_update = 0; st.sa.do_forward = 1;
     st.sa.pos_n = row0; st.sa.base_n = (int)row0; st.sa.nvalid_n = nrows;
     st.sa.pos_t = row0; st.sa.base_t = (int)row0; st.sa.nvalid_t = nrows;
-    st.sa.ac.ss = 0.f; st.sa.ac.bc2s = 1.f;
+    st.sa.ac = ac;
     st.nchain = 0;
     const unsigned nsw = (unsigned)(p->desc_start[k + 1] - p->desc_start[k]);
     size_t lds_need = p->lds_step;   // (a population laid out for resident units budgets its streaming LDS without them)
@@ -1360,26 +1365,46 @@ extern "C" int mfas_population_forward_train(mfas_population* p, int32_t k, cons
         else if (g.MB == 2) HIPCHK(set_lds((k_step<2, false, 2, false>), lds_need));
         else HIPCHK(set_lds((k_step<4, false, 2, false>), lds_need));
     }
+    auto sweep = [&]() {
+        if (g.MB == 1) hipLaunchKernelGGL((k_step<1, false, 4, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
+        else if (g.MB == 2) hipLaunchKernelGGL((k_step<2, false, 2, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
+        else hipLaunchKernelGGL((k_step<4, false, 2, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
+    };
     // 1. forward partial sums of the batch (no update): the sweep's forward half over this candidate's units
-    if (g.MB == 1) hipLaunchKernelGGL((k_step<1, false, 4, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
-    else if (g.MB == 2) hipLaunchKernelGGL((k_step<2, false, 2, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
-    else hipLaunchKernelGGL((k_step<4, false, 2, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
-    // 2. the chain up to the logits: batch-statistics BN (running statistics move like in any train-mode forward), dropout
+    sweep();
+    // 2. the chain: batch-statistics BN (running statistics move like in any train-mode forward), dropout stream of step_index;
+    //    forward only: stops at the logits; backward: continues from the caller's dL/dlogits and leaves dy_i for the sweep
     ChainArgs& c = st.ca;
     c.cands = p->d_cands + k; c.plane = p->plane; c.plane_stride = p->plane_stride; c.wt = p->wt; c.stepbuf = p->stepbuf;
     c.tab = *tab; c.order = nullptr; c.pos_t = row0; c.base_t = (int)row0; c.nvalid = nrows;
-    c.gstep = step_index; c.epoch = 0; c.E = 1; c.g = g; c.stats = nullptr; c.status = p->d_status;
+    c.gstep = step_index; c.epoch = 0; c.E = 1; c.g = st.sa.g; c.stats = nullptr; c.status = p->d_status;
     c.yf_in_lds = p->yf_in_lds ? 1 : 0; c.vec_in_lds = p->vec_in_lds ? 1 : 0; c.pos_w = p->d_posw;
-    c.yf_reduced = 0; c.logits_out = logits;
+    c.yf_reduced = 0; c.logits_out = dlogits ? nullptr : logits; c.dlogits_in = dlogits; c.ac = ac;
 #define CHAIN_LAUNCH(M, F) hipLaunchKernelGGL((k_chain<M, F>), dim3(1), dim3(STEP_THREADS), p->lds_chain, p->stream, st.ca)
     if (p->lean_chain) { if (g.MB == 1) CHAIN_LAUNCH(1, true); else CHAIN_LAUNCH(2, true); }
     else if (g.MB == 1) CHAIN_LAUNCH(1, false);
     else if (g.MB == 2) CHAIN_LAUNCH(2, false);
     else CHAIN_LAUNCH(4, false);
 #undef CHAIN_LAUNCH
+    if (dlogits) {   // 3. dW of every matrix into its m slot (see the header comment); W, v-scaled-by-lr-0 steps leave W as it was
+        st.sa.do_update = 1; st.sa.do_forward = 0;
+        sweep();
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->stream));
     return MFAS_OK;
+}
+
+extern "C" int mfas_population_forward_train(mfas_population* p, int32_t k, const mfas_table* tab, int64_t row0, int32_t nrows,
+                                             int32_t step_index, float* logits) {
+    if (!logits) return fail(MFAS_EINVAL, "bad argument");
+    return single_batch(p, k, tab, row0, nrows, step_index, logits, nullptr);
+}
+
+extern "C" int mfas_population_backward(mfas_population* p, int32_t k, const mfas_table* tab, int64_t row0, int32_t nrows,
+                                        int32_t step_index, const float* dlogits) {
+    if (!dlogits) return fail(MFAS_EINVAL, "bad argument");
+    return single_batch(p, k, tab, row0, nrows, step_index, nullptr, dlogits);
 }
 
 extern "C" int mfas_stream_probe(int64_t bytes_per_plane, int32_t iters, double* gb_per_s) {

@@ -402,6 +402,19 @@ class Population:
                                                               C.c_void_p(logits.data_ptr())))
         return logits
 
+    def backward(self, k: int, table: FeatureTable, dlogits: torch.Tensor, row0: int = 0, nrows: Optional[int] = None, step: int = 0):
+        """Gradients of an external loss of ONE train-mode batch (mfas_population_backward): `dlogits` = dL/dlogits (nrows, C) on
+        the device.  Returns the flat gradient vector (reference state_dict order, like get_params); parameters are unchanged, the
+        Adam slots and BN running statistics of this population are scratch afterwards."""
+        nrows = len(table) - row0 if nrows is None else nrows
+        self._check_table(table)
+        d = dlogits.to(device=self.device, dtype=torch.float32).contiguous()
+        assert tuple(d.shape) == (nrows, self.hp.C), (tuple(d.shape), (nrows, self.hp.C))
+        tc = table.to_c()
+        with torch.cuda.device(self._idx):
+            _lib.check(self.lib.mfas_population_backward(self._h, k, C.byref(tc), row0, nrows, int(step), C.c_void_p(d.data_ptr())))
+        return self.get_params(k, plane=1)
+
     def set_pos_weight(self, w):
         w = np.ascontiguousarray(np.asarray(w, np.float32))
         assert w.size == self.hp.C

@@ -60,6 +60,43 @@ class FeatureTap(nn.Module):
         return x
 
 
+class _TrainModeForward(torch.autograd.Function):
+    """Train-mode forward of one batch on the engine WITH an autograd edge to the central parameters: forward =
+    mfas_population_forward_train on a scratch population holding the module's parameters; backward = mfas_population_backward on
+    the same population (same dropout stream, same batch statistics) with the incoming dL/dlogits — the engine's own fused
+    backward, not a torch graph.  ntu_searchable.py:206-247 under model.train(True), for callers that write their own loop."""
+
+    @staticmethod
+    def forward(ctx, module, table, n, seed, *params):
+        hp = module.hyper(False)
+        hp.B = max(n, 2)
+        pop = Population(hp, [module.conf], table.label.device, drop_seeds=[seed & 0xFFFFFFFF])
+        flat0 = module.flat_params()
+        pop.set_params(0, flat0)
+        out = pop.forward_train(0, table, 0, n, step=0)
+        if module.args.batchnorm:
+            module.load_flat(pop.get_params(0))      # the moved running statistics (nothing else changed)
+            _bump_bn_counters(module, 1)
+        ctx.pop, ctx.table, ctx.n, ctx.flat0, ctx.module = pop, table, n, flat0, module
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pop, module = ctx.pop, ctx.module
+        pop.set_params(0, ctx.flat0)              # the state the forward saw (its own call moved the running statistics)
+        gflat = pop.backward(0, ctx.table, grad_out, 0, ctx.n, step=0).cpu()
+        where = {key: (shape, off) for key, shape, off in flat_layout(module.conf, module.hyper(False))[0]}
+        grads = []
+        for key, prm in module.named_parameters():
+            # (alphas.parameters() sit in the optimiser but never see a gradient without --alphas, ntu_searchable.py:251)
+            if key not in where or (key.startswith("alphas") and not module.args.alphas):
+                grads.append(None)
+                continue
+            shape, off = where[key]
+            grads.append(gflat[off:off + int(np.prod(shape))].reshape(shape).to(prm.device))
+        return (None, None, None, None, *grads)
+
+
 # ------------------------------------------------------------------------------------------------ the fusion net
 class Searchable_Skeleton_Image_Net(nn.Module):
     """Module surface of ntu_searchable.py:178-301: attributes ``conf, args, rgbnet, skenet, alphas, gp_v,
@@ -178,22 +215,15 @@ class Searchable_Skeleton_Image_Net(nn.Module):
         table = FeatureTable(taps, torch.zeros(n, dtype=torch.int32, device=some.device))
         if self.training:
             # train mode (ntu_searchable.py:206-247 under model.train(True)): batch-statistics BatchNorm — running statistics and
-            # num_batches_tracked move — and Dropout (the engine's counter-based stream, seeded from torch's RNG).  The logits
-            # carry no autograd graph: backward + Adam run inside the engine (train_ntu_track_acc / train_sampled_models).
+            # num_batches_tracked move — and Dropout (the engine's counter-based stream, seeded from torch's RNG).  The logits carry
+            # an autograd edge to the central parameters (_TrainModeForward: loss.backward() runs the engine's fused backward);
+            # the fast path for training stays train_ntu_track_acc / train_sampled_models.
             if not 1 <= n <= 64:
                 raise NotImplementedError("train-mode forward handles one batch of 1..64 samples (the engine's batch range)")
             if n == 1 and self.args.batchnorm:
                 raise ValueError("Expected more than 1 value per channel when training")     # torch BatchNorm1d's message
-            hp = self.hyper(False)
-            hp.B = max(n, 2)
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-            pop = Population(hp, [self.conf], some.device, drop_seeds=[seed & 0xFFFFFFFF])
-            pop.set_params(0, self.flat_params())
-            out = pop.forward_train(0, table, 0, n, step=0)
-            if self.args.batchnorm:
-                self.load_flat(pop.get_params(0))      # the moved running statistics (nothing else changed)
-                _bump_bn_counters(self, 1)
-            pop.close()
+            out = _TrainModeForward.apply(self, table, n, seed, *[p for _, p in self.named_parameters()])
             if not self.args.multitask:
                 return out
             return out, visual["vlogit"], skel["slogit"]

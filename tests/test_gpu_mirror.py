@@ -450,6 +450,86 @@ def test_per_candidate_sample_orders(dev):
     assert abs(a.mean() - b.mean()) <= 3.0 * se + 1e-3, (a.mean(), b.mean(), se)
 
 
+@pytest.mark.parametrize("R,B,bn,drpt,alphas,cname", [(16, 20, False, 0.5, False, "c4"), (16, 16, True, 0.4, True, "l3"),
+                                                      (128, 16, True, 0.5, False, "c4"), (64, 11, True, 0.0, False, "l2")])
+def test_train_mode_forward_is_differentiable(dev, R, B, bn, drpt, alphas, cname):
+    """Searchable_Skeleton_Image_Net.forward under model.train(True) is differentiable in the reference
+    (ntu_searchable.py:206-247): a caller may write its own loop — loss = f(model(batch)); loss.backward(); optimizer.step().
+    Here the logits carry an autograd edge whose backward is the engine's fused backward run from the caller's dL/dlogits
+    (mfas_population_backward).  (1) C ABI: gradients of an ARBITRARY dlogits equal the oracle's backward, parameters untouched;
+    (2) module surface: loss.backward() fills .grad of every central parameter like torch's own autograd does on the oracle-pinned
+    restatement of the network, and one torch.optim.Adam step moves the parameters."""
+    import mfas_amd as M
+    from tests.helpers import engine_hyper
+    conf = np.array(CONFS[cname])
+    ohp = O.Hyper(R=R, B=B, bn=bn, drpt=drpt, alphas=alphas)
+    t = O.synth_table(B, 91, snr=0.4)
+    tab = M.FeatureTable.from_numpy(t, dev, torch.float32)
+    params = O.init_params(conf, ohp, 17, perturb_bn=True)
+    rng = np.random.default_rng(5)
+    dlog = (rng.standard_normal((B, 60)) * 0.1).astype(np.float32)          # not a softmax gradient: an arbitrary upstream gradient
+    # (1) the C ABI
+    pop = M.Population(engine_hyper(ohp), [conf], dev, drop_seeds=[77])
+    pop.set_state_dict(0, params)
+    before = pop.get_params(0).clone()
+    gflat = pop.backward(0, tab, torch.from_numpy(dlog).to(dev), 0, B, step=3)
+    assert torch.equal(pop.get_state_dict(0)["central_classifier.weight"], torch.from_numpy(params["central_classifier.weight"]))
+    feats = {k: v for k, v in t.items() if k != "label"}
+    _, cache = O.forward({k: v.copy() for k, v in params.items()}, conf, ohp, feats, True, seed=77, step=3)
+    want = O.backward(params, ohp, cache, dlog)
+    layout, _ = M.engine.flat_layout(conf, engine_hyper(ohp))
+    seen = 0
+    for key, shape, off in layout:
+        if key not in want:
+            continue
+        got = gflat[off:off + int(np.prod(shape))].reshape(shape).cpu().numpy()
+        sc = float(np.abs(want[key]).max()) + 1e-30
+        assert np.abs(got - want[key]).max() <= 2e-4 * sc + 1e-8, (key, np.abs(got - want[key]).max(), sc)
+        seen += 1
+    assert seen == len(want) >= 2 * len(conf) + 2
+    w_after = pop.get_params(0)
+    keep = torch.ones_like(before, dtype=torch.bool)
+    for key, shape, off in layout:
+        if "running" in key:                                                 # (train-mode BN moves its running statistics)
+            keep[off:off + int(np.prod(shape))] = False
+    assert torch.equal(w_after[keep], before[keep])                          # the parameters are untouched
+    pop.close()
+    # (2) the module surface
+    args = mkargs(inner_representation_size=R, batchnorm=bn, drpt=drpt, batchsize=B, alphas=alphas)
+    model = M.Searchable_Skeleton_Image_Net(args, conf)
+    sd = model.state_dict()
+    for k, v in params.items():
+        sd[k].copy_(torch.from_numpy(v))
+    model.train(True)
+    x = {k: torch.from_numpy(v).to(dev) for k, v in feats.items()}
+    rgb, ske = {k: v for k, v in x.items() if k[0] == "v"}, {k: v for k, v in x.items() if k[0] == "s"}
+    opt = torch.optim.Adam(model.central_params(), lr=1e-3, weight_decay=1e-4)
+    torch.manual_seed(123)
+    out = model((rgb, ske))
+    assert out.requires_grad and out.shape == (B, 60)
+    label = torch.from_numpy(t["label"]).to(dev)
+    loss = torch.nn.functional.cross_entropy(out, label) + 0.01 * (out ** 2).mean()      # the caller's own loss
+    loss.backward()
+    # oracle with the same mask stream: the module drew its dropout seed from torch's RNG right after manual_seed(123)
+    torch.manual_seed(123)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) & 0xFFFFFFFF
+    logits, cache = O.forward({k: v.copy() for k, v in params.items()}, conf, ohp, feats, True, seed=seed, step=0)
+    lt = torch.from_numpy(logits).requires_grad_(True)
+    (torch.nn.functional.cross_entropy(lt, torch.from_numpy(t["label"])) + 0.01 * (lt ** 2).mean()).backward()
+    want = O.backward(params, ohp, cache, lt.grad.numpy())
+    named = dict(model.named_parameters())
+    for key, w in want.items():
+        g = named[key].grad
+        assert g is not None, key
+        sc = float(np.abs(w).max()) + 1e-30
+        assert np.abs(g.cpu().numpy() - w).max() <= 3e-4 * sc + 1e-8, (key, np.abs(g.cpu().numpy() - w).max(), sc)
+    if not alphas:
+        assert all(p.grad is None for k, p in named.items() if k.startswith("alphas"))       # ntu_searchable.py:251
+    w0 = named["fusion_layers.0.0.weight"].detach().clone()
+    opt.step()
+    assert not torch.equal(named["fusion_layers.0.0.weight"].detach(), w0)
+
+
 def test_search_cli_two_ranks_matches_single(dev):
     """main_searchable_ntu.py end to end under 2 processes (gloo, both on cuda:0): every rank runs the seeded controller, the
     population of every call is sharded, accuracies are all-gathered — the search result equals the single-process run."""
