@@ -530,6 +530,39 @@ def test_train_mode_forward_is_differentiable(dev, R, B, bn, drpt, alphas, cname
     assert not torch.equal(named["fusion_layers.0.0.weight"].detach(), w0)
 
 
+def test_gpu_surrogate_reproduces_the_pinned_controller_decisions(dev):
+    """--surrogate_device gpu (graph-replayed train steps, device GEMM arithmetic) takes the SAME decisions as the CPU path — and as
+    the unchanged reference controller — on the reference-pinned runs of golden G9 (every sampled configuration of every call,
+    the best accuracies kept).  (At the search script's defaults — 50 surrogate epochs, hundreds of Adam steps — the two decision
+    streams part ways after ~900-1,700 decisions, tools/gpu_surrogate_decisions.py / profiles/r03_gpu_surrogate_decisions.log,
+    while the CPU path is invariant to its thread count: the device surrogate therefore stays opt-in.)"""
+    import random
+    import mfas_amd as M
+    from mfas_amd.search import ModelSearcher, SimpleRecurrentSurrogate
+    g = golden("g9_controller_run.npz")
+    for tag, iters, levels, K in (("a", 2, 3, 5), ("b", 3, 4, 6)):
+        args = SimpleNamespace(search_iterations=iters, max_progression_levels=levels, num_samples=K,
+                               initial_temperature=10.0, final_temperature=0.2, temperature_decay=4.0,
+                               lr_surrogate=0.001, epochs_surrogate=8, verbose=False)
+        calls = []
+
+        def fake_train(confs, model_type, dataloaders, a, device, state_dict=None):
+            calls.append([np.array(c) for c in confs])
+            return [O.fake_accuracy(c) for c in confs]
+
+        np.random.seed(3)
+        torch.manual_seed(3)
+        random.seed(3)
+        surrogate = SimpleRecurrentSurrogate(100, 3, 100).to(dev)
+        s_data = ModelSearcher(args)._epnas(None, {"model": surrogate, "criterion": torch.nn.MSELoss()}, None,
+                                            {"train_sampled_fun": fake_train,
+                                             "get_layer_confs": M.get_possible_layer_configurations}, dev)
+        flat = np.concatenate([np.concatenate([np.asarray(c).reshape(-1), [-1]]) for call in calls for c in call])
+        assert np.array_equal(flat, g[tag + "/calls_flat"]), tag
+        _, accs, _ = s_data.get_k_best(5)
+        np.testing.assert_allclose(np.sort(np.array(accs)), g[tag + "/best_accs"], rtol=1e-12)
+
+
 def test_search_cli_two_ranks_matches_single(dev):
     """main_searchable_ntu.py end to end under 2 processes (gloo, both on cuda:0): every rank runs the seeded controller, the
     population of every call is sharded, accuracies are all-gathered — the search result equals the single-process run."""
