@@ -296,7 +296,7 @@ def main():
         achieved = bytes_per_launch / (ms / n_launch * 1e-3) / 1e9 if n_launch else None
         sched = NS.PROFILE[-1][3] if NS.PROFILE else {}
         if sched.get("persistent"):
-            kernel = ("k_persist (ONE launch per epoch: per-candidate chain workgroups + "
+            kernel = (("k_president" if sched.get("resident_units") else "k_persist") + " (ONE launch per epoch: per-candidate chain workgroups + "
                       + (f"{sched['resident_units']} feature units resident in registers on {sched['resident_workgroups']} workgroups" if sched.get("resident_units")
                          else "streaming feature units")
                       + "; algorithmic bytes = what one epoch of a streaming schedule moves (24 B/param/step + taps): resident W/m/v never touch HBM, "
