@@ -5,6 +5,7 @@
 (population sharded inside train_sampled_models, accuracies all-gathered over RCCL)."""
 import argparse
 import os
+import sys
 import time
 
 import numpy as np
@@ -70,10 +71,6 @@ def main(argv=None):
     import mfas_amd as M
     from mfas_amd.search import NTUSearcher
     args = parse_args(argv)
-    # torch.optim's first optimizer construction imports torch._dynamo (0.6-0.7 s): let that happen while the tables are built
-    import threading
-    warm = threading.Thread(target=lambda: __import__("torch._dynamo"), daemon=True)
-    warm.start()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local = local % max(torch.cuda.device_count(), 1)
@@ -95,8 +92,15 @@ def main(argv=None):
                   "dev": M.FeatureTable.synthetic(args.synthetic[1], 2, device, dt)}
     else:
         tables = {s: M.FeatureTable.load(args.featuredir, s, device) for s in ("train", "dev")}
+    # torch.optim's first optimizer construction imports torch._dynamo (0.6-0.7 s).  The table generation above is asynchronous device
+    # work, so importing it HERE — on the main thread, after every other import and after init_process_group — still overlaps it,
+    # without a second thread importing overlapping torch submodules behind the main thread's back.
+    try:
+        import importlib
+        importlib.import_module("torch._dynamo")
+    except Exception as e:     # an optional warm-up: never a reason to lose the search
+        print("warm import of torch._dynamo failed:", repr(e), file=sys.stderr)
     searcher = NTUSearcher(args, device, tables)
-    warm.join()
     rank0 = int(os.environ.get("RANK", "0")) == 0
     if rank0:
         print("MFAS for NTU Started!!!!")

@@ -613,7 +613,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
         DevStats& st = a.stats[(int64_t)cgidx * a.E + cs.epoch];
         st.train_loss += (double)ls;
         st.train_corr += (long long)ncor;
-        if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
+        if (!(fabsf(ls) <= 3.0e38f)) atomicMax(&a.status[cgidx], 1);   // (never downgrades a timeout mark 2 set by a sweep unit of the same launch)
     }
     CT_STAMP(7);
     // dlogits -> global (dy operand of the HEAD segment); head-bias Adam
@@ -1253,7 +1253,7 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
             DevStats& st = a.stats[(int64_t)cgidx * a.E + cs.epoch];
             st.train_loss += (double)ls;
             st.train_corr += (long long)ncor;
-            if (!(fabsf(ls) <= 3.0e38f)) a.status[cgidx] = 1;
+            if (!(fabsf(ls) <= 3.0e38f)) atomicMax(&a.status[cgidx], 1);   // (never downgrades a timeout mark 2 set by a sweep unit of the same launch)
         }
     }
     const int hc = tid - (CHAIN_THREADS - 256);
@@ -1394,6 +1394,6 @@ __device__ __forceinline__ void lean_res_store(const ChainArgs& a, const int bid
         DevStats& st = a.stats[(int64_t)cd.gidx * a.E + epoch];
         st.train_loss += rs.loss;
         st.train_corr += rs.corr;
-        if (rs.bad) a.status[cd.gidx] = 1;
+        if (rs.bad) atomicMax(&a.status[cd.gidx], 1);   // (never downgrades a timeout mark 2 set by a sweep unit of the same launch)
     }
 }

@@ -175,7 +175,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
                 int go = 1;
                 while (ld_u32_relaxed(f) < a.flag_target) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > CELLFLAG_SPIN_LIMIT) { go = 0; a.flag_status[cd.gidx] = 2; break; }
+                    if (++spins > CELLFLAG_SPIN_LIMIT) { go = 0; atomicMax(&a.flag_status[cd.gidx], 2); break; }
                 }
                 s_go = go;
             }
