@@ -563,6 +563,45 @@ def test_gpu_surrogate_reproduces_the_pinned_controller_decisions(dev):
         np.testing.assert_allclose(np.sort(np.array(accs)), g[tag + "/best_accs"], rtol=1e-12)
 
 
+def test_plan_query_equals_the_created_layout(dev):
+    """mfas_population_plan (pure query: nothing allocated) answers what mfas_population_create then does — schedule, resident units,
+    their workgroups and units per workgroup — for search-sized and bench-sized populations, homogeneous and mixed, with a forced
+    chunk and with the persistent schedule forbidden."""
+    import os
+    import mfas_amd as M
+    rng = np.random.default_rng(2)
+    cases = []
+    for R, B, bn in ((16, 20, False), (16, 16, True), (128, 16, True), (32, 20, False)):
+        for K in (1, 6, 9, 16, 24, 28, 29, 40, 50):
+            for mixed in (False, True):
+                cases.append((R, B, bn, K, mixed, 0))
+    cases += [(16, 20, False, 7, False, 512), (16, 20, False, 16, True, 1024), (16, 20, False, 30, False, 256)]
+    seen_res = seen_lpp = 0
+    for R, B, bn, K, mixed, cc in cases:
+        hp = M.Hyper(R=R, C=60, B=B, bn=bn, drpt=0.5, tap_bits=16)
+        confs = [np.array(CONFS["c4"])] * K
+        if mixed:
+            confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in rng.integers(1, 5, K)]
+        plan = M.engine.plan_population(hp, confs, dev, cc)
+        pop = M.Population(hp, confs, dev, chunk_cols=cc)
+        sched = pop.schedule()
+        pop.close()
+        assert bool(plan["persistent"]) == bool(sched["persistent"]), (R, B, K, mixed, cc, plan, sched)
+        if sched["persistent"]:
+            for key in ("resident_units", "resident_workgroups", "units_per_workgroup"):
+                assert plan[key] == sched[key], (key, R, B, K, mixed, cc, plan, sched)
+            seen_res += 1
+        else:
+            seen_lpp += 1
+    assert seen_res >= 20 and seen_lpp >= 20
+    os.environ["MFAS_PERSIST"] = "0"
+    try:
+        hp = M.Hyper(R=16, C=60, B=20, bn=False, drpt=0.5, tap_bits=16)
+        assert not M.engine.plan_population(hp, [np.array(CONFS["c4"])] * 6, dev)["persistent"]
+    finally:
+        del os.environ["MFAS_PERSIST"]
+
+
 def test_search_cli_two_ranks_matches_single(dev):
     """main_searchable_ntu.py end to end under 2 processes (gloo, both on cuda:0): every rank runs the seeded controller, the
     population of every call is sharded, accuracies are all-gathered — the search result equals the single-process run."""
