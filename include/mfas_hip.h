@@ -160,7 +160,7 @@ int mfas_population_sweep_profile(const mfas_population* pop, int64_t* launches,
 int mfas_population_set_profiling(mfas_population* pop, int32_t on);
 
 /* (new) The step schedule this population was laid out for, so that a measurement can name the kernel it
- * timed: info[0] = 1 persistent step loop (k_president resident, or k_persist streaming; one launch per epoch) / 0 launch per phase (k_step / k_chain);
+ * timed: info[0] = 1 persistent step loop (k_president: resident units + resident chain, one launch per epoch) / 0 launch per phase (k_step / k_chain);
  * info[1] = feature units resident in registers; info[2] = their workgroups; info[3] = units per resident workgroup;
  * info[4] = 1 when the resident lean chain owns OUT/HEAD; info[5] = 1 lean chain (R <= 16); info[6] = candidate groups of the
  * launch-per-phase schedule (2 = fused A/B launches, 1 = chain and sweep back to back, -1 = one launch per step holding the chain

@@ -25,7 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 // No implicit FMA contraction anywhere in this translation unit (see __graft_entry__.build): every schedule (k_chain / k_step /
-// k_persist instantiations) must round identically.  MFMA instructions are unaffected.
+// k_president instantiations) must round identically.  MFMA instructions are unaffected.
 #pragma clang fp contract(off)
 #include <stdint.h>
 #include <stdio.h>
@@ -151,7 +151,6 @@ struct mfas_population {
     int nres = 0;                   // resident feature units (one workgroup each, W/m/v in registers): the first nres persistent units
     SegDesc* d_pdescs = nullptr;    // persistent schedule's unit list: [resident feature units | streamed units]
     int n_pdescs = 0;
-    size_t lds_persist = 0;         // streaming form (k_persist)
     size_t lds_president = 0;       // resident form (k_president)
     int chunk_cols_req = 0;         // chunk_cols the caller asked for at creation (the fallback layout is built with the same request)
     int fell_back = 0;              // the resident schedule was given up for launch-per-phase inside a train() call (roll call never complete)
@@ -191,7 +190,7 @@ static hipError_t set_lds(KT kernel, size_t bytes) {
 // mfas_population_plan() answers it on its own (the host's capacity planning, ntu_searchable._plan_rounds).
 // ------------------------------------------------------------------------------------------------
 struct LayoutPlan {
-    bool want_persist = false, force_persist = false;
+    bool want_persist = false;
     int target = 0, nu = 1;          // feature-column chunk (0: the launch-per-phase heuristics of create_impl decide), units per resident workgroup
     bool plan_res = false;           // the chunk was chosen for the resident schedule
     int nfeat = 0, max_fcc = 0;      // feature units and the widest of them at that chunk
@@ -219,7 +218,7 @@ static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs
     // schedule at 4..28 candidates per GPU); the streaming form (larger R, or units that do not fit) is slower than
     // launch-per-phase (x0.8-0.9) and only runs when forced.  MFAS_PERSIST=1/0 overrides.
     lp.want_persist = allow_persist;
-    if (const char* e = getenv("MFAS_PERSIST")) { lp.want_persist = allow_persist && atoi(e) != 0; lp.force_persist = lp.want_persist; }
+    if (const char* e = getenv("MFAS_PERSIST")) lp.want_persist = allow_persist && atoi(e) != 0;
     // (lean-chain feasibility, same formula as the LDS budget in create_impl: resident units exist only together with the resident
     // lean chain — k_president; everything else that is forced persistent runs the streaming form)
     const size_t lean_bytes = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
@@ -346,7 +345,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     }
     LayoutPlan lp;
     plan_layout(hp, g, confs, n_cells, K, chunk_cols, p->n_cus, allow_persist, lp);
-    const bool want_persist = lp.want_persist, force_persist = lp.force_persist;
+    const bool want_persist = lp.want_persist;
     int target = lp.target;
     const int plan_nu = lp.nu;
     target = std::max(16, (target / 16) * 16);
@@ -518,7 +517,6 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             return MFAS_RETRY_NO_PERSIST;
         }
         const size_t lds_rchain = p->res_chain ? p->lds_chain + 16 + 4 * (size_t)LeanLds<1>::own_floats() : 0;
-        p->lds_persist = ((std::max(p->lds_step, p->lds_chain) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
         p->lds_president = ((std::max(lds_rchain, lds_res) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
     }
     p->nrbw = (g.nrb + 3) / 4;
@@ -568,11 +566,8 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
         {   // persistent step loop: small populations (one workgroup per CU must hold every chain + a useful number of sweep workgroups)
             const bool want = want_persist;
-            const int64_t n_stream = p->res_chain ? 0 : (int64_t)p->descs.size();   // (a resident lean chain owns OUT / HEAD)
-            const bool fits = K <= p->n_cus / 4 && g.MB != 4 && K + p->nres_wg + (n_stream > 0 ? 1 : 0) <= p->n_cus &&
-                              n_stream <= (int64_t)PERSIST_MAX_UNITS * (p->n_cus - K - p->nres_wg) &&
-                              (double)p->plane_stride * 4.0 < 3.9e9 && (double)step_off * 4.0 < 3.9e9 && (double)wt_off * 4.0 < 3.9e9;
-            p->persist = want && fits && (p->res_chain || force_persist);
+            const bool fits = K <= p->n_cus / 4 && g.MB != 4 && K + p->nres_wg <= p->n_cus;
+            p->persist = want && fits && p->res_chain;
             if (p->persist) ngroups = 1;
             else if (p->nres > 0) {   // units and LDS budgets were laid out for resident units: start over without them
                 mfas_population_destroy(p);
@@ -696,21 +691,17 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     CREATE_CHK(set_lds((k_chain<1, true>), p->lds_chain));
     CREATE_CHK(set_lds((k_chain<2, true>), p->lds_chain));
     if (p->persist) {
-        {   // unit list of the persistent schedule: resident feature units first, then the streamed units (largest first)
-            std::vector<SegDesc> res, rest;
-            for (const SegDesc& d : p->descs) {
-                if (p->res_chain) { if (d.kind <= KIND_V) res.push_back(d); }     // (a resident lean chain updates OUT / HEAD itself)
-                else rest.push_back(d);
-            }
-            std::stable_sort(rest.begin(), rest.end(), [](const SegDesc& x, const SegDesc& y) { return x.cc * x.rows_p > y.cc * y.rows_p; });
-            res.insert(res.end(), rest.begin(), rest.end());
+        {   // unit list of the resident schedule: the feature units (the resident lean chain updates OUT / HEAD itself)
+            std::vector<SegDesc> res;
+            for (const SegDesc& d : p->descs)
+                if (d.kind <= KIND_V) res.push_back(d);
             p->n_pdescs = (int)res.size();
             CREATE_CHK(hipMalloc(&p->d_pdescs, sizeof(SegDesc) * res.size()));
             CREATE_CHK(hipMemcpy(p->d_pdescs, res.data(), sizeof(SegDesc) * res.size(), hipMemcpyHostToDevice));
         }
         std::vector<int32_t> need(K, 0);
         for (const SegDesc& d : p->descs)
-            if (!(p->res_chain && d.kind > KIND_V)) need[d.cand]++;
+            if (d.kind <= KIND_V) need[d.cand]++;
         CREATE_CHK(hipMalloc(&p->d_need, sizeof(int32_t) * K));
         CREATE_CHK(hipMemcpy(p->d_need, need.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice));
         CREATE_CHK(hipMalloc(&p->d_sync, sizeof(uint32_t) * ((size_t)K * PERSIST_SYNC_STRIDE + 64)));
@@ -718,18 +709,11 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             CREATE_CHK(hipMalloc(&p->d_trace, sizeof(unsigned long long) * 256));
             CREATE_CHK(hipMemset(p->d_trace, 0, sizeof(unsigned long long) * 256));
         }
-        if (p->res_chain) {
 #define SET_RES(M) CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 1>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 2>), p->lds_president)); \
                    CREATE_CHK(set_lds((k_president<M, PERSIST_NTR16, true, 1>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 1>), p->lds_president)); \
                    CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2>), p->lds_president))
-            SET_RES(1); SET_RES(2);
+        SET_RES(1); SET_RES(2);
 #undef SET_RES
-        } else {
-            CREATE_CHK(set_lds((k_persist<1, false, 2>), p->lds_persist));
-            CREATE_CHK(set_lds((k_persist<2, false, 2>), p->lds_persist));
-            CREATE_CHK(set_lds((k_persist<1, true, 2>), p->lds_persist));
-            CREATE_CHK(set_lds((k_persist<2, true, 2>), p->lds_persist));
-        }
     }
     // W/m/v beyond what the 256 MiB Infinity Cache can keep between steps are streamed nontemporally
     p->nontemporal = (double)p->plane_stride * 12.0 > 200.0 * 1024 * 1024;
@@ -1117,10 +1101,8 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         pa.N = N; pa.pos0 = (int64_t)ep * N;
         pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);
         pa.scal = p->d_scal; pa.sync = p->d_sync; pa.need = p->d_need; pa.trace = p->d_trace;
-        const int n_stream = p->res_chain ? 0 : pa.nitems;
-        const unsigned grid = (unsigned)(K + pa.nres_wg + (n_stream > 0 ? std::max(1, std::min(n_stream, p->n_cus - K)) : 0));
-        const int ldsw = (int)(p->lds_persist / 4) - PERSIST_LDS_WORDS;
-        if ((n_stream > 0 && n_stream > PERSIST_MAX_UNITS * (int)(grid - K)) || (int)grid > p->n_cus) return hipErrorInvalidConfiguration;
+        const unsigned grid = (unsigned)(K + pa.nres_wg);
+        if ((int)grid > p->n_cus) return hipErrorInvalidConfiguration;
         const bool prof = p->profiling;
         if (prof) {
             if (p->ev.size() < ev_used + 2) {
@@ -1130,7 +1112,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             }
             hipEventRecord(p->ev[ev_used], p->stream);
         }
-        if (p->res_chain) {      // resident form: one instantiation per unit form
+        {      // one instantiation per unit form
             const int lw = (int)(p->lds_president / 4) - PERSIST_LDS_WORDS;
 #define RES_LAUNCH(M, NTR, X, NU) hipLaunchKernelGGL((k_president<M, NTR, X, NU>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw)
 #define RES_PICK(M) do { if (train->dtype == MFAS_DT_F32) { if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, false, 2); else RES_LAUNCH(M, PERSIST_NTR, false, 1); } \
@@ -1139,12 +1121,6 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             if (g.MB == 1) RES_PICK(1); else RES_PICK(2);
 #undef RES_PICK
 #undef RES_LAUNCH
-        } else {
-#define PERSIST_LAUNCH(M, F) hipLaunchKernelGGL((k_persist<M, F, 2>), dim3(grid), dim3(STEP_THREADS), p->lds_persist, p->stream, pa, ldsw)
-        if (p->lean_chain) { if (g.MB == 1) PERSIST_LAUNCH(1, true); else PERSIST_LAUNCH(2, true); }
-        else if (g.MB == 1) PERSIST_LAUNCH(1, false);
-        else PERSIST_LAUNCH(2, false);
-#undef PERSIST_LAUNCH
         }
         if (prof) {
             hipEventRecord(p->ev[ev_used + 1], p->stream);

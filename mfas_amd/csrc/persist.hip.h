@@ -3,27 +3,30 @@
 // (part of the single translation unit mfas_hip.hip; see the header comment there and DESIGN.md)
 #pragma once
 // ------------------------------------------------------------------------------------------------
-// With a handful of candidates a train step is a latency chain, not a bandwidth problem: chain(c,t) -> sweep(c,t) ->
+// With a handful of candidates a train step is a latency chain, not a bandwidth problem: chain(c,t) -> units(c,t) ->
 // chain(c,t+1), and the launch-per-phase schedule (k_chain / k_step) additionally serialises ALL candidates' sweeps against
-// ALL chains at every kernel boundary.  k_persist is ONE launch per epoch: every workgroup is resident (one per CU) and
+// ALL chains at every kernel boundary.  k_president is ONE launch per epoch: every workgroup is resident (one per CU) and
 // loops over the epoch's train steps; dependencies are per CANDIDATE:
-//   * chain workgroup c (blocks [0, K)) waits until the arrival counter cnt[c] shows that every sweep unit of candidate c
+//   * chain workgroup c (blocks [0, K)) waits until the arrival counter cnt[c] shows that every feature unit of candidate c
 //     has finished step t-1 (its W/m/v update and the forward partial sums of batch t), runs the chain of step t and
 //     publishes flag[c] = t + 1;
-//   * sweep workgroups (the remaining blocks; unit i is owned by workgroup i mod G, fixed for the whole launch) wait for
-//     flag[cand(i)] >= t + 1, run the unit's dW + Adam + next-step forward and arrive on cnt[cand(i)].
-// So while candidate A sits in its serial chain, the CUs stream the sweeps of the candidates whose chains have finished.
-// Data exchanged inside the launch (dy / out_i / dlogits from the chain; partial sums and the OUT / HEAD weight tiles from
-// the sweep) is stored write-through and loaded with sc1 (COH helpers, common.hip.h): no release / acquire fences, whose
-// L2 write-back would drag the whole XCD's dirty W/m/v lines along.  Every storing wave drains (`s_waitcnt vmcnt(0)`) before the
-// workgroup barrier that precedes the relaxed agent-scope flag store / counter add; pollers are ONE lane per workgroup,
-// relaxed loads + s_sleep, bounded (a timeout sets the abort word, every workgroup leaves, the host reports an error).
+//   * unit workgroups (the remaining blocks; fixed ownership for the whole launch) wait for flag[cand(i)] >= t + 1, run the
+//     unit's dW + Adam + next-step forward and arrive on cnt[cand(i)].
+// So while candidate A sits in its serial chain, the CUs serve the units of the candidates whose chains have finished.
+// Data exchanged inside the launch (dy from the chain; partial sums from the units) is stored write-through and loaded with
+// sc1 (COH helpers, common.hip.h): no release / acquire fences, whose L2 write-back would drag the whole XCD's dirty lines
+// along.  Every storing wave drains (`s_waitcnt vmcnt(0)`) before the workgroup barrier that precedes the relaxed agent-scope
+// flag store / counter add; pollers are ONE lane per workgroup, relaxed loads + s_sleep, bounded (a timeout sets the abort
+// word, every workgroup leaves, the host reports an error).
 // Reduction orders, tile decomposition and arithmetic are those of the launch-per-phase schedule: results are bit-identical.
+// (Rounds 2-3 also carried a STREAMING form — any R, units streaming W/m/v from memory like k_step, general or lean chain
+//  exchanging everything through memory — that was measured 0.8-1.1x of launch-per-phase (profiles/r02_popsweep_general_chain.log,
+//  DESIGN.md 5a/5b), ran only when forced, spilled, and hung on the device after an unrelated edit: removed in round 3.)
 // ------------------------------------------------------------------------------------------------
 struct PersistArgs {
     SweepArgs sa;              // desc = the population's sweep units (per-segment), cands = all candidates
     ChainArgs ca;              // cands = all candidates
-    int32_t nchain, nitems;    // K, number of sweep units
+    int32_t nchain, nitems;    // K, number of feature units
     int32_t res_wide, res_nu;  // resident units wider than 512 columns exist (16-bit staging, 8 tiles per wave); units per workgroup (1 / 2)
     int32_t nres_wg, res_buf_words;   // resident workgroups (blocks K .. K + nres_wg: unit u of workgroup w = w + u * nres_wg);
                                       // LDS words of one staged batch
@@ -45,12 +48,8 @@ struct PersistArgs {
 #define PERSIST_SYNC_STRIDE 64          // uint32 words per candidate in the sync area
 #define PERSIST_FLAG(sync, c) ((sync) + (size_t)(c) * PERSIST_SYNC_STRIDE)
 #define PERSIST_CNT(sync, c) ((sync) + (size_t)(c) * PERSIST_SYNC_STRIDE + 32)
-#define PERSIST_MAX_UNITS 8             // sweep units one workgroup may own
 #define PERSIST_LDS_WORDS 32            // LDS words the loop itself uses (behind the bodies' LDS)
-// step-phase timestamps (profiles/r02_persist_trace_k6_r16.log; MFAS_PERSIST_TRACE=1 in the environment allocates the buffer).
-// (Round 3 tried compiling these out of production builds: the streaming k_persist then hung on the device at its first launch —
-//  same source otherwise, same launch parameters; with the run-time branches back it runs.  Not understood; the branches cost a
-//  pointer and a compare per site, so they stay.)
+// step-phase timestamps (profiles/r02_persist_trace_k6_r16.log; MFAS_PERSIST_TRACE=1 in the environment allocates the buffer)
 #define PTRACE(slot) do { if (a.trace && tr_on) a.trace[tr_base + (slot)] = wall_clock64(); } while (0)
 #define PTRACE_UNIT(base) do { if (a.trace && un.cand == 0 && t == 12 && tid == 0 && un.index < 64) a.trace[(base) + un.index] = wall_clock64(); } while (0)
 #define PERSIST_SPIN_LIMIT (1u << 22)   // a few seconds of s_sleep polls: only a lost workgroup or a bug gets here
@@ -406,8 +405,7 @@ __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, c
 // k_president<MB, NTR, X16, NU> — the RESIDENT schedule (the default for small populations at R <= 16): ONE launch per epoch,
 // blocks [0, K) = the resident lean chain of candidate blockIdx.x, blocks [K, K + nres_wg) = workgroups of resident feature
 // units.  One instantiation per unit form (staging width, tiles per wave, units per workgroup): an instantiation carries exactly
-// the two bodies its grid runs — the streaming units, the non-resident chains and the run-time dispatch over unit forms live in
-// k_persist below.  (Round 3 also ran the two roles as two kernels on two streams, each with its own register budget — the unit
+// the two bodies its grid runs.  (Round 3 also ran the two roles as two kernels on two streams, each with its own register budget — the unit
 // kernels then need 109-184 VGPRs and no scratch, the chain kernel 231-255: the step time did not move (15.4-15.5 us at 4-8
 // candidates, profiles/r03_popsweep_split_kernels.log), and co-residency of two launches depends on the streams landing on different
 // hardware queues, which HIP does not promise: after a few hundred stream creations in one process the second launch queued
@@ -453,118 +451,4 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
         lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the feature units run
     }
     lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_persist — the STREAMING form (any R; forced only, MFAS_PERSIST=1: measured slower than launch-per-phase): blocks [0, K) run
-// the chains (lean MODE 1 or the general chain_body, everything exchanged through memory), the remaining blocks own the sweep
-// units (unit i -> workgroup i mod G, fixed for the launch) and stream their W/m/v like k_step.
-// ------------------------------------------------------------------------------------------------
-template <int MB, bool LEAN, int U>
-__global__ void __launch_bounds__(STEP_THREADS, 2) k_persist(const PersistArgs a, const int lds_word) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
-    const int bid = (int)blockIdx.x, tid = threadIdx.x;
-    const int K = a.nchain;
-    uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
-    if (!persist_roll_call(a.sync, K, gridDim.x, ldsw)) return;
-
-    if (bid < K) {
-        // ------------------------------------------------------------------ chain workgroup of candidate `bid`
-        const uint32_t need = (uint32_t)a.need[bid];
-        for (int t = 0; t < a.T; ++t) {
-            const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
-            const int tr_base = (t - 8) * 8;
-            PTRACE(0);
-            if (!wg_wait_ge(PERSIST_CNT(a.sync, bid), need * (uint32_t)(t + 1), abortw, ldsw)) return;
-            PTRACE(1);
-            ChainStep cs;
-            cs.pos_t = a.pos0 + (int64_t)t * a.B;
-            cs.base_t = t * a.B;
-            cs.nvalid = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
-            cs.gstep = a.gstep0 + t;
-            cs.epoch = a.epoch;
-            cs.ss = a.scal[2 * (int64_t)cs.gstep];
-            cs.bc2s = a.scal[2 * (int64_t)cs.gstep + 1];
-            if constexpr (LEAN) chain_lean<MB, 1>(a.ca, cs, bid, lds);
-            else chain_body<MB, true, true>(a.ca, cs, bid, lds);
-            PTRACE(2);
-            wg_publish_barrier();
-            if (tid == 0 && !(bid == 0 && t == a.lose_step))
-                __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            PTRACE(3);
-            if constexpr (LEAN) chain_lean_tail<MB, 1>(a.ca, cs, bid, lds);
-        }
-        return;
-    }
-    // ---------------------------------------------------------------------- sweep workgroup: owns units wg, wg + G, ...
-    // Ownership is FIXED for the whole launch: a unit's W/m/v stream through plain (not write-through) stores and are only
-    // ever re-read by the same CU, so they stay coherent without any fence.  A workgroup that owns several units serves
-    // whichever of them is ready (its candidate's chain has published the step the unit is waiting for): units of different
-    // candidates never block each other (in-order service convoys all candidates behind the slowest chain).
-    const int G = (int)gridDim.x - K, wg = bid - K;
-    const int n_gen = a.nitems;
-    const int n_my = wg < n_gen ? (n_gen - wg + G - 1) / G : 0;   // <= PERSIST_MAX_UNITS (host)
-    int* nxt = ldsw + 8;                     // next step of my j-th unit (-1 = the epoch's prologue: forward of batch 0, no update)
-    int* cnd = ldsw + 8 + PERSIST_MAX_UNITS; // its candidate
-    if (tid < n_my) {
-        nxt[tid] = -1;
-        cnd[tid] = a.sa.desc[wg + tid * G].cand;
-    }
-    __syncthreads();
-    int last = n_my - 1;
-    for (;;) {
-        if (tid == 0) {
-            int pick = -2;   // -2: every unit has finished its last step
-            uint32_t spins = 0;
-            for (;;) {
-                bool pending = false;
-                for (int q = 1; q <= n_my; ++q) {
-                    const int j = (last + q) % n_my;
-                    const int tj = nxt[j];
-                    if (tj >= a.T) continue;
-                    pending = true;
-                    if (tj < 0 || ld_u32_relaxed(PERSIST_FLAG(a.sync, cnd[j])) >= (uint32_t)(tj + 1)) { pick = j; break; }
-                }
-                if (pick >= 0 || !pending) break;
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 0x3FFu) == 0 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
-                    __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    pick = -3;
-                    break;
-                }
-            }
-            ldsw[0] = pick;
-        }
-        __syncthreads();
-        const int pick = ldsw[0];
-        if (pick < 0) return;
-        const int t = nxt[pick], cand = cnd[pick], it = wg + pick * G;
-        __syncthreads();   // everyone has read the pick before lane 0 can overwrite it
-        last = pick;
-        SweepStep st;
-        const int tt = t < 0 ? 0 : t;
-        st.upd = t >= 0;
-        st.fwd = t + 1 < a.T;
-        st.pos_t = a.pos0 + (int64_t)tt * a.B;
-        st.base_t = tt * a.B;
-        st.nvalid_t = (int)min((int64_t)a.B, a.N - (int64_t)tt * a.B);
-        const int tn = t + 1;
-        st.pos_n = a.pos0 + (int64_t)tn * a.B;
-        st.base_n = tn * a.B;
-        st.nvalid_n = (int)min((int64_t)a.B, a.N - (int64_t)tn * a.B);
-        st.ss = t >= 0 ? a.scal[2 * (int64_t)(a.gstep0 + t)] : 0.f;
-        st.bc2s = t >= 0 ? a.scal[2 * (int64_t)(a.gstep0 + t) + 1] : 1.f;
-        const bool tr_on = it == 0 && tid == 0 && t >= 8 && t < 16;
-        const int tr_base = (t - 8) * 8 + 4;
-        PTRACE(1);
-        sweep_body<MB, false, U, true>(a.sa, st, it, lds);
-        PTRACE(2);
-        wg_publish_barrier();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(PERSIST_CNT(a.sync, cand), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            nxt[pick] = t + 1;
-        }
-        PTRACE(3);
-    }
 }

@@ -670,9 +670,8 @@ def test_full_size_properties(dev):
     b = run(8, 1, seeds)
     assert a.tobytes() == b.tobytes(), "fused vs back-to-back schedule differ"   # (1)
     # (1b, round 2) reduce-in-sweep (the last feature workgroup of a cell sums the partial slabs) vs the chain reducing them
-    # itself, and the persistent step loop in its streaming form (one launch per epoch, per-candidate flags): same bits
+    # itself: same bits
     assert run(8, 2, seeds, env=(("MFAS_NO_RED_IN_SWEEP", "1"),)).tobytes() == a.tobytes(), "reduce-in-sweep changes results"
-    assert run(8, 1, seeds, env=(("MFAS_PERSIST", "1"),)).tobytes() == a.tobytes(), "persistent (streaming) step loop differs"
     # (1c) `b` ran the same-group fused launch (one launch per step, units released per cell: the default at this size); the plain
     # two-launch schedule (k_chain, then the sweep) must give the same bits as well
     assert run(8, 1, seeds, env=(("MFAS_SAME_GROUP", "0"),)).tobytes() == a.tobytes(), "same-group fused launch differs"

@@ -37,8 +37,6 @@ for K in Ks:
     for mode in ("0", "1"):          # "1" = the engine's default policy (persistent where the resident form fits), "0" = forced off
         if mode == "0":
             os.environ["MFAS_PERSIST"] = "0"
-        elif "force" in sys.argv:            # A/B: the persistent schedule wherever it can be laid out (streaming form beyond R = 16)
-            os.environ["MFAS_PERSIST"] = "1"
         else:
             os.environ.pop("MFAS_PERSIST", None)
         best = None
