@@ -119,7 +119,7 @@ struct ResUnit {              // wave-uniform constants of one resident unit
     const void* tp;
     int64_t part, dyo, gsco;  // step-buffer indices: partial slot, dy_i, alpha scale
     float *Wp, *Mp, *Vp;
-    const int32_t* ord;       // the sample order its candidate walks
+    int32_t gidx;             // its candidate's population index (selects the sample order it walks)
     uint32_t *flag, *cnt;
     int32_t xb0, xbw;         // the two staged batches in LDS: word offsets xb0 and xb0 + xbw (a pointer picked at run time would be a
                               // flat pointer; a two-element ARRAY indexed at run time parks the whole record in scratch memory)
@@ -159,7 +159,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         U[u].Wp = sa.plane + d.w_off;
         U[u].Mp = U[u].Wp + sa.plane_stride;
         U[u].Vp = U[u].Mp + sa.plane_stride;
-        U[u].ord = cand_order(sa.order, sa.g, cd.gidx);
+        U[u].gidx = cd.gidx;
         U[u].flag = PERSIST_FLAG(a.sync, d.cand);
         U[u].cnt = PERSIST_CNT(a.sync, d.cand);
         U[u].xb0 = (2 * u) * a.res_buf_words;
@@ -193,9 +193,9 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
     auto stage = [&](const ResUnit& un, float* dst, int t) {     // rows of batch t -> LDS
         const int nv = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
         if constexpr (X16)
-            stage_table16(reinterpret_cast<uint16_t*>(dst), un.S, un.tp, un.width, un.k0, un.cc, un.ord, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
+            stage_table16(reinterpret_cast<uint16_t*>(dst), un.S, un.tp, un.width, un.k0, un.cc, cand_order(sa.order, sa.g, un.gidx), a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
         else
-            stage_table(dst, un.S, un.tp, sa.tab.dtype, un.width, un.k0, un.cc, un.ord, a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
+            stage_table(dst, un.S, un.tp, sa.tab.dtype, un.width, un.k0, un.cc, cand_order(sa.order, sa.g, un.gidx), a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
     };
     // cross-wave reduction of a forward partial (fixed order 0..7, as sweep_body) -> partial slot (write-through) -> arrive
     auto reduce_publish = [&](const ResUnit& un, const f32x4 (&yacc)[MB]) {
