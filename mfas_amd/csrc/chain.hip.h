@@ -302,7 +302,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     constexpr int Bp = MB * 16;
     // (co-scheduled builds of the two-batch-block chain live in 128 VGPRs: 4 tiles per batch in the same-group launch, where the chain
     //  is on the critical path, 2 under the other group's sweep — k_step<2,*,4,false> spilled 31 registers with 8, none with 2)
-    constexpr int CHAIN_TW = (MB >= 2 && !PF) ? (COH ? 4 : 2) : 8;
+    constexpr int CHAIN_TW = (MB >= 2 && !PF) ? (COH ? 4 : 2) : (MB >= 4 ? 4 : 8);
     constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;   // softmax lanes per batch row
     const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
     const int SX = Rp + 4, SC = Cp + 4;
@@ -430,7 +430,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     __syncthreads();
 
     // one row block per wave and <= 8 k-blocks per product: register-prefetched tiles (wa = current, wb = next)
-    const bool pf = PF && nrb <= CHAIN_NW && ncb <= CHAIN_NW;
+    // (MB = 4, B > 32: four batch blocks of accumulators leave no room for two prefetched tile sets — 130 spilled registers with them)
+    const bool pf = PF && MB < 4 && nrb <= CHAIN_NW && ncb <= CHAIN_NW;
     f32x4 wa[8], wb[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { wa[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; wb[u] = wa[u]; }
