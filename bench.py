@@ -296,9 +296,8 @@ def main():
         achieved = bytes_per_launch / (ms / n_launch * 1e-3) / 1e9 if n_launch else None
         sched = NS.PROFILE[-1][3] if NS.PROFILE else {}
         if sched.get("persistent"):
-            kernel = (("k_president" if sched.get("resident_units") else "k_persist") + " (ONE launch per epoch: per-candidate chain workgroups + "
-                      + (f"{sched['resident_units']} feature units resident in registers on {sched['resident_workgroups']} workgroups" if sched.get("resident_units")
-                         else "streaming feature units")
+            kernel = ("k_president (ONE launch per epoch: per-candidate chain workgroups + "
+                      + f"{sched['resident_units']} feature units resident in registers on {sched['resident_workgroups']} workgroups"
                       + "; algorithmic bytes = what one epoch of a streaming schedule moves (24 B/param/step + taps): resident W/m/v never touch HBM, "
                         "so `achieved` is a nominal rate for comparison, the loop itself is latency-bound, DESIGN.md 4a)")
         else:

@@ -214,13 +214,13 @@ static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs
     // Persistent step loop (persist.hip.h): with one row block (R <= 16) the feature units become RESIDENT (one workgroup per
     // unit, or two units per workgroup; W/m/v in registers): the column chunk is then the smallest of 128 / 256 / 512 / 1024
     // columns with which every chain and every unit workgroup gets a CU of its own.
-    // Default (measured, profiles/r02_popsweep_*.log): ON where the resident form fits (x1.6-2.1 over the launch-per-phase
-    // schedule at 4..28 candidates per GPU); the streaming form (larger R, or units that do not fit) is slower than
-    // launch-per-phase (x0.8-0.9) and only runs when forced.  MFAS_PERSIST=1/0 overrides.
+    // Default (measured, profiles/r02_popsweep_*.log, r03_popsweep.log): ON where the resident form fits (x1.6-2.1 over the
+    // launch-per-phase schedule at 4..28 candidates per GPU).  Nothing else is persistent: the streaming form of round 2 (larger R,
+    // or units that do not fit; x0.8-0.9 of launch-per-phase) was removed in round 3.  MFAS_PERSIST=0 turns the schedule off.
     lp.want_persist = allow_persist;
     if (const char* e = getenv("MFAS_PERSIST")) lp.want_persist = allow_persist && atoi(e) != 0;
     // (lean-chain feasibility, same formula as the LDS budget in create_impl: resident units exist only together with the resident
-    // lean chain — k_president; everything else that is forced persistent runs the streaming form)
+    // lean chain — k_president; a population without both runs launch-per-phase)
     const size_t lean_bytes = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
                                + (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.MB * 256 + (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp)
                                + LEAN_SCR + 8) * 4;

@@ -688,7 +688,7 @@ def test_full_size_properties(dev):
 @pytest.mark.parametrize("K,B,bn,cc,mixed", [(6, 20, False, 256, False), (9, 20, True, 128, True), (7, 16, True, 512, True), (16, 16, False, 1024, False)])
 def test_persistent_resident_schedule_bit_identical_full_size(dev, K, B, bn, cc, mixed):
     """Search-script defaults at full size (R=16, N_train=10,000, N_dev=5,600, bf16 taps, drpt 0.5, shuffled, E=2): the
-    persistent resident schedule (k_persist: W/m/v in registers, resident lean chain, per-candidate flags — the default for
+    persistent resident schedule (k_president: W/m/v in registers, resident lean chain, per-candidate flags — the default for
     small populations) against the launch-per-phase schedule on the same units: statistics, parameters and both Adam moments
     must be bit-identical; 1024-column units exercise the raw 16-bit staging."""
     import os

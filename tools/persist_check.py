@@ -1,6 +1,6 @@
-"""Persistent step loop (MFAS_PERSIST=1) vs the launch-per-phase schedule on the same small population: results must be
+"""Persistent resident step loop (the default where it fits; MFAS_PERSIST=0 turns it off) vs the launch-per-phase schedule on the same small population: results must be
 bit-identical (statistics and every parameter / Adam moment); prints cand/s of both.
-usage: persist_check.py R B bn K E [N_train N_dev] [mixed] [cc=COLS] [steps=N]"""
+usage: persist_check.py R B bn K E [N_train N_dev] [mixed] [cc=COLS] [steps=N] [toggle=ENV [persist]]"""
 import os
 import sys
 import time
@@ -34,7 +34,10 @@ toggle = next((a.split("=")[1] for a in sys.argv if a.startswith("toggle=")), No
 res = {}
 for mode in ("0", "1", "0", "1"):
     if toggle:
-        os.environ["MFAS_PERSIST"] = "1" if "force=1" in sys.argv else "0"
+        if "persist" in sys.argv:                     # toggle under the default (resident where it fits) schedule ...
+            os.environ.pop("MFAS_PERSIST", None)
+        else:                                         # ... or under launch-per-phase
+            os.environ["MFAS_PERSIST"] = "0"
         if mode == "0":
             os.environ[toggle] = "1"
         else:
