@@ -358,9 +358,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     }
     const int nvalid = cs.nvalid;
     const float nf = (float)nvalid;
-    AdamC ac = a.ac;
-    ac.ss = cs.ss;
-    ac.bc2s = cs.bc2s;
+    const AdamC ac = adam_consts(a.ac, cs.ss, cs.bc2s);
     const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(cs.gstep + 1));
     const int64_t sbo = cd.step_off;   // this candidate's step buffers inside a.stepbuf (COH accesses index from the base)
 
@@ -874,9 +872,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
     const int nvalid = cs.nvalid;
     const float nf = (float)nvalid;
-    AdamC ac = a.ac;
-    ac.ss = cs.ss;
-    ac.bc2s = cs.bc2s;
+    const AdamC ac = adam_consts(a.ac, cs.ss, cs.bc2s);
     const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(cs.gstep + 1));
     const int64_t sbo = cd.step_off;
 
@@ -1230,9 +1226,7 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
     const float* gv2 = ll.scr + 256;
     const int64_t cvec_off = cd.vec_off;
     const int cgidx = cd.gidx;
-    AdamC ac = a.ac;
-    ac.ss = cs.ss;
-    ac.bc2s = cs.bc2s;
+    const AdamC ac = adam_consts(a.ac, cs.ss, cs.bc2s);
     // parameters + moments: the LDS copy (MODE 2: the master copy; MODE 0 / 1: what chain_lean staged at entry — only the running
     // statistics and nothing below have been written since)
     const float* vecW = vec_l;
@@ -1346,9 +1340,6 @@ __device__ __forceinline__ void lean_res_update(const ChainArgs& a, const ChainS
     if (wave >= 1 && wave < L) { s = wave - 1; x = ll.xo_l + (wave - 1) * Bp * SX; dy = ll.dy_l + wave * Bp * SX; }
     else if (wave >= 4 && wave - 4 < g.ncb) { s = 3 + (wave - 4); x = ll.xo_l + (L - 1) * Bp * SX; dy = ll.lg_l; sd = ll.SC; dcol = (wave - 4) * 16; }
     if (s >= 0) {
-        AdamC ac = a.ac;
-        ac.ss = cs.ss;
-        ac.bc2s = cs.bc2s;
         float* oW = ll.own + s * 256 + lane * 4;
         float* oM = oW + LEAN_OWN_TILES * 256;
         float* oV = oM + LEAN_OWN_TILES * 256;
@@ -1358,12 +1349,7 @@ __device__ __forceinline__ void lean_res_update(const ChainArgs& a, const ChainS
         for (int j = 0; j < MB * 4; ++j)
             acc = MFMA16(x[(4 * j + lg) * sx + l15], dy[(4 * j + lg) * sd + dcol + l15], acc);
         const float gsc = 1.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float w = w4[q], m = m4[q], v = v4[q];
-            adam1(w, m, v, acc[q] * gsc, ac);
-            w4[q] = w; m4[q] = m; v4[q] = v;
-        }
+        adam4(w4, m4, v4, acc * gsc, cs.ss, cs.bc2s, a.ac.w1, a.ac.b2, a.ac.w2, a.ac.eps, a.ac.wd);
         *reinterpret_cast<f32x4*>(oW) = w4;
         *reinterpret_cast<f32x4*>(oM) = m4;
         *reinterpret_cast<f32x4*>(oV) = v4;

@@ -6,6 +6,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Explicit LDS / global address spaces for pointers whose provenance the compiler cannot see (a buffer picked by a runtime
 // index, "in LDS if it fits, else scratch"): a generic pointer is accessed with FLAT instructions, and every flat load is
 // followed by s_waitcnt vmcnt(0) lgkmcnt(0) -- it drains all of the wave's prefetches in flight.
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 / uint2 classes have no address-space-qualified operators)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define MFAS_LDS __attribute__((address_space(3)))
@@ -87,6 +88,13 @@ struct DevStats {
 struct AdamC {
     float ss, bc2s, w1, b2, w2, eps, wd;
 };
+// field-by-field copy out of the kernel arguments with this step's step size / bias correction: a whole-struct copy is a 28-byte
+// memcpy into a stack object, which the vectoriser then reads back as <4 x float> and the object stays in scratch
+__device__ __forceinline__ AdamC adam_consts(const AdamC& k, const float ss, const float bc2s) {
+    AdamC c;
+    c.ss = ss; c.bc2s = bc2s; c.w1 = k.w1; c.b2 = k.b2; c.w2 = k.w2; c.eps = k.eps; c.wd = k.wd;
+    return c;
+}
 
 struct Geo {             // geometry shared by all candidates of a population
     int32_t R, C, Rp, Cp, nrb, ncb, B, Bp, MB;
@@ -134,6 +142,66 @@ __device__ __forceinline__ float act_bwd(float a, float da, int nl) {
     return a > 0.0f ? da : 0.01f * da;   // leaky: sign(a) == sign(y)
 }
 
+// ---- Adam(+L2) on weights held in registers (torch.optim.Adam, foreach=False form; oracle/np_oracle.py adam_step) --------
+//     g += wd*w;  m += (1-b1)*(g-m);  v = v*b2 + ((1-b2)*g)*g;  denom = sqrt(v)/sqrt(bc2) + eps;  w -= (lr/bc1) * (m/denom)
+// The square root and the two divisions are written out as the correctly-rounding sequences the compiler's own f32 lowering
+// uses (v_sqrt_f32 + one-ulp neighbour test; v_rcp_f32 + Newton step, quotient + two fma residual corrections), WITHOUT the
+// range scaling / class fix-ups around them (v_div_scale / v_div_fmas / v_div_fixup, 2^32 pre-scaling of sqrt): 100 VALU
+// instructions per 4 elements, most of them packed (v_pk_fma_f32 / v_pk_mul_f32), instead of 200.  The results are the
+// IEEE-754 correctly rounded ones — bit for bit what sqrtf() and operator/ give — whenever no intermediate leaves the normal
+// range: v >= 2^-96 (below that sqrt(v)/sqrt(bc2) < 1.2e-13 and the neighbour test may be off by one ulp of THAT, i.e.
+// < 1e-20 absolute next to eps = 1e-8) and |m| >= 2^-100 (below that the quotient's residual underflows; the step it would
+// contribute is < 1e-22 * lr).  Zero, infinity and NaN behave as the library forms do (0/0 -> NaN, sqrt(0) = 0).
+// tools/adam_exact.hip compares both forms bit by bit on the GPU (profiles/r03_adam_exact.log).
+__device__ __forceinline__ f32x4 vfma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float y = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, y, 1.0f), y, y);
+}
+__device__ __forceinline__ f32x4 rcp_refined4(f32x4 d) {
+    f32x4 y;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) y[q] = __builtin_amdgcn_rcpf(d[q]);
+    return vfma4(vfma4(-d, y, (f32x4)(1.0f)), y, y);
+}
+// n / d given y = rcp_refined(d)
+__device__ __forceinline__ float div_by(float n, float d, float y) {
+    float q = n * y;
+    float r = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(r, y, q);
+}
+__device__ __forceinline__ f32x4 div_by4(f32x4 n, f32x4 d, f32x4 y) {
+    f32x4 q = n * y;
+    f32x4 r = vfma4(-d, q, n);
+    q = vfma4(r, y, q);
+    r = vfma4(-d, q, n);
+    return vfma4(r, y, q);
+}
+__device__ __forceinline__ float sqrt_rn(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __builtin_bit_cast(float, __builtin_bit_cast(int32_t, s) - 1);
+    const float up = __builtin_bit_cast(float, __builtin_bit_cast(int32_t, s) + 1);
+    const float vp = __builtin_fmaf(-dn, s, x), vs = __builtin_fmaf(-up, s, x);
+    s = vp <= 0.0f ? dn : s;
+    return vs > 0.0f ? up : s;
+}
+__device__ __forceinline__ f32x4 sqrt_rn4(f32x4 x) {
+    f32x4 s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = __builtin_amdgcn_sqrtf(x[q]);
+    const f32x4 dn = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, s) - 1);
+    const f32x4 up = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, s) + 1);
+    const f32x4 vp = vfma4(-dn, s, x), vs = vfma4(-up, s, x);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        s[q] = vp[q] <= 0.0f ? dn[q] : s[q];
+        s[q] = vs[q] > 0.0f ? up[q] : s[q];
+    }
+    return s;
+}
+#ifdef MFAS_ADAM_LIBRARY_FORMS      // the reference form of the same arithmetic (tools/adam_exact.hip builds both)
 __device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, const AdamC& c) {
     g = g + c.wd * w;
     m = m + c.w1 * (g - m);
@@ -142,6 +210,39 @@ __device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, con
     const float denom = sqrtf(v) / c.bc2s + c.eps;
     w = w - c.ss * (m / denom);
 }
+__device__ __forceinline__ void adam4(f32x4& w, f32x4& m, f32x4& v, const f32x4 g, const AdamC& c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float w1 = w[q], m1 = m[q], v1 = v[q];
+        adam1(w1, m1, v1, g[q], c);
+        w[q] = w1; m[q] = m1; v[q] = v1;
+    }
+}
+#else
+__device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, const AdamC& c) {
+    g = g + c.wd * w;
+    m = m + c.w1 * (g - m);
+    v = v * c.b2;
+    v = v + (c.w2 * g) * g;
+    const float denom = div_by(sqrt_rn(v), c.bc2s, rcp_refined(c.bc2s)) + c.eps;
+    w = w - c.ss * div_by(m, denom, rcp_refined(denom));
+}
+// the same on the 4 elements a lane holds of a 16x16 tile (element-wise identical to adam1)
+__device__ __forceinline__ void adam4(f32x4& w, f32x4& m, f32x4& v, f32x4 g, const float ss, const float bc2s, const float w1,
+                                      const float b2, const float w2, const float eps, const float wd) {
+    g = g + wd * w;
+    m = m + w1 * (g - m);
+    v = v * b2;
+    v = v + (w2 * g) * g;
+    const f32x4 denom = div_by4(sqrt_rn4(v), (f32x4)(bc2s), (f32x4)(rcp_refined(bc2s))) + eps;
+    w = w - ss * div_by4(m, denom, rcp_refined4(denom));
+}
+// (callers read the AdamC fields into scalars OUTSIDE their tile loops and pass those: with the struct read inside the loop the
+// stack object survives into code generation — 24..32 bytes of scratch per lane)
+__device__ __forceinline__ void adam4(f32x4& w, f32x4& m, f32x4& v, const f32x4 g, const AdamC& c) {
+    adam4(w, m, v, g, c.ss, c.bc2s, c.w1, c.b2, c.w2, c.eps, c.wd);
+}
+#endif
 
 // cross entropy of one row of C logits against `lab` (one lane, serial): the constant unimodal terms of the multitask
 // loss, criteria[1](output[1], label) + criteria[2](output[2], label) (train_searchable/ntu.py:60-61)

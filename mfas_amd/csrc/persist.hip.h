@@ -175,7 +175,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
             v4[u][s] = *reinterpret_cast<const f32x4*>(U[u].Vp + off);
         }
     }
-    AdamC ac = sa.ac;
+    const float a_w1 = sa.ac.w1, a_b2 = sa.ac.b2, a_w2 = sa.ac.w2, a_eps = sa.ac.eps, a_wd = sa.ac.wd;   // scalars, not a struct copy (common.hip.h adam4)
 
     // MFMA operand reads from a staged batch: one element (dW: A[i = column][k = batch row]) / four consecutive columns
     auto x1 = [&](const float* xb, int S, int row, int col) -> float {
@@ -299,8 +299,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 for (int j = 0; j < MB * 4; ++j) dyf[j] = ldc1<true>(sa.stepbuf + un.dyo + (4 * j + lg) * 16 + l15);
                 float gsc = 1.0f;
                 if (sa.g.alphas) gsc = ldc1<true>(sa.stepbuf + un.gsco);
-                ac.ss = a.scal[2 * (int64_t)(a.gstep0 + t)];
-                ac.bc2s = a.scal[2 * (int64_t)(a.gstep0 + t) + 1];
+                const float a_ss = a.scal[2 * (int64_t)(a.gstep0 + t)], a_bc2s = a.scal[2 * (int64_t)(a.gstep0 + t) + 1];
                 f32x4 yacc[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -312,14 +311,9 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
 #pragma unroll
                         for (int j = 0; j < MB * 4; ++j)
                             acc = MFMA16(x1(xt, un.S, 4 * j + lg, kb * 16 + l15), dyf[j], acc);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float w = w4[u][s][q], m = m4[u][s][q], v = v4[u][s][q];
-                            adam1(w, m, v, acc[q] * gsc, ac);
-                            w4[u][s][q] = w;
-                            m4[u][s][q] = m;
-                            v4[u][s][q] = v;
-                        }
+                        { f32x4 w = w4[u][s], m = m4[u][s], v = v4[u][s];
+                          adam4(w, m, v, acc * gsc, a_ss, a_bc2s, a_w1, a_b2, a_w2, a_eps, a_wd);
+                          w4[u][s] = w; m4[u][s] = m; v4[u][s] = v; }
                         if (fwd) {
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) {

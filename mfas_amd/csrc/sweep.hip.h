@@ -14,6 +14,7 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
                                          const bool fwd, f32x4 (&yacc)[MB], float* T, const int tstride_rb,
                                          const int lane) {
     const int l15 = lane & 15, lg = lane >> 4;
+    const float a_ss = ac.ss, a_bc2s = ac.bc2s, a_w1 = ac.w1, a_b2 = ac.b2, a_w2 = ac.w2, a_eps = ac.eps, a_wd = ac.wd;
     for (int kbb = kb0; kbb < nkb; kbb += SWEEP_U * kbs) {
         f32x4 w4[SWEEP_U], m4[SWEEP_U], v4[SWEEP_U];
 #pragma unroll
@@ -42,14 +43,9 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
 #pragma unroll
                     for (int j = 0; j < MB * 4; ++j)
                         acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float w = w4[u][q], m = m4[u][q], v = v4[u][q];
-                        adam1(w, m, v, acc[q] * gsc, ac);
-                        w4[u][q] = w;
-                        m4[u][q] = m;
-                        v4[u][q] = v;
-                    }
+                    { f32x4 w = w4[u], m = m4[u], v = v4[u];
+                      adam4(w, m, v, acc * gsc, a_ss, a_bc2s, a_w1, a_b2, a_w2, a_eps, a_wd);
+                      w4[u] = w; m4[u] = m; v4[u] = v; }
                     if (NT) {
                         __builtin_nontemporal_store(w4[u], reinterpret_cast<f32x4*>(Wp + off));
                         __builtin_nontemporal_store(m4[u], reinterpret_cast<f32x4*>(Mp + off));
@@ -197,9 +193,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
     float* Wp = a.plane + d.w_off;
     float* Mp = Wp + a.plane_stride;
     float* Vp = Mp + a.plane_stride;
-    AdamC ac = a.ac;
-    ac.ss = upd ? st.ss : 0.f;
-    ac.bc2s = upd ? st.bc2s : 1.f;
+    const AdamC ac = adam_consts(a.ac, upd ? st.ss : 0.f, upd ? st.bc2s : 1.f);
     // alpha scaling of the gradient of S / V columns (aux_models.py:103-111): sigma(alpha_t) as used by this
     // step's forward, published by k_chain (alpha itself has already been stepped); 1.0 when alphas are off
     float gsc = 1.0f;
@@ -335,7 +329,7 @@ __device__ __forceinline__ void sweep_tap_body(const SweepArgs& a, const int bid
     float* Wp = a.plane + d.w_off[item];
     float* Mp = Wp + a.plane_stride;
     float* Vp = Mp + a.plane_stride;
-    const AdamC ac = a.ac;
+    const AdamC ac = adam_consts(a.ac, a.ac.ss, a.ac.bc2s);
     f32x4 yacc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
