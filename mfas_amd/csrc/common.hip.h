@@ -144,16 +144,26 @@ __device__ __forceinline__ float act_bwd(float a, float da, int nl) {
 
 // ---- Adam(+L2) on weights held in registers (torch.optim.Adam, foreach=False form; oracle/np_oracle.py adam_step) --------
 //     g += wd*w;  m += (1-b1)*(g-m);  v = v*b2 + ((1-b2)*g)*g;  denom = sqrt(v)/sqrt(bc2) + eps;  w -= (lr/bc1) * (m/denom)
-// The square root and the two divisions are written out as the correctly-rounding sequences the compiler's own f32 lowering
-// uses (v_sqrt_f32 + one-ulp neighbour test; v_rcp_f32 + Newton step, quotient + two fma residual corrections), WITHOUT the
-// range scaling / class fix-ups around them (v_div_scale / v_div_fmas / v_div_fixup, 2^32 pre-scaling of sqrt): 100 VALU
-// instructions per 4 elements, most of them packed (v_pk_fma_f32 / v_pk_mul_f32), instead of 200.  The results are the
-// IEEE-754 correctly rounded ones — bit for bit what sqrtf() and operator/ give — whenever no intermediate leaves the normal
-// range: v >= 2^-96 (below that sqrt(v)/sqrt(bc2) < 1.2e-13 and the neighbour test may be off by one ulp of THAT, i.e.
-// < 1e-20 absolute next to eps = 1e-8) and |m| >= 2^-100 (below that the quotient's residual underflows; the step it would
-// contribute is < 1e-22 * lr).  Zero, infinity and NaN behave as the library forms do (0/0 -> NaN, sqrt(0) = 0).
-// tools/adam_exact.hip compares both forms bit by bit on the GPU (profiles/r03_adam_exact.log).
+// The square root and the two divisions are written out as correctly-rounding fma sequences — sqrt: v_rsq_f32 seed, one coupled
+// Newton step, exact-residual correction (Markstein); division: v_rcp_f32 + Newton step, quotient + two fma residual corrections
+// (the compiler's own f32 division, minus its v_div_scale / v_div_fmas / v_div_fixup range handling) — on the 4 elements a lane
+// holds of a tile, so that nearly everything is a packed instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): ~50 VALU
+// instructions per 4 elements instead of the 200 of sqrtf() and operator/.  The results are the IEEE-754 correctly rounded ones
+// — bit for bit what sqrtf() and operator/ give — whenever no intermediate leaves the normal range: v >= 2^-102 (below that
+// the residual x - g*g is not exact; sqrt(v) < 4.5e-16 is then far inside the rounding of + eps) and |m| >= 2^-100 (below that
+// the quotient's residual underflows; the step it would contribute is < 1e-22 * lr).  sqrt(0) = 0; 0/0 -> NaN as in the library
+// form; m/0 (adam_eps = 0 with v = 0, not reachable from training) gives NaN where the library form gives +-inf.
+// tools/adam_exact.hip compares both forms bit by bit on the GPU — sqrt over every non-negative float, the whole update on
+// 7 x 64M sampled states (profiles/r03_adam_exact.log).
 __device__ __forceinline__ f32x4 vfma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+// a - b on two register pairs (the compiler lowers a <4 x float> subtraction to four v_sub_f32; v_pk_add_f32 takes neg modifiers)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pk_sub4(const f32x4 a, const f32x4 b) {
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(a.lo), "v"(b.lo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(a.hi), "v"(b.hi));
+    return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ float rcp_refined(float d) {
     const float y = __builtin_amdgcn_rcpf(d);
     return __builtin_fmaf(__builtin_fmaf(-d, y, 1.0f), y, y);
@@ -179,27 +189,26 @@ __device__ __forceinline__ f32x4 div_by4(f32x4 n, f32x4 d, f32x4 y) {
     r = vfma4(-d, q, n);
     return vfma4(r, y, q);
 }
+// sqrt: v_rsq_f32 seed, one coupled Newton step on (g ~ sqrt x, h ~ 1/(2 sqrt x)), then the exact-residual correction
+// g + (x - g*g) * h (Markstein's sequence).  tools/adam_exact.hip checks it against sqrtf for EVERY non-negative float.
+// min(., 2^64) only acts on rsq(0) = inf (sqrt(0) = 0 without a branch); rsq of any normal x is <= 2^63.
 __device__ __forceinline__ float sqrt_rn(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float dn = __builtin_bit_cast(float, __builtin_bit_cast(int32_t, s) - 1);
-    const float up = __builtin_bit_cast(float, __builtin_bit_cast(int32_t, s) + 1);
-    const float vp = __builtin_fmaf(-dn, s, x), vs = __builtin_fmaf(-up, s, x);
-    s = vp <= 0.0f ? dn : s;
-    return vs > 0.0f ? up : s;
+    const float y = fminf(__builtin_amdgcn_rsqf(x), 0x1p64f);
+    float g = x * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
 }
 __device__ __forceinline__ f32x4 sqrt_rn4(f32x4 x) {
-    f32x4 s;
+    f32x4 y;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s[q] = __builtin_amdgcn_sqrtf(x[q]);
-    const f32x4 dn = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, s) - 1);
-    const f32x4 up = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, s) + 1);
-    const f32x4 vp = vfma4(-dn, s, x), vs = vfma4(-up, s, x);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        s[q] = vp[q] <= 0.0f ? dn[q] : s[q];
-        s[q] = vs[q] > 0.0f ? up[q] : s[q];
-    }
-    return s;
+    for (int q = 0; q < 4; ++q) y[q] = fminf(__builtin_amdgcn_rsqf(x[q]), 0x1p64f);
+    f32x4 g = x * y, h = 0.5f * y;
+    const f32x4 r = vfma4(-h, g, (f32x4)(0.5f));
+    g = vfma4(g, r, g);
+    h = vfma4(h, r, h);
+    return vfma4(vfma4(-g, g, x), h, g);
 }
 #ifdef MFAS_ADAM_LIBRARY_FORMS      // the reference form of the same arithmetic (tools/adam_exact.hip builds both)
 __device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, const AdamC& c) {
@@ -231,11 +240,11 @@ __device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, con
 __device__ __forceinline__ void adam4(f32x4& w, f32x4& m, f32x4& v, f32x4 g, const float ss, const float bc2s, const float w1,
                                       const float b2, const float w2, const float eps, const float wd) {
     g = g + wd * w;
-    m = m + w1 * (g - m);
+    m = m + w1 * pk_sub4(g, m);
     v = v * b2;
     v = v + (w2 * g) * g;
     const f32x4 denom = div_by4(sqrt_rn4(v), (f32x4)(bc2s), (f32x4)(rcp_refined(bc2s))) + eps;
-    w = w - ss * div_by4(m, denom, rcp_refined4(denom));
+    w = pk_sub4(w, ss * div_by4(m, denom, rcp_refined4(denom)));
 }
 // (callers read the AdamC fields into scalars OUTSIDE their tile loops and pass those: with the struct read inside the loop the
 // stack object survives into code generation — 24..32 bytes of scratch per lane)

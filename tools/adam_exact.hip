@@ -106,12 +106,39 @@ __global__ void k_cmp(Counts* out, int cls, uint64_t n, uint32_t seed, int nstep
     atomicAdd(&out->dw, dw); atomicAdd(&out->dm, dm); atomicAdd(&out->dv, dv); atomicMax(&out->dw_ulp_max, mx); atomicAdd(&out->nan_mismatch, nn);
 }
 
+// sqrt_rn against sqrtf over every non-negative float bit pattern: [0] mismatches for x >= 2^-102 (must be 0), [1] below,
+// [2] the largest |sqrt_rn - sqrtf| below (as float bits), [3] NaN results below
+__global__ void k_sqrt_all(unsigned long long* out) {
+    unsigned long long hi = 0, lo = 0, mx = 0, nn = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= 0x7F800000ull; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __builtin_bit_cast(float, (uint32_t)i);
+        const uint32_t a = __builtin_bit_cast(uint32_t, sqrt_rn(x)), b = __builtin_bit_cast(uint32_t, sqrtf(x));
+        if (i == 0x7F800000ull) continue;                     // +inf: NaN here (rsq = 0, 0 * inf), inf in the library — a diverged state
+        if (a != b) {
+            if (i >= ((uint32_t)(127 - 102) << 23)) ++hi; else ++lo;
+            const float fa = __builtin_bit_cast(float, a), fb = __builtin_bit_cast(float, b);
+            if (fa != fa) ++nn;
+            else { const unsigned long long d = __builtin_bit_cast(uint32_t, fabsf(fa - fb)); mx = d > mx ? d : mx; }
+        }
+    }
+    atomicAdd(&out[0], hi); atomicAdd(&out[1], lo); atomicMax(&out[2], mx); atomicAdd(&out[3], nn);
+}
+
 int main(int argc, char** argv) {
     const uint64_t n = (uint64_t)(argc > 1 ? atoi(argv[1]) : 64) * 1000000ull;
     Counts* d;
     if (hipMalloc(&d, sizeof(Counts)) != hipSuccess) { fprintf(stderr, "no device\n"); return 2; }
     const char* names[7] = {"training-like", "decayed (g=0, normal-range m,v)", "deep underflow (m<2^-100, v<2^-96)", "zeros / padding", "first step (m=v=0)", "wide log-uniform", "eps=0, v=0 (inf vs NaN)"};
     int bad = 0;
+    {
+        unsigned long long* ds; unsigned long long hs[4];
+        (void)hipMalloc(&ds, 32); (void)hipMemset(ds, 0, 32);
+        k_sqrt_all<<<4096, 256>>>(ds);
+        (void)hipMemcpy(hs, ds, 32, hipMemcpyDeviceToHost);
+        const uint32_t mxb = (uint32_t)hs[2]; float mxf; memcpy(&mxf, &mxb, 4);
+        printf("sqrt_rn vs sqrtf over all 2,139,095,040 finite non-negative floats: %llu differ at x >= 2^-102; below: %llu differ, largest |difference| %.3g, %llu NaN\n", hs[0], hs[1], (double)mxf, hs[3]);
+        if (hs[0]) bad = 1;
+    }
     for (int cls = 0; cls < 7; ++cls) {
         (void)hipMemset(d, 0, sizeof(Counts));
         k_cmp<<<2048, 256>>>(d, cls, n, 0xC0FFEEu + cls, 50000);
