@@ -20,7 +20,7 @@ struct EvalArgs {
 
 #define EVAL_CE 128   // staged feature columns per pass
 
-template <int MBE, int NRBW>
+template <int MBE, int NRBW, int MSP = 0>   // MSP: 0, or the number of row blocks (1 / 2) when the m-blocks are split over the waves
 __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cand = a.cand0 + blockIdx.y;
@@ -30,15 +30,75 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
     const int l15 = lane & 15, lg = lane >> 4;
     constexpr int ME = MBE * 16;
     const int Rp = g.Rp, nrb = g.nrb, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
-    const int SX = Rp + 4, SC = Cp + 4, SS = EVAL_CE + 4;
+    // row strides = 8 mod 16 floats: the A-operand reads (row l15, columns 4 lg .. 4 lg + 3, ds_read_b128) are then conflict-free in
+    // each of the instruction's four 16-lane groups (with +4 every group had one 2-way conflict: SQ_LDS_BANK_CONFLICT = half of
+    // SQ_LDS_IDX_ACTIVE, profiles/r03_pmc_eval.log)
+    const int SX = Rp + 8, SC = Cp + 4, SS = EVAL_CE + 8;
     // LDS kept to <= 80 KiB so that two workgroups share a CU (one stages features while the other runs MFMAs):
     // ONE activation buffer (extra barrier per cell) and the logits alias the feature staging tile.
     float* xs = lds;                     // [ME][SS]   feature staging tile; later the logits [ME][SC]
     float* xo_l = xs + ME * max(SS, SC); // [ME][SX]   out_{i-1} -> out_i
     float* lg_l = xs;
     const float* W = a.plane;
+    // wave -> (row block, m-blocks).  R >= 64: wave w owns row blocks w, w+4, ... and all MBE m-blocks of the rows.  With one or
+    // two row blocks (R <= 32) that leaves 3 (2) of the 4 waves without MFMA work, so there the m-blocks are split instead:
+    // wave w owns row block w % nrb and m-blocks w / nrb, w / nrb + 4 / nrb, ...  Every output element still accumulates the same
+    // products in the same order, so the logits are bit-identical under either mapping.
+    static_assert(MSP == 0 || (NRBW == 1 && (MSP == 1 || MSP == 2)), "m-block split: one or two row blocks");
+    constexpr int NPI = MSP ? (MBE * MSP >= 4 ? MBE * MSP / 4 : 1) : MBE;        // accumulators (m-blocks) per wave and row block
+    const int rbw = MSP ? wave % MSP : wave;                       // (NRBW == 1) this wave's row block
+    const int mb0 = MSP ? wave / MSP : 0;
+    constexpr int mbs = MSP ? 4 / MSP : 1;
     const int64_t brow = a.row0 + (int64_t)blockIdx.x * ME;
     const int nvalid = (int)min((int64_t)ME, a.row0 + a.nrows - brow);
+
+    // register-staged table rows (16-bit tables, NRBW <= 2 path): e = tid + 256 u walks [ME rows][nc / 8 vectors of 8 columns]
+    // (not for the unsplit one-row-block-per-wave build, R = 48 / 64: its 128-register budget has no room for the row registers)
+    const bool t16 = a.tab.dtype != MFAS_DT_F32 && !(MSP == 0 && NRBW == 1);
+    const bool bf16 = a.tab.dtype == MFAS_DT_BF16;
+    uint4 raw[MBE];
+    bool have = false;
+    auto rows_load = [&](const void* tp, const int tw, const int c0, const int nc) {
+        const int vpr = nc >> 3;
+#pragma unroll
+        for (int u = 0; u < MBE; ++u) {
+            const int e = tid + u * 256;
+            int b, c;
+            if (vpr == 16) { b = e >> 4; c = (e & 15) << 3; }      // full chunk: no division (uniform branch)
+            else { b = e / vpr; c = (e - b * vpr) << 3; }
+            raw[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (b < nvalid) raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(tp) + (brow + b) * tw + c0 + c);
+        }
+    };
+    auto rows_store = [&](const int nc) {
+        const int vpr = nc >> 3;
+#pragma unroll
+        for (int u = 0; u < MBE; ++u) {
+            const int e = tid + u * 256;
+            int b, c;
+            if (vpr == 16) { b = e >> 4; c = (e & 15) << 3; }
+            else { b = e / vpr; c = (e - b * vpr) << 3; }
+            if (b < ME) {
+                const uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                float f[8];
+                if (bf16) {                      // (one uniform branch per 8 columns, not one per element)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        f[2 * k] = __uint_as_float(w[k] << 16);
+                        f[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000U);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        f[2 * k] = __half2float(__ushort_as_half((unsigned short)(w[k] & 0xFFFFU)));
+                        f[2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(w[k] >> 16)));
+                    }
+                }
+                *as_lds(reinterpret_cast<f32x4*>(xs + b * SS + c)) = (f32x4){f[0], f[1], f[2], f[3]};
+                *as_lds(reinterpret_cast<f32x4*>(xs + b * SS + c + 4)) = (f32x4){f[4], f[5], f[6], f[7]};
+            }
+        }
+    };
 
     for (int i = 0; i < L; ++i) {
         const float* xprev = xo_l;
@@ -54,11 +114,11 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
         // sigma(alpha) rounds to exactly 1 for alpha >~ 17: the V modality then contributes v * 0 (aux_models.py:103-111);
         // (accS * sgS / sgV + accV) * sgV would be inf * 0, so that case keeps accS * sgS and skips the V columns
         const bool vdead = g.alphas && !(sgV > 0.0f);
-        f32x4 acc[NRBW][MBE];
+        f32x4 acc[NRBW][NPI];
 #pragma unroll
         for (int j = 0; j < NRBW; ++j)
 #pragma unroll
-            for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int mb = 0; mb < NPI; ++mb) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int sv = 0; sv < 2; ++sv) {
             const int tap = cd.conf[i][sv];
             const void* tp = sv == 0 ? a.tab.s[tap] : a.tab.v[tap];
@@ -68,9 +128,14 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
 #pragma unroll
                 for (int j = 0; j < NRBW; ++j)
 #pragma unroll
-                    for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * (vdead ? sgS : sgS / sgV);
+                    for (int mb = 0; mb < NPI; ++mb) acc[j][mb] = acc[j][mb] * (vdead ? sgS : sgS / sgV);
             }
-            for (int c0 = 0; c0 < cols; c0 += EVAL_CE) {
+            have = false;
+            // (weight chunk, k-block inside it) of this eval chunk's first k-block, carried along instead of dividing per tile
+            const int nkb_c = cc >> 4;
+            int wch = 0, wkb = 0;
+            for (int c0 = 0; c0 < cols; c0 += EVAL_CE, wkb += EVAL_CE / 16) {
+                while (wkb >= nkb_c) { wkb -= nkb_c; ++wch; }
                 const int nc = min(EVAL_CE, cols - c0);
                 if constexpr (NRBW <= 2) {
                     // this chunk's weight tiles are requested BEFORE the feature staging so that their L2 latency
@@ -80,25 +145,43 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
                     for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl)
 #pragma unroll
                         for (int j = 0; j < NRBW; ++j) {
-                            const int rb = wave + 4 * j;
-                            if (kbl < (nc >> 4) && rb < nrb)
-                                wt[kbl][j] = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][sv], Rp, cc, rb, (c0 >> 4) + kbl) + lane * 4);
+                            const int rb = NRBW == 1 ? rbw : wave + 4 * j;
+                            if (kbl < (nc >> 4) && rb < nrb) {
+                                int ch = wch, t = wkb + kbl;
+                                while (t >= nkb_c) { t -= nkb_c; ++ch; }
+                                wt[kbl][j] = *reinterpret_cast<const f32x4*>(W + cd.seg_off[i][sv] + (int64_t)ch * Rp * cc + ((int64_t)rb * nkb_c + t) * 256 + lane * 4);
+                            }
                         }
-                    __syncthreads();
-                    stage_table(xs, SS, tp, a.tab.dtype, tw, c0, nc, nullptr, 0, (int)brow, nvalid, ME, tid, 256);
-                    __syncthreads();
+                    if (t16) {
+                        // 16-bit rows travel global -> registers -> LDS, and the NEXT chunk of this segment is requested before
+                        // this chunk's MFMAs (MBE x 16 bytes per thread in flight): the staging latency leaves the critical path
+                        if (!have) rows_load(tp, tw, c0, nc);
+                        __syncthreads();
+                        rows_store(nc);
+                        __syncthreads();
+                        have = c0 + EVAL_CE < cols;
+                        if (have) rows_load(tp, tw, c0 + EVAL_CE, min(EVAL_CE, cols - c0 - EVAL_CE));
+                    } else {
+                        __syncthreads();
+                        stage_table(xs, SS, tp, a.tab.dtype, tw, c0, nc, nullptr, 0, (int)brow, nvalid, ME, tid, 256);
+                        __syncthreads();
+                    }
+                    const int nkbl = nc >> 4;
 #pragma unroll
                     for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl)
-                        if (kbl < (nc >> 4)) {
+                        if (kbl < nkbl) {
 #pragma unroll
                             for (int j = 0; j < NRBW; ++j) {
-                                const int rb = wave + 4 * j;
+                                const int rb = NRBW == 1 ? rbw : wave + 4 * j;
                                 if (rb < nrb) {
 #pragma unroll
-                                    for (int mb = 0; mb < MBE; ++mb) {
-                                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+                                    for (int pi = 0; pi < NPI; ++pi) {
+                                        const int mb = mb0 + mbs * pi;
+                                        if (mb < MBE) {
+                                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
 #pragma unroll
-                                        for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], wt[kbl][j][q], acc[j][mb]);
+                                            for (int q = 0; q < 4; ++q) acc[j][pi] = MFMA16(x4[q], wt[kbl][j][q], acc[j][pi]);
+                                        }
                                     }
                                 }
                             }
@@ -111,14 +194,17 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
                         const int kb = (c0 >> 4) + kbl;
 #pragma unroll
                         for (int j = 0; j < NRBW; ++j) {
-                            const int rb = wave + 4 * j;
+                            const int rb = NRBW == 1 ? rbw : wave + 4 * j;
                             if (rb < nrb) {
                                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][sv], Rp, cc, rb, kb) + lane * 4);
 #pragma unroll
-                                for (int mb = 0; mb < MBE; ++mb) {
-                                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+                                for (int pi = 0; pi < NPI; ++pi) {
+                                    const int mb = mb0 + mbs * pi;
+                                    if (mb < MBE) {
+                                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
 #pragma unroll
-                                    for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], w4[q], acc[j][mb]);
+                                        for (int q = 0; q < 4; ++q) acc[j][pi] = MFMA16(x4[q], w4[q], acc[j][pi]);
+                                    }
                                 }
                             }
                         }
@@ -130,20 +216,23 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
 #pragma unroll
             for (int j = 0; j < NRBW; ++j)
 #pragma unroll
-                for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = acc[j][mb] * (vdead ? 1.0f : sgV);
+                for (int mb = 0; mb < NPI; ++mb) acc[j][mb] = acc[j][mb] * (vdead ? 1.0f : sgV);
         }
         if (i > 0) {
 #pragma unroll
             for (int j = 0; j < NRBW; ++j) {
-                const int rb = wave + 4 * j;
+                const int rb = NRBW == 1 ? rbw : wave + 4 * j;
                 if (rb < nrb) {
                     for (int kb = 0; kb < nrb; ++kb) {
                         const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + tile_addr(cd.seg_off[i][2], Rp, Rp, rb, kb) + lane * 4);
 #pragma unroll
-                        for (int mb = 0; mb < MBE; ++mb) {
-                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xprev + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
+                        for (int pi = 0; pi < NPI; ++pi) {
+                            const int mb = mb0 + mbs * pi;
+                            if (mb < MBE) {
+                                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xprev + (mb * 16 + l15) * SX + kb * 16 + 4 * lg);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[j][mb] = MFMA16(x4[q], w4[q], acc[j][mb]);
+                                for (int q = 0; q < 4; ++q) acc[j][pi] = MFMA16(x4[q], w4[q], acc[j][pi]);
+                            }
                         }
                     }
                 }
@@ -152,7 +241,7 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
         }
 #pragma unroll
         for (int j = 0; j < NRBW; ++j) {
-            const int rb = wave + 4 * j;
+            const int rb = NRBW == 1 ? rbw : wave + 4 * j;
             if (rb < nrb) {
                 const int r = rb * 16 + l15;
                 const float bias = W[vb + VEC_B * Rp + r];
@@ -164,15 +253,19 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
                 const float gam = g.bn ? W[vb + VEC_G * Rp + r] : 1.0f;
                 sh = g.bn ? W[vb + VEC_BE * Rp + r] : 0.0f;
 #pragma unroll
-                for (int mb = 0; mb < MBE; ++mb)
+                for (int pi = 0; pi < NPI; ++pi) {
+                    const int mb = mb0 + mbs * pi;
+                    if (mb < MBE) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int b = mb * 16 + 4 * lg + q;
-                        float o = act_fwd(acc[j][mb][q] + bias, nl);
-                        if (g.bn) o = ((o - rm) * sc) * gam + sh;
-                        if (!(r < R)) o = 0.f;
-                        xcur[b * SX + r] = o;
+                        for (int q = 0; q < 4; ++q) {
+                            const int b = mb * 16 + 4 * lg + q;
+                            float o = act_fwd(acc[j][pi][q] + bias, nl);
+                            if (g.bn) o = ((o - rm) * sc) * gam + sh;
+                            if (!(r < R)) o = 0.f;
+                            xcur[b * SX + r] = o;
+                        }
                     }
+                }
             }
         }
         __syncthreads();

@@ -523,7 +523,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     if (p->nrbw == 3) p->nrbw = 4;
     for (p->mbe = 4; p->mbe >= 1; p->mbe >>= 1) {
         const int ME = p->mbe * 16;
-        p->lds_eval = ((size_t)ME * std::max(EVAL_CE + 4, g.Cp + 4) + (size_t)ME * (g.Rp + 4)) * 4;
+        p->lds_eval = ((size_t)ME * std::max(EVAL_CE + 8, g.Cp + 4) + (size_t)ME * (g.Rp + 8)) * 4;   // strides: eval.hip.h
         if (p->lds_eval <= 80 * 1024) break;
     }
     if (p->mbe < 1 || p->nrbw > 8 || p->lds_step > 150 * 1024) {
@@ -834,17 +834,21 @@ static int check_table(const mfas_population* p, const mfas_table* t, bool need_
     return MFAS_OK;
 }
 
-template <int MBE, int NRBW>
+template <int MBE, int NRBW, int MSP = 0>
 static hipError_t launch_eval_t(mfas_population* p, const EvalArgs& a, int ncand, hipStream_t st) {
-    hipError_t e = set_lds(k_eval<MBE, NRBW>, p->lds_eval);
+    hipError_t e = set_lds(k_eval<MBE, NRBW, MSP>, p->lds_eval);
     if (e != hipSuccess) return e;
     const int ME = MBE * 16;
     const unsigned nblk = (unsigned)((a.nrows + ME - 1) / ME);
-    hipLaunchKernelGGL((k_eval<MBE, NRBW>), dim3(nblk, ncand), dim3(256), p->lds_eval, st, a);
+    hipLaunchKernelGGL((k_eval<MBE, NRBW, MSP>), dim3(nblk, ncand), dim3(256), p->lds_eval, st, a);
     return hipGetLastError();
 }
 
 static hipError_t launch_eval(mfas_population* p, const EvalArgs& a, int ncand, hipStream_t st) {
+    // one or two row blocks (R <= 32): the m-blocks of a row tile are split over the four waves (eval.hip.h)
+#define EV_SPLIT(M, S) if (p->mbe == M && p->nrbw == 1 && p->g.nrb == S && !getenv("MFAS_EVAL_NO_MSPLIT")) return launch_eval_t<M, 1, S>(p, a, ncand, st);
+    EV_SPLIT(4, 1) EV_SPLIT(4, 2) EV_SPLIT(2, 1) EV_SPLIT(2, 2) EV_SPLIT(1, 1) EV_SPLIT(1, 2)
+#undef EV_SPLIT
 #define EV_CASE(M, N) if (p->mbe == M && p->nrbw == N) return launch_eval_t<M, N>(p, a, ncand, st);
     EV_CASE(4, 1) EV_CASE(4, 2) EV_CASE(4, 4) EV_CASE(4, 8)
     EV_CASE(2, 1) EV_CASE(2, 2) EV_CASE(2, 4) EV_CASE(2, 8)

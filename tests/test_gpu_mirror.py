@@ -692,3 +692,49 @@ def test_graphed_surrogate_trainer_matches_cpu_eager(dev):
     with torch.no_grad():
         for xx in data[0]:
             torch.testing.assert_close(gpu(xx.to(dev)).cpu(), cpu(xx), rtol=0, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,bn,alphas,K,mixed,dt", [(16, False, False, 6, False, "bf16"), (16, True, False, 9, True, "f16"), (32, False, True, 7, True, "bf16"),
+                                                    (16, True, True, 5, False, "bf16"), (32, True, False, 4, True, "f32")])
+def test_small_r_eval_mapping_is_bit_identical(dev, R, bn, alphas, K, mixed, dt):
+    """R <= 32 (one or two row blocks): the dev pass splits the m-blocks of a 64-row tile over the four waves and stages 16-bit table
+    rows through registers, one chunk ahead (eval.hip.h).  Same products in the same order per logit as the plain mapping
+    (MFAS_EVAL_NO_MSPLIT=1: one wave per row block, rows staged at the barrier), so every statistic of a training call — dev
+    corrects AND dev loss — must be bit-identical.  Dev sizes with a ragged last row block, mixed depths / taps, batchnorm, alphas
+    (including a sigma(alpha) == 1 cell: the V modality is skipped), bf16 / f16 / f32 tables."""
+    import os
+    import torch
+    import mfas_amd as M
+    rng = np.random.default_rng(11)
+    N, Nd, E, B = 400, 1000 + 37, 2, 20
+    hp = M.Hyper(R=R, C=60, B=B, bn=bn, drpt=0.5, alphas=alphas, tap_bits=16 if dt != "f32" else 32)
+    confs = [np.array(CONFS["c4"])] * K
+    if mixed:
+        confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in rng.integers(1, 5, K)]
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dt]
+    ta = M.FeatureTable.from_numpy(O.synth_table(N, 3, snr=0.6), dev, tdt)
+    tb = M.FeatureTable.from_numpy(O.synth_table(Nd, 4, snr=0.6), dev, tdt)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, E * (-(-N // B)))
+    order = M.ntu_searchable.make_order(N, E, True, 5, dev)
+
+    def run(plain):
+        if plain:
+            os.environ["MFAS_EVAL_NO_MSPLIT"] = "1"
+        try:
+            pop = M.Population(hp, confs, dev, drop_seeds=list(range(40, 40 + K)))
+            pop.init(list(range(1, K + 1)))
+            if alphas:      # one cell with sigma(alpha) == 1 exactly
+                flat = pop.get_params(0, 0)
+                flat[0] = 30.0
+                pop.set_params(0, flat)
+            stats, status = pop.train(ta, tb, E, etas, order=order)
+            pop.close()
+        finally:
+            os.environ.pop("MFAS_EVAL_NO_MSPLIT", None)
+        assert not status.any()
+        return stats
+
+    s_new, s_old = run(False), run(True)
+    assert s_new.tobytes() == s_old.tobytes()
+    assert (s_old["dev_corrects"] > 0).any()
