@@ -20,7 +20,10 @@ struct EvalArgs {
 
 #define EVAL_CE 128   // staged feature columns per pass
 
-template <int MBE, int NRBW, int MSP = 0>   // MSP: 0, or the number of row blocks (1 / 2) when the m-blocks are split over the waves
+// MSP: 0, or the number of row blocks (1 / 2) when the m-blocks are split over the waves.  XB (with MSP): bf16 table rows stay 16-bit
+// in the LDS tile (half the store instructions, no store conflicts: 8 consecutive lanes write 128 contiguous bytes) and are widened by
+// the wave that reads them (each element is read by exactly one wave under the split)
+template <int MBE, int NRBW, int MSP = 0, bool XB = false>
 __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cand = a.cand0 + blockIdx.y;
@@ -37,7 +40,7 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
     // LDS kept to <= 80 KiB so that two workgroups share a CU (one stages features while the other runs MFMAs):
     // ONE activation buffer (extra barrier per cell) and the logits alias the feature staging tile.
     float* xs = lds;                     // [ME][SS]   feature staging tile; later the logits [ME][SC]
-    float* xo_l = xs + ME * max(SS, SC); // [ME][SX]   out_{i-1} -> out_i
+    float* xo_l = xs + ME * (XB ? max((EVAL_CE + 8) / 2, SC) : max(SS, SC)); // [ME][SX]   out_{i-1} -> out_i (XB: the row tile is half as wide)
     float* lg_l = xs;
     const float* W = a.plane;
     // wave -> (row block, m-blocks).  R >= 64: wave w owns row blocks w, w+4, ... and all MBE m-blocks of the rows.  With one or
@@ -45,6 +48,9 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
     // wave w owns row block w % nrb and m-blocks w / nrb, w / nrb + 4 / nrb, ...  Every output element still accumulates the same
     // products in the same order, so the logits are bit-identical under either mapping.
     static_assert(MSP == 0 || (NRBW == 1 && (MSP == 1 || MSP == 2)), "m-block split: one or two row blocks");
+    static_assert(!XB || MSP > 0, "16-bit LDS rows: with the m-block split only");
+    constexpr int SSH = EVAL_CE + 8;       // row stride of the 16-bit tile in elements: ds_read_b64 of (row l15, columns 4 lg ..) conflict-free
+    uint16_t* xh = reinterpret_cast<uint16_t*>(lds);
     constexpr int NPI = MSP ? (MBE * MSP >= 4 ? MBE * MSP / 4 : 1) : MBE;        // accumulators (m-blocks) per wave and row block
     const int rbw = MSP ? wave % MSP : wave;                       // (NRBW == 1) this wave's row block
     const int mb0 = MSP ? wave / MSP : 0;
@@ -79,6 +85,10 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
             if (vpr == 16) { b = e >> 4; c = (e & 15) << 3; }
             else { b = e / vpr; c = (e - b * vpr) << 3; }
             if (b < ME) {
+                if constexpr (XB) {
+                    *as_lds(reinterpret_cast<u32x4*>(xh + b * SSH + c)) = (u32x4){raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                    continue;
+                }
                 const uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
                 float f[8];
                 if (bf16) {                      // (one uniform branch per 8 columns, not one per element)
@@ -178,7 +188,15 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
                                     for (int pi = 0; pi < NPI; ++pi) {
                                         const int mb = mb0 + mbs * pi;
                                         if (mb < MBE) {
-                                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+                                            f32x4 x4;
+                                            if constexpr (XB) {
+                                                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                                                const u32x2 r = *as_lds(reinterpret_cast<const u32x2*>(xh + (mb * 16 + l15) * SSH + kbl * 16 + 4 * lg));
+                                                x4 = (f32x4){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xFFFF0000U),
+                                                             __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xFFFF0000U)};
+                                            } else {
+                                                x4 = *reinterpret_cast<const f32x4*>(xs + (mb * 16 + l15) * SS + kbl * 16 + 4 * lg);
+                                            }
 #pragma unroll
                                             for (int q = 0; q < 4; ++q) acc[j][pi] = MFMA16(x4[q], wt[kbl][j][q], acc[j][pi]);
                                         }

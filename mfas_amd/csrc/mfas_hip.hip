@@ -834,19 +834,24 @@ static int check_table(const mfas_population* p, const mfas_table* t, bool need_
     return MFAS_OK;
 }
 
-template <int MBE, int NRBW, int MSP = 0>
+template <int MBE, int NRBW, int MSP = 0, bool XB = false>
 static hipError_t launch_eval_t(mfas_population* p, const EvalArgs& a, int ncand, hipStream_t st) {
-    hipError_t e = set_lds(k_eval<MBE, NRBW, MSP>, p->lds_eval);
-    if (e != hipSuccess) return e;
     const int ME = MBE * 16;
+    // (16-bit row tile: half the width, more workgroups per CU)
+    const size_t lds = XB ? ((size_t)ME * std::max((EVAL_CE + 8) / 2, p->g.Cp + 4) + (size_t)ME * (p->g.Rp + 8)) * 4 : p->lds_eval;
+    hipError_t e = set_lds(k_eval<MBE, NRBW, MSP, XB>, lds);
+    if (e != hipSuccess) return e;
     const unsigned nblk = (unsigned)((a.nrows + ME - 1) / ME);
-    hipLaunchKernelGGL((k_eval<MBE, NRBW, MSP>), dim3(nblk, ncand), dim3(256), p->lds_eval, st, a);
+    hipLaunchKernelGGL((k_eval<MBE, NRBW, MSP, XB>), dim3(nblk, ncand), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
 static hipError_t launch_eval(mfas_population* p, const EvalArgs& a, int ncand, hipStream_t st) {
     // one or two row blocks (R <= 32): the m-blocks of a row tile are split over the four waves (eval.hip.h)
-#define EV_SPLIT(M, S) if (p->mbe == M && p->nrbw == 1 && p->g.nrb == S && !getenv("MFAS_EVAL_NO_MSPLIT")) return launch_eval_t<M, 1, S>(p, a, ncand, st);
+    // (bf16 tables: the rows stay 16-bit in LDS)
+    const bool xb = a.tab.dtype == MFAS_DT_BF16 && !getenv("MFAS_EVAL_NO_X16");
+#define EV_SPLIT(M, S) if (p->mbe == M && p->nrbw == 1 && p->g.nrb == S && !getenv("MFAS_EVAL_NO_MSPLIT")) \
+        return xb ? launch_eval_t<M, 1, S, true>(p, a, ncand, st) : launch_eval_t<M, 1, S, false>(p, a, ncand, st);
     EV_SPLIT(4, 1) EV_SPLIT(4, 2) EV_SPLIT(2, 1) EV_SPLIT(2, 2) EV_SPLIT(1, 1) EV_SPLIT(1, 2)
 #undef EV_SPLIT
 #define EV_CASE(M, N) if (p->mbe == M && p->nrbw == N) return launch_eval_t<M, N>(p, a, ncand, st);
