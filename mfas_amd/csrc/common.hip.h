@@ -152,7 +152,9 @@ __device__ __forceinline__ float act_bwd(float a, float da, int nl) {
 // — bit for bit what sqrtf() and operator/ give — whenever no intermediate leaves the normal range: v >= 2^-102 (below that
 // the residual x - g*g is not exact; sqrt(v) < 4.5e-16 is then far inside the rounding of + eps) and |m| >= 2^-100 (below that
 // the quotient's residual underflows; the step it would contribute is < 1e-22 * lr).  sqrt(0) = 0; 0/0 -> NaN as in the library
-// form; m/0 (adam_eps = 0 with v = 0, not reachable from training) gives NaN where the library form gives +-inf.
+// form; m/0 (adam_eps = 0 with v = 0, not reachable from training) gives NaN where the library form gives +-inf, and so does an
+// OVERFLOWED second moment (v = +inf, |g| > 1.8e19: rsq = 0, 0 * inf) where the library form's m / inf = 0 freezes the element —
+// either way the candidate has diverged, here its weights say so.
 // tools/adam_exact.hip compares both forms bit by bit on the GPU — sqrt over every non-negative float, the whole update on
 // 7 x 64M sampled states (profiles/r03_adam_exact.log).
 __device__ __forceinline__ f32x4 vfma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
