@@ -324,7 +324,9 @@ def main():
                     mfma_src = f"profiles/{tag}_pmc_mfma.json (separate rocprofv3 --pmc pass; not measured in this run)"
                 except Exception:
                     mfma = None
-        stream = None       # live ceiling of THIS box for the sweep's access pattern (no compute), same units as `achieved`
+        # live rate of THIS box for a compute-free 3-plane read-modify-write probe (k_stream_probe), same units as `achieved`: a
+        # reference point for box-to-box comparisons, NOT a ceiling — since the packed Adam the sweep itself is faster than the probe
+        stream = None
         if world == 1:
             import ctypes
             from mfas_amd import _lib
@@ -354,7 +356,7 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": n_launch, "avg_launch_us": (ms / n_launch * 1e3) if n_launch else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "stream_ceiling": stream, "frac_of_stream": (achieved / stream) if (achieved and stream) else None,
+                         "stream_probe": stream, "frac_of_stream_probe": (achieved / stream) if (achieved and stream) else None,
                          "mfma_util_pct_from_profile": mfma, "mfma_util_source": mfma_src},
         }
         if world == 1 and not a.no_cpu_baseline:
