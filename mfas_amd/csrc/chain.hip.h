@@ -1345,9 +1345,7 @@ __device__ __forceinline__ void lean_res_update(const ChainArgs& a, const ChainS
         float* oV = oM + LEAN_OWN_TILES * 256;
         f32x4 w4 = *reinterpret_cast<const f32x4*>(oW), m4 = *reinterpret_cast<const f32x4*>(oM), v4 = *reinterpret_cast<const f32x4*>(oV);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < MB * 4; ++j)
-            acc = MFMA16(x[(4 * j + lg) * sx + l15], dy[(4 * j + lg) * sd + dcol + l15], acc);
+        DW_BATCH_LOOP(MB, (g.B + 3) >> 2, acc = MFMA16(x[(4 * j + lg) * sx + l15], dy[(4 * j + lg) * sd + dcol + l15], acc))
         const float gsc = 1.0f;
         adam4(w4, m4, v4, acc * gsc, cs.ss, cs.bc2s, a.ac.w1, a.ac.b2, a.ac.w2, a.ac.eps, a.ac.wd);
         *reinterpret_cast<f32x4*>(oW) = w4;

@@ -142,6 +142,18 @@ __device__ __forceinline__ float act_bwd(float a, float da, int nl) {
     return a > 0.0f ? da : 0.01f * da;   // leaky: sign(a) == sign(y)
 }
 
+// dW = x_t^T dy runs over the batch in blocks of 4 rows (one 16x16x4 MFMA each).  The batch is padded to MB * 16 rows; with the
+// search default B = 20 (MB = 2) the blocks 5..7 hold only zeros and are skipped, B <= 48 (MB = 4) skips 12..15: ONE uniform branch
+// per tile between two straight-line forms (a predicate per block cost registers: scratch in k_step_same / k_president).  Every dW
+// path uses this helper, so all schedules keep summing the same products in the same order.
+template <int MB> __device__ __forceinline__ constexpr int dw_short_blocks() { return MB == 2 ? 5 : (MB == 4 ? 12 : MB * 4); }
+#define DW_BATCH_LOOP(MB, nj, BODY)                                                    \
+    if (MB > 1 && (nj) <= dw_short_blocks<MB>()) {                                      \
+        _Pragma("unroll") for (int j = 0; j < dw_short_blocks<MB>(); ++j) { BODY; }     \
+    } else {                                                                            \
+        _Pragma("unroll") for (int j = 0; j < MB * 4; ++j) { BODY; }                    \
+    }
+
 // ---- Adam(+L2) on weights held in registers (torch.optim.Adam, foreach=False form; oracle/np_oracle.py adam_step) --------
 //     g += wd*w;  m += (1-b1)*(g-m);  v = v*b2 + ((1-b2)*g)*g;  denom = sqrt(v)/sqrt(bc2) + eps;  w -= (lr/bc1) * (m/denom)
 // The square root and the two divisions are written out as correctly-rounding fma sequences — sqrt: v_rsq_f32 seed, one coupled

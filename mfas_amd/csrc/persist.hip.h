@@ -175,6 +175,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
             v4[u][s] = *reinterpret_cast<const f32x4*>(U[u].Vp + off);
         }
     }
+    const int nj = (sa.g.B + 3) >> 2;      // batch blocks of 4 rows that hold data (tile_run)
     const float a_w1 = sa.ac.w1, a_b2 = sa.ac.b2, a_w2 = sa.ac.w2, a_eps = sa.ac.eps, a_wd = sa.ac.wd;   // scalars, not a struct copy (common.hip.h adam4)
 
     // MFMA operand reads from a staged batch: one element (dW: A[i = column][k = batch row]) / four consecutive columns
@@ -308,9 +309,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     const int kb = wave + STEP_NW * s;
                     if (kb < un.nkb) {
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int j = 0; j < MB * 4; ++j)
-                            acc = MFMA16(x1(xt, un.S, 4 * j + lg, kb * 16 + l15), dyf[j], acc);
+                        DW_BATCH_LOOP(MB, nj, acc = MFMA16(x1(xt, un.S, 4 * j + lg, kb * 16 + l15), dyf[j], acc))
                         { f32x4 w = w4[u][s], m = m4[u][s], v = v4[u][s];
                           adam4(w, m, v, acc * gsc, a_ss, a_bc2s, a_w1, a_b2, a_w2, a_eps, a_wd);
                           w4[u][s] = w; m4[u][s] = m; v4[u][s] = v; }

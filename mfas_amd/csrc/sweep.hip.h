@@ -12,7 +12,8 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
                                          const int kbs, const float* xt, const int ST, const float* xn, const int SN,
                                          const float (&dyf)[MB * 4], const float gsc, const AdamC& ac, const bool upd,
                                          const bool fwd, f32x4 (&yacc)[MB], float* T, const int tstride_rb,
-                                         const int lane) {
+                                         const int lane, const int nj) {
+    // nj = ceil(B / 4): batch blocks that hold data (DW_BATCH_LOOP, common.hip.h)
     const int l15 = lane & 15, lg = lane >> 4;
     const float a_ss = ac.ss, a_bc2s = ac.bc2s, a_w1 = ac.w1, a_b2 = ac.b2, a_w2 = ac.w2, a_eps = ac.eps, a_wd = ac.wd;
     for (int kbb = kb0; kbb < nkb; kbb += SWEEP_U * kbs) {
@@ -40,9 +41,10 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
                 const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
                 if (upd) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < MB * 4; ++j)
-                        acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc);
+                    // (COH = the same-group fused launch: its 128-register budget has no room for two loop bodies, so it keeps the
+                    // padded blocks — they add +0, which can only turn an accumulator of -0 into +0, and Adam's m, v and w come out
+                    // the same for g = -0 and g = +0: tests/test_gpu_parity.py::test_same_group_launch_fuzz_bit_identical)
+                    DW_BATCH_LOOP(MB, (COH ? MB * 4 : nj), acc = MFMA16(xt[(4 * j + lg) * ST + kb * 16 + l15], dyf[j], acc))
                     { f32x4 w = w4[u], m = m4[u], v = v4[u];
                       adam4(w, m, v, acc * gsc, a_ss, a_bc2s, a_w1, a_b2, a_w2, a_eps, a_wd);
                       w4[u] = w; m4[u] = m; v4[u] = v; }
@@ -216,7 +218,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         tile_run<MB, NT, U, COH>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
-                                 d.wt_off >= 0 ? a.wt + d.wt_off + ((int64_t)(d.k0 >> 4) * d.seg_nrb + d.rb0) * 256 : nullptr, d.seg_nrb, lane);
+                                 d.wt_off >= 0 ? a.wt + d.wt_off + ((int64_t)(d.k0 >> 4) * d.seg_nrb + d.rb0) * 256 : nullptr, d.seg_nrb, lane, (a.g.B + 3) >> 2);
         if (fwd) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -333,7 +335,7 @@ __device__ __forceinline__ void sweep_tap_body(const SweepArgs& a, const int bid
     f32x4 yacc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tile_run<MB, NT, U>(Wp, Mp, Vp, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc, nullptr, nrb, lane);
+    tile_run<MB, NT, U>(Wp, Mp, Vp, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc, nullptr, nrb, lane, (a.g.B + 3) >> 2);
     if (fwd) {
         float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[cell] + d.part_idx[item]) * nrb * MB) << 8);
 #pragma unroll
