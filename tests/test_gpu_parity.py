@@ -1071,3 +1071,27 @@ def test_degenerate_shapes(dev):
     stats, status = pop.train(table(ttr, dev), None, 1, etas_for(ohp, 10), max_steps=0)
     assert torch.equal(before, pop.get_params(0)) and stats["train_loss_sum"].sum() == 0 and stats["train_corrects"].sum() == 0
     pop.close()
+
+
+@pytest.mark.gpu
+def test_written_out_adam_arithmetic_equals_the_library_forms(dev, tmp_path):
+    """common.hip.h writes Adam's sqrt and divisions out as packed fma sequences on the hardware rsq / rcp seeds.  tools/adam_exact.hip
+    runs them next to sqrtf() / operator/ on the GPU: the square root over EVERY finite non-negative float (no difference allowed for
+    x >= 2^-102), the whole update on 7 classes of 8 M sampled optimizer states (training-like, decayed, deep underflow, zeros, first
+    step, wide log-uniform: no differing bit of w, m or v; packed == scalar)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    exe = str(tmp_path / "adam_exact")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "include"),
+                    "-I" + os.path.join(root, "mfas_amd", "csrc"), os.path.join(root, "tools", "adam_exact.hip"), "-o", exe],
+                   check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe, "8"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "IDENTICAL" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
+    first = out.stdout.splitlines()[0]
+    assert " 0 differ at x >= 2^-102" in first, first
