@@ -14,12 +14,19 @@ Strong scaling of a SMALL population — what the search actually issues (models
   --workload c2   BASELINE configs[2]: 16 sampled L=4 confs (np.random.seed(0)), search-script defaults R=16, B=20, no BN,
                   drpt 0.5, E=10, total population 16 (strong scaling)
   --workload c3   one call of BASELINE configs[3]: 50 sampled confs, same defaults, total population 50 (strong scaling)
+  --workload c5   BASELINE configs[4] (the fifth): MM-IMDB-shaped fusion search — text taps 64 / 128, image taps 4 x 512, 23 genres,
+                  weighted BCE + F1-samples, fp16 taps, R=16, B=20, N = 15,552 / 2,608 (the MM-IMDB split sizes), --pop sampled
+                  L=4 confs per GPU (weak scaling; default 512: the "memory-bound cell-kernel stress")
 
-With N > 1 and no workload flags the line ALSO carries the strong-scaling workloads next to the weak one, measured after the
-timed region with the same process group: ``config.strong = {"c2": {...}, "c3": {...}}`` (candidates/s of one
-train_sampled_models call on 16 / 50 sampled confs, per-rank seconds, per-rank shares, ranks the sharder used).
+The default line (workload c1, no workload flags) ALSO carries the search-sized workloads, measured after the timed region:
+  N = 1: ``config.small_pop = {"c2": {...}, "c3": {...}, "c1_single": {...}}`` — one call of 16 / 50 sampled L=4 confs at the search
+         script's defaults (candidates/s, us per train step, schedule, nominal fraction of the HBM bound) and ONE conf-4 R=128
+         candidate (train steps/s: SURVEY.md 8d C2);
+  N > 1: ``config.strong = {"c2": {...}, "c3": {...}}`` — the same two calls sharded over the ranks by the engine's own policy
+         (per-rank seconds, per-rank shares, ranks the sharder used, the calibrated step-time model).
 
-Launch: ``python bench.py --gpus 1`` or
+Launch: ``python bench.py --gpus N`` (N > 1 and no WORLD_SIZE in the environment: bench.py starts its own N ranks under
+torch.distributed.run on 127.0.0.1 and exits non-zero if any of them fails) or
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
 bench.py --gpus N --steps K --warmup W``.
 """
@@ -163,18 +170,67 @@ def cpu_baseline(train, dev, args, budget_s=24.0):
     return out
 
 
+def synth_mm_tables(n_train, n_dev, device, C=23):
+    """MM-IMDB-shaped synthetic multi-label tables (BASELINE configs[4]): text taps 64 / 128 (MaxOut_MLP o1 / o3,
+    models/central/mm_imdb.py:176-196), image taps 4 x 512 (GP_VGG, :19-59), 23 genres, fp16 taps, multi-hot targets."""
+    import mfas_amd as M
+    from mfas_amd import mmimdb_searchable as MM
+    g = torch.Generator(device=device)
+    g.manual_seed(321)
+    mus = {f"s{j}": torch.randn(C, w, generator=g, device=device) for j, w in enumerate(MM.MM_TEXT_SIZES)}
+    mus.update({f"v{j}": torch.randn(C, w, generator=g, device=device) for j, w in enumerate(MM.MM_IMAGE_SIZES)})
+    out = []
+    for n, seed in ((n_train, 1), (n_dev, 2)):
+        g.manual_seed(seed)
+        z = (torch.rand(n, C, generator=g, device=device) < 0.15).float()
+        taps = {k: torch.relu(0.6 * z @ mu + torch.randn(n, mu.shape[1], generator=g, device=device)).to(torch.float16)
+                for k, mu in mus.items()}
+        out.append(M.FeatureTable(taps, torch.zeros(n, dtype=torch.int32, device=device), multilabel=z))
+    return out
+
+
+def alg_bytes_per_candidate(conf, R, C, bn, s_sizes, v_sizes, B, E, n_train, n_dev, elt):
+    """E * [ceil(N_tr/B) * 24 P + (N_tr + N_dev) * (sum F * s_f + 8) + 4 P] — the HBM-roofline bytes of ONE candidate."""
+    conf = np.asarray(conf).reshape(-1, 3)
+    P, F = 0, 0
+    for i, (s, v, _) in enumerate(conf):
+        f = s_sizes[int(s)] + v_sizes[int(v)]
+        F += f
+        P += R * (f + (R if i else 0)) + R + (2 * R if bn else 0)
+    P += R * C + C
+    nb = -(-n_train // B)
+    return E * (nb * 24.0 * P + (n_train + n_dev) * (F * elt + 8.0) + 4.0 * P)
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks ourselves (one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 at a free port).  Rank 0's JSON line is the only thing on stdout; the exit code
+    is torchrun's (non-zero when any rank fails)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pop", type=int, default=128, help="candidates per GPU per step")
+    ap.add_argument("--pop", type=int, default=0, help="candidates per GPU per step (default: 128; 512 for --workload c5)")
     ap.add_argument("--R", type=int, default=128)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--drpt", type=float, default=0.5)
-    ap.add_argument("--n-train", type=int, default=10000)
-    ap.add_argument("--n-dev", type=int, default=5600)
+    ap.add_argument("--n-train", type=int, default=0, help="default 10,000 (c5: 15,552)")
+    ap.add_argument("--n-dev", type=int, default=0, help="default 5,600 (c5: 2,608)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
     ap.add_argument("--chunk-cols", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,19 +239,42 @@ def main():
     ap.add_argument("--no-bn", action="store_true", help="search-script defaults: no BatchNorm")
     ap.add_argument("--mixed-confs", action="store_true", help="population of sampled L=1..4 confs instead of conf 4")
     ap.add_argument("--total-pop", type=int, default=0, help="strong scaling: this many candidates IN TOTAL, sharded over the ranks")
-    ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c3"], help="named BASELINE workloads (see the module docstring)")
+    ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c3", "c5"], help="named BASELINE workloads (see the module docstring)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling workloads (config.strong) reported next to the weak headline")
+    ap.add_argument("--no-small-pop", action="store_true", help="N = 1: skip the search-sized workloads (config.small_pop) reported next to the headline")
     ap.add_argument("--snr", type=float, default=0.12, help="planted-signal strength of the synthetic taps (BASELINE.md section 2: 0.12)")
+    ap.add_argument("--engine-init", default="torch", choices=["torch", "device"],
+                    help="candidate initialisation: torch = train_sampled_models' default (the module's own draws from torch's CPU generator, "
+                         "uploaded); device = the engine's hash generator on the GPU")
+    ap.add_argument("--engine-order", default="shared", choices=["shared", "per_candidate"],
+                    help="sample order: one shuffle per epoch shared by the call's candidates, or the reference's per-candidate shuffles")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(a.gpus))
     if a.workload in ("c2", "c3"):      # search-script defaults (main_searchable_ntu.py:26-47)
         a.R, a.batch, a.no_bn = 16, 20, True
         a.total_pop = a.total_pop or (16 if a.workload == "c2" else 50)
+    if a.workload == "c5":
+        a.R, a.batch, a.no_bn, a.dtype = 16, 20, True, "f16"
+        a.n_train, a.n_dev = a.n_train or 15552, a.n_dev or 2608
+        a.pop = a.pop or 512
+    a.pop = a.pop or 128
+    a.n_train, a.n_dev = a.n_train or 10000, a.n_dev or 5600
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    local = local % max(torch.cuda.device_count(), 1)
+    if world != a.gpus:     # the launcher's world is what runs; say so instead of dying on the first line
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
+        a.gpus = world
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device (torch.cuda.device_count() == 0)")
+    if world > ndev and a.backend == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, {ndev} visible (one process per GPU); "
+                         "--backend gloo shares GPUs between ranks (tests only)")
+    local = local % ndev
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
@@ -207,46 +286,48 @@ def main():
 
     import mfas_amd as M
     from mfas_amd import ntu_searchable as NS
+    from mfas_amd import mmimdb_searchable as MM
+    from mfas_amd import population as popmod
 
     dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
-    train, dev = synth_tables(a.n_train, a.n_dev, device, dtype, snr=a.snr)
+    elt = 4 if a.dtype == "f32" else 2
+    mm = a.workload == "c5"
+    if mm:
+        train, dev = synth_mm_tables(a.n_train, a.n_dev, device)
+        s_sizes, v_sizes, C = MM.MM_TEXT_SIZES, MM.MM_IMAGE_SIZES, MM.MM_NUM_OUTPUTS
+        train_fn, stype = MM.train_sampled_models, MM.Searchable_Text_Image_Net
+    else:
+        train, dev = synth_tables(a.n_train, a.n_dev, device, dtype, snr=a.snr)
+        s_sizes, v_sizes, C = M.engine.S_SIZES, M.engine.V_SIZES, 60
+        train_fn, stype = M.train_sampled_models, M.Searchable_Skeleton_Image_Net
     loaders = {"train": M.FeatureLoader(train, a.batch, shuffle=True), "dev": M.FeatureLoader(dev, a.batch, shuffle=False)}
-    args = SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=a.drpt, inner_representation_size=a.R,
+    args = SimpleNamespace(vid_len=(8, 32), num_outputs=C, drpt=a.drpt, inner_representation_size=a.R,
                            batchnorm=not a.no_bn, alphas=False, multitask=False, weightsharing=False, batchsize=a.batch,
                            eta_max=1e-3, eta_min=1e-6, Ti=1, Tm=2, use_dataparallel=False, verbose=False,
-                           epochs=a.epochs, engine_init="device", engine_profile=not a.no_profile,
-                           engine_chunk_cols=a.chunk_cols)
+                           epochs=a.epochs, engine_init=a.engine_init, engine_profile=not a.no_profile,
+                           engine_chunk_cols=a.chunk_cols, engine_order=a.engine_order)
     total = a.total_pop if a.total_pop > 0 else a.pop * world
     confs = [np.array(CONF4) for _ in range(total)]
     if a.mixed_confs:
         rng = np.random.default_rng(0)
         confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1)
                  for L in rng.integers(1, 5, total)]
-    def sampled_l4(n):      # L=4 configurations sampled like the controller does at progression level 3
+
+    def sampled_l4(n, layer=None):      # L=4 configurations sampled like the controller does at progression level 3
         np.random.seed(0)
-        layer = NS.get_possible_layer_configurations(0)
+        layer = layer or NS.get_possible_layer_configurations(0)
         return [np.array([layer[i] for i in np.random.choice(len(layer), 4)]) for _ in range(n)]
 
     if a.workload in ("c2", "c3"):
         confs = sampled_l4(total)
+    if mm:
+        confs = sampled_l4(total, MM.get_possible_layer_configurations(0))
     torch.manual_seed(0)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    accs = None
-    for _ in range(a.warmup):
-        accs = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, loaders, args, device)
-    NS.PROFILE.clear()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        accs = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, loaders, args, device)
-    barrier()
-    dt = time.perf_counter() - t0
-    rank_dt = None
 
     def rank_times(dt_local):
         if world == 1:
@@ -256,45 +337,101 @@ def main():
         dist.all_gather(allt, t)
         return [float(x.item()) for x in allt]
 
-    rank_dt = rank_times(dt)      # per-rank seconds around the same K timed steps
-    dt = max(rank_dt)
-
-    # Strong scaling next to the weak headline (N > 1 only, outside the timed region): BASELINE configs[2] / [3] are ONE
-    # train_sampled_models call on 16 / 50 sampled L=4 confs at the search script's defaults (models/searchable.py:90,120),
-    # sharded over the ranks by the engine's own policy (mfas_amd/population.py: a call uses only as many ranks as its
-    # step-time model says pay — a latency-bound step costs the same for 1..8 resident candidates).
-    strong = None
-    if world > 1 and a.workload == "c1" and a.total_pop == 0 and not a.mixed_confs and not a.no_strong:
-        from mfas_amd import population as popmod
-        strong = {}
-        sargs = SimpleNamespace(**vars(args))
-        sargs.inner_representation_size, sargs.batchsize, sargs.batchnorm, sargs.engine_profile = 16, 20, False, False
-        sloaders = {"train": M.FeatureLoader(train, 20, shuffle=True), "dev": M.FeatureLoader(dev, 20, shuffle=False)}
-        for name, K in (("c2", 16), ("c3", 50)):
-            sconfs = sampled_l4(K)
-            costs = [popmod.candidate_cost(c, 16, M.engine.S_SIZES, M.engine.V_SIZES, 60) for c in sconfs]
-            owner, _ = popmod.shard(costs, world, 16)
-            reps = 3
-            M.train_sampled_models(sconfs, M.Searchable_Skeleton_Image_Net, sloaders, sargs, device)
-            barrier()
-            ts = time.perf_counter()
-            for _ in range(reps):
-                saccs = M.train_sampled_models(sconfs, M.Searchable_Skeleton_Image_Net, sloaders, sargs, device)
-            barrier()
-            rt = rank_times(time.perf_counter() - ts)
-            strong[name] = {"workload": f"BASELINE configs[{2 if name == 'c2' else 3}]: one call of {K} sampled L=4 confs, R=16, no batchnorm, "
-                                        f"drpt {a.drpt}, B=20, E={a.epochs}, N_train={a.n_train}, N_dev={a.n_dev}",
-                            "scaling": "strong", "candidates": K, "calls_timed": reps, "cand_per_s": K * reps / max(rt),
-                            "ms_per_call": max(rt) / reps * 1e3, "rank_seconds": rt,
-                            "share": [owner.count(r) for r in range(world)], "ranks_used": len(set(owner)),
-                            "mean_best_dev_acc": float(np.mean(saccs))}
-
-    if rank == 0:
+    def profile_summary():
+        """(launches, ms, algorithmic bytes per launch, schedule of the last population) over the calls since PROFILE.clear()"""
         n_launch = sum(p[0] for p in NS.PROFILE)
         ms = sum(p[1] for p in NS.PROFILE)
-        bytes_per_launch = NS.PROFILE[-1][2] if NS.PROFILE else 0.0
+        by = sum(p[0] * p[2] for p in NS.PROFILE) / n_launch if n_launch else 0.0
+        return n_launch, ms, by, (NS.PROFILE[-1][3] if NS.PROFILE else {})
+
+    accs = None
+    for _ in range(a.warmup):
+        accs = train_fn(confs, stype, loaders, args, device)
+    NS.PROFILE.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        accs = train_fn(confs, stype, loaders, args, device)
+    barrier()
+    dt = time.perf_counter() - t0
+    rank_dt = rank_times(dt)      # per-rank seconds around the same K timed steps
+    dt = max(rank_dt)
+    n_launch, ms, bytes_per_launch, sched = profile_summary()
+
+    def timed_calls(fn, reps):
+        fn()                      # warm-up (layout decisions, first-touch of the population's pages, calibration of the sharder)
+        NS.PROFILE.clear()
+        barrier()
+        ts = time.perf_counter()
+        out = None
+        for _ in range(reps):
+            out = fn()
+        barrier()
+        return out, rank_times(time.perf_counter() - ts)
+
+    def search_sized(name, K, reps=3):
+        """ONE train_sampled_models call on K sampled L=4 confs at the search script's defaults (models/searchable.py:90,120;
+        main_searchable_ntu.py:26-47: R=16, B=20, no batchnorm, drpt 0.5) — BASELINE configs[2] (K=16) / configs[3] (K=50)."""
+        sargs = SimpleNamespace(**vars(args))
+        sargs.inner_representation_size, sargs.batchsize, sargs.batchnorm, sargs.engine_profile = 16, 20, False, not a.no_profile
+        sloaders = {"train": M.FeatureLoader(train, 20, shuffle=True), "dev": M.FeatureLoader(dev, 20, shuffle=False)}
+        sconfs = sampled_l4(K)
+        saccs, rt = timed_calls(lambda: M.train_sampled_models(sconfs, stype, sloaders, sargs, device), reps)
+        nl, pms, pby, psched = profile_summary()
+        nb = -(-a.n_train // 20)
+        gb = float(np.mean([alg_bytes_per_candidate(c, 16, 60, False, s_sizes, v_sizes, 20, a.epochs, a.n_train, a.n_dev, elt) for c in sconfs]))
+        cps = K * reps / max(rt)
+        ent = {"workload": f"BASELINE configs[{2 if K == 16 else 3}]: one call of {K} sampled L=4 confs, R=16, no batchnorm, "
+                           f"drpt {a.drpt}, B=20, E={a.epochs}, N_train={a.n_train}, N_dev={a.n_dev}",
+               "scaling": "strong", "candidates": K, "calls_timed": reps, "cand_per_s": cps, "ms_per_call": max(rt) / reps * 1e3,
+               "rank_seconds": rt, "mean_best_dev_acc": float(np.mean(saccs)),
+               "hbm_bound_cand_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / gb, "frac_of_hbm_bound": cps * gb / (HBM_PEAK_GBS * 1e9 * world)}
+        if world == 1:
+            ent.update({"us_per_train_step_incl_dev_eval": max(rt) / reps / (a.epochs * nb) * 1e6, "schedule": psched,
+                        "populations_per_call": len(NS.PROFILE) // max(reps, 1),
+                        "kernel_us_per_train_step": (pms * 1e3 / (reps * a.epochs * nb)) if (nl and psched.get("persistent")) else None})
+        else:
+            owner, _, model = popmod.shard_call(sconfs, M.Hyper.from_args(sargs), world, device, False)
+            ent.update({"share": [owner.count(r) for r in range(world)], "ranks_used": len(set(owner)),
+                        "step_time_model": model.describe() if model is not None else None})
+        return ent
+
+    small = strong = None
+    plain = a.workload == "c1" and a.total_pop == 0 and not a.mixed_confs
+    if plain and world > 1 and not a.no_strong:
+        # Strong scaling next to the weak headline (outside the timed region): the search's own call sizes, sharded by the engine's
+        # policy (mfas_amd/population.py: a call uses only as many ranks as its calibrated step-time model says pay)
+        strong = {"c2": search_sized("c2", 16), "c3": search_sized("c3", 50)}
+    if plain and world == 1 and not a.no_small_pop and a.R == 128 and not a.no_bn:
+        small = {"c2": search_sized("c2", 16), "c3": search_sized("c3", 50)}
+        # SURVEY.md 8(d) C2: steps/s of the single found architecture — ONE conf-4 candidate (R=128, batchnorm, B=16), and the
+        # share an 8-GPU search call leaves a rank at this R (6 candidates)
+        for name, K in (("c1_single", 1), ("c1_pop6", 6)):
+            kargs = SimpleNamespace(**vars(args))
+            kargs.engine_profile = not a.no_profile
+            kconfs = [np.array(CONF4)] * K
+            kaccs, rt = timed_calls(lambda: M.train_sampled_models(kconfs, stype, loaders, kargs, device), 2)
+            nl, pms, pby, psched = profile_summary()
+            nb = -(-a.n_train // a.batch)
+            gb = alg_bytes_per_candidate(CONF4, a.R, 60, True, s_sizes, v_sizes, a.batch, a.epochs, a.n_train, a.n_dev, elt)
+            cps = K * 2 / max(rt)
+            small[name] = {"workload": f"{K} x NTU found conf 4, R={a.R}, batchnorm, drpt {a.drpt}, B={a.batch}, E={a.epochs}, one call",
+                           "candidates": K, "cand_per_s": cps, "ms_per_call": max(rt) / 2 * 1e3,
+                           "train_steps_per_s": a.epochs * nb * 2 / max(rt),
+                           "us_per_train_step_incl_dev_eval": max(rt) / 2 / (a.epochs * nb) * 1e6,
+                           "kernel_us_per_train_step": (pms / nl * 1e3) if nl else None,
+                           "kernel_algorithmic_gbs": (pby / (pms / nl * 1e-3) / 1e9) if nl else None,
+                           "schedule": psched, "frac_of_hbm_bound": cps * gb / (HBM_PEAK_GBS * 1e9),
+                           "mean_best_dev_acc": float(np.mean(kaccs))}
+    other_init = None
+    if plain and world == 1 and not a.no_small_pop:      # the same workload with the OTHER initialisation path, one call
+        oargs = SimpleNamespace(**vars(args))
+        oargs.engine_init = "device" if a.engine_init == "torch" else "torch"
+        _, rt = timed_calls(lambda: train_fn(confs, stype, loaders, oargs, device), 1)
+        other_init = {"engine_init": oargs.engine_init, "cand_per_s": total / max(rt), "ms_per_step": max(rt) * 1e3}
+
+    if rank == 0:
         achieved = bytes_per_launch / (ms / n_launch * 1e-3) / 1e9 if n_launch else None
-        sched = NS.PROFILE[-1][3] if NS.PROFILE else {}
         if sched.get("persistent"):
             kernel = ("k_president (ONE launch per epoch: per-candidate chain workgroups + "
                       + f"{sched['resident_units']} feature units resident in registers on {sched['resident_workgroups']} workgroups"
@@ -308,8 +445,8 @@ def main():
         # HBM traffic / MfmaUtil need rocprofv3 --pmc passes (separate runs, MI355X_MICROARCH.md): they are NOT measured in this
         # process.  When the committed passes of exactly this workload exist they are quoted WITH their source; else null.
         traffic = mfma = traffic_src = mfma_src = None
-        headline = a.total_pop == 0 and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1 and not a.mixed_confs
-        for tag in ("r03", "r02", "r01"):
+        headline = plain and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1
+        for tag in ("r04", "r03", "r02", "r01"):
             tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
             if headline and traffic is None and os.path.exists(tp):
                 try:
@@ -334,23 +471,30 @@ def main():
             with torch.cuda.device(device):
                 if _lib.lib().mfas_stream_probe(400 << 20, 10, ctypes.byref(gb)) == 0:
                     stream = gb.value
+        bytes_cand = float(np.mean([alg_bytes_per_candidate(c, a.R, C, not a.no_bn, s_sizes, v_sizes, a.batch, a.epochs, a.n_train, a.n_dev, elt)
+                                    for c in confs[:64]]))
+        wl = {"c1": 1, "c2": 2, "c3": 3, "c5": 4}[a.workload]
+        what = ("NTU found conf 4" if a.workload == "c1" and not a.mixed_confs else "sampled L=1..4 confs" if a.workload == "c1"
+                else f"{total} sampled L=4 MM-IMDB-shaped confs (text taps 64/128, image taps 4x512, 23 genres, weighted BCE + F1-samples)" if mm
+                else f"{total} sampled L=4 confs (np.random.seed(0))")
         line = {
             "metric": "candidate-archs trained/sec (NTU inner loop)", "value": total_trained / dt, "unit": "candidates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if a.total_pop > 0 else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[{ {'c1': 1, 'c2': 2, 'c3': 3}[a.workload] }]: "
-                                    + ("NTU found conf 4" if a.workload == "c1" and not a.mixed_confs else
-                                       "sampled L=1..4 confs" if a.workload == "c1" else f"{total} sampled L=4 confs (np.random.seed(0))")
-                                    + f", R={a.R}, {'no batchnorm' if a.no_bn else 'batchnorm'}, drpt {a.drpt}, B={a.batch}, E={a.epochs}, "
-                                      f"N_train={a.n_train}, N_dev={a.n_dev}, snr {a.snr}, {a.dtype} precomputed taps, f32 state/compute"),
+            "config": {"workload": (f"BASELINE configs[{wl}]: {what}, R={a.R}, {'no batchnorm' if a.no_bn else 'batchnorm'}, drpt {a.drpt}, "
+                                    f"B={a.batch}, E={a.epochs}, N_train={a.n_train}, N_dev={a.n_dev}, "
+                                    + ("" if mm else f"snr {a.snr}, ") + f"{a.dtype} precomputed taps, f32 state/compute"),
                        "candidates_total_per_step": total,
                        "candidates_per_gpu_per_step": (a.pop if a.total_pop == 0 else f"{total // world}..{-(-total // world)}"),
                        "parallelism": f"population-sharded x{world}",
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (a.backend if world > 1 else None),
                        "rank_seconds": rank_dt,
-                       "mean_best_dev_acc": float(np.mean(accs)),
-                       "strong": strong},
+                       "engine_init": a.engine_init, "engine_order": a.engine_order, "other_init": other_init,
+                       "mean_best_dev_acc" if not mm else "mean_best_dev_f1": float(np.mean(accs)),
+                       "hbm_bound_cand_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / bytes_cand,
+                       "frac_of_hbm_bound": total_trained / dt * bytes_cand / (HBM_PEAK_GBS * 1e9 * world),
+                       "small_pop": small, "strong": strong},
             "roofline": {"bound": "hbm", "kernel": kernel, "schedule": sched,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
@@ -359,7 +503,7 @@ def main():
                          "stream_probe": stream, "frac_of_stream_probe": (achieved / stream) if (achieved and stream) else None,
                          "mfma_util_pct_from_profile": mfma, "mfma_util_source": mfma_src},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not mm:     # (the CPU restatements are NTU-shaped: the c5 line carries none)
             line["cpu_baseline"] = cpu_baseline(train, dev, a)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -147,8 +147,10 @@ int mfas_population_forward_train(mfas_population* pop, int32_t k, const mfas_ta
  * /root/reference/models/search/ntu_searchable.py:206-247, for callers that write their own training loop).  The batch is run
  * again in train mode with the same dropout stream (`step_index`) and batch statistics, `dlogits` (DEVICE, nrows x C float32
  * = dL/dlogits) takes the place of the loss gradient, and each parameter's gradient is left in its Adam first-moment slot:
- * read it with mfas_population_get_params(pop, k, 1, flat).  Parameters are not changed; the second-moment slots and the BN
- * running statistics are scratch afterwards — call it on a population used for nothing else (the Python mirror clones one). */
+ * read it with mfas_population_get_params(pop, k, 1, flat).  Parameters are not changed.  Candidate k's Adam moment slots are
+ * ZEROED at entry (the gradient is accumulated into the first-moment slot from 0, whatever the handle trained before) and are
+ * scratch afterwards, like the BN running statistics: the optimizer state of candidate k does not survive this call — use a
+ * population kept for the purpose (the Python mirror builds one per call). */
 int mfas_population_backward(mfas_population* pop, int32_t k, const mfas_table* table, int64_t row0, int32_t nrows,
                              int32_t step_index, const float* dlogits);
 
@@ -187,6 +189,12 @@ int mfas_stream_probe(int64_t bytes_per_plane, int32_t iters, double* gb_per_s);
  * x / out are device pointers of dtype MFAS_DT_* ; f32 accumulation.  The step that builds an mfas_table from raw taps. */
 int mfas_global_pool(const void* x, int32_t dtype, int64_t rows, int64_t inner, void* out, int32_t out_dtype,
                      void* hip_stream);
+
+/* (new, round 4) Profiler ranges (roctx markers; no-ops when the marker library is not loadable): mfas_population_train opens one
+ * range per call and one per epoch itself; the host side brackets each train_sampled_models call
+ * (/root/reference/models/search/ntu_searchable.py:23-102) with these.  Always return MFAS_OK. */
+int mfas_range_push(const char* name);
+int mfas_range_pop(void);
 
 /* snapshot_best bookkeeping: a dev metric must EXCEED `threshold` to replace the kept parameters (best_acc = 0,
  * train_searchable/ntu.py:18; best_f1 = init_f1, train_searchable/mmimdb.py:18).  Default 0.  If no epoch exceeds it the

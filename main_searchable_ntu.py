@@ -54,6 +54,9 @@ def parse_args(argv=None):
     p.add_argument("--engine_order", default="shared", choices=["shared", "per_candidate"],
                    help="shared: one shuffled order per epoch for the whole call (lockstep); per_candidate: every candidate draws its own "
                         "permutations, as the reference's per-candidate DataLoader(shuffle=True) does (models/searchable.py:248-250)")
+    p.add_argument("--engine_all_ranks", action="store_true", default=False,
+                   help="under torchrun: shard every call over ALL ranks (default: only as many ranks as the calibrated step-time model "
+                        "says shorten the call, mfas_amd/population.py)")
     p.add_argument("--surrogate_device", default="cpu", choices=["cpu", "gpu"],
                    help="where the 81k-parameter LSTM surrogate trains (the reference puts it on its training device).  gpu: train steps "
                         "replayed as HIP graphs (0.87 ms instead of the CPU path's 1.9 ms per step; device GEMM numerics, so sampled "

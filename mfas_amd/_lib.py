@@ -71,6 +71,7 @@ def lib():
     L.mfas_population_set_pos_weight.argtypes = [P, P]
     L.mfas_stream_probe.argtypes = [C.c_int64, C.c_int32, P]
     L.mfas_global_pool.argtypes = [P, C.c_int32, C.c_int64, C.c_int64, P, C.c_int32, P]
+    L.mfas_range_push.argtypes = [C.c_char_p]
     _lib = L
     return L
 
@@ -80,7 +81,21 @@ EXPORTS = ["mfas_last_error", "mfas_version", "mfas_population_create", "mfas_po
            "mfas_population_init", "mfas_population_train", "mfas_population_forward",
            "mfas_population_sweep_profile", "mfas_population_set_profiling", "mfas_population_set_pos_weight", "mfas_global_pool", "mfas_stream_probe", "mfas_source_digest",
            "mfas_population_set_best_threshold", "mfas_population_forward_train", "mfas_population_schedule",
-           "mfas_population_plan", "mfas_population_backward"]
+           "mfas_population_plan", "mfas_population_backward", "mfas_range_push", "mfas_range_pop"]
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def profiler_range(name: str):
+    """A roctx range around a host-side region (mfas_range_push / mfas_range_pop: no-ops without the marker library)."""
+    L = lib()
+    L.mfas_range_push(name.encode())
+    try:
+        yield
+    finally:
+        L.mfas_range_pop()
 
 
 def check(rc):

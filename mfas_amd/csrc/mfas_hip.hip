@@ -36,6 +36,7 @@
 #include <vector>
 #include <thread>
 #include <chrono>
+#include <dlfcn.h>
 
 #include "mfas_hip.h"
 
@@ -162,6 +163,33 @@ struct mfas_population {
 };
 
 static inline int ceil16(int x) { return (x + 15) & ~15; }
+
+// roctx ranges around a train() call and each of its epochs (rocprofv3 --marker-trace shows them next to the kernels).  The
+// marker library is looked up at run time: no link-time dependency, plain no-ops where it is absent (or MFAS_NO_ROCTX is set).
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        if (getenv("MFAS_NO_ROCTX")) return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+struct RangeGuard {      // pops on every return path
+    bool on;
+    explicit RangeGuard(const std::string& name) : on(roctx().push != nullptr) { if (on) roctx().push(name.c_str()); }
+    ~RangeGuard() { if (on) roctx().pop(); }
+};
+}
+extern "C" int mfas_range_push(const char* name) { if (name && roctx().push) roctx().push(name); return MFAS_OK; }
+extern "C" int mfas_range_pop(void) { if (roctx().pop) roctx().pop(); return MFAS_OK; }
 
 extern "C" const char* mfas_last_error(void) { return g_err.c_str(); }
 extern "C" int mfas_version(void) { return 200; }
@@ -290,12 +318,10 @@ static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs
     lp.resident = lp.want_persist && lp.res_ok && K <= n_cus / 4 && g.MB != 4 && K + lp.nres_wg <= n_cus;
 }
 
-#define MFAS_RETRY_NO_PERSIST 12345   // internal: the layout was planned for the resident persistent schedule, which then did not fit
-
-static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells,
-                       const uint32_t* drop_seeds, int32_t K, int32_t device, void* hip_stream,
-                       int32_t chunk_cols, mfas_population** out, const bool allow_persist) {
-    if (!hp || !confs || !n_cells || !out || K <= 0) return fail(MFAS_EINVAL, "null argument or K <= 0");
+// Everything mfas_population_create refuses about (hp, confs, n_cells, K): shared with mfas_population_plan, so that the query never
+// reports a layout for inputs create() would reject.
+static int validate_inputs(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells, int32_t K) {
+    if (!hp || !confs || !n_cells || K <= 0) return fail(MFAS_EINVAL, "null argument or K <= 0");
     if (hp->R < 1 || hp->R > 512 || hp->C < 1 || hp->C > 256) return fail(MFAS_EINVAL, "R must be in [1,512], C in [1,256]");
     if (hp->B < 2 || hp->B > 64) return fail(MFAS_EINVAL, "batchsize must be in [2,64]");
     {
@@ -309,6 +335,26 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     for (int j = 0; j < MFAS_MAX_TAPS; ++j)
         if (hp->s_sizes[j] < 0 || hp->v_sizes[j] < 0 || hp->s_sizes[j] > (1 << 20) || hp->v_sizes[j] > (1 << 20))
             return fail(MFAS_EINVAL, "tap widths must be in [0, 2^20]");
+    for (int k = 0; k < K; ++k) {
+        const int L = n_cells[k];
+        if (L < 1 || L > MFAS_MAX_CELLS) return fail(MFAS_EINVAL, "n_cells must be in [1,4]");
+        for (int i = 0; i < L; ++i) {
+            const int32_t* c = confs + (k * 4 + i) * 3;
+            if (c[0] < 0 || c[0] >= MFAS_MAX_TAPS || c[1] < 0 || c[1] >= MFAS_MAX_TAPS || c[2] < 0 || c[2] > 2 ||
+                hp->s_sizes[c[0]] < 1 || hp->v_sizes[c[1]] < 1)
+                return fail(MFAS_EINVAL, "configuration entry out of range (tap index / unused tap slot / non-linearity)");
+        }
+    }
+    return MFAS_OK;
+}
+
+#define MFAS_RETRY_NO_PERSIST 12345   // internal: the layout was planned for the resident persistent schedule, which then did not fit
+
+static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells,
+                       const uint32_t* drop_seeds, int32_t K, int32_t device, void* hip_stream,
+                       int32_t chunk_cols, mfas_population** out, const bool allow_persist) {
+    if (!out) return fail(MFAS_EINVAL, "null argument or K <= 0");
+    if (int vrc = validate_inputs(hp, confs, n_cells, K)) return vrc;
     mfas_population* p = new (std::nothrow) mfas_population();
     if (!p) return fail(MFAS_ENOMEM, "host alloc");
     p->hp = *hp;
@@ -736,8 +782,8 @@ extern "C" int mfas_population_create(const mfas_hyper* hp, const int32_t* confs
 // destroying populations.
 extern "C" int mfas_population_plan(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells, int32_t K, int32_t device,
                                     int32_t chunk_cols, int32_t info[8]) {
-    if (!hp || !confs || !n_cells || !info || K <= 0) return fail(MFAS_EINVAL, "null argument or K <= 0");
-    if (hp->R < 1 || hp->R > 512 || hp->C < 1 || hp->C > 256 || hp->B < 2 || hp->B > 64) return fail(MFAS_EINVAL, "R / C / batchsize out of range");
+    if (!info) return fail(MFAS_EINVAL, "null argument or K <= 0");
+    if (int vrc = validate_inputs(hp, confs, n_cells, K)) return vrc;
     Geo g;
     memset(&g, 0, sizeof(g));
     g.R = hp->R; g.C = hp->C; g.Rp = ceil16(hp->R); g.Cp = ceil16(hp->C);
@@ -968,6 +1014,8 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     const double metric_scale = g.loss_mode == 1 ? 1.0 / 4294967296.0 : 1.0;   // F1 sums are 32.32 fixed point
     std::vector<DevStats> hstats((size_t)K * epochs);
 
+    RangeGuard call_range("mfas_population_train K=" + std::to_string(K) + " R=" + std::to_string(g.R) + " B=" + std::to_string(B) +
+                          " E=" + std::to_string(epochs) + (p->persist ? " resident" : " launch-per-phase"));
     const mfas_hyper& hp = p->hp;
     AdamC ac;
     ac.w1 = (float)(1.0 - hp.beta1); ac.b2 = (float)hp.beta2; ac.w2 = (float)(1.0 - hp.beta2);
@@ -1168,6 +1216,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         int64_t T = nb;
         if (max_steps >= 0) T = std::min<int64_t>(nb, max_steps - done);
         if (T <= 0) break;
+        RangeGuard epoch_range("epoch " + std::to_string(ep));
         if (p->persist) {
             HIPCHK(persist_epoch(ep, T));
             if (aborts[ep] == PERSIST_ABORT_NOT_RESIDENT) {
@@ -1355,6 +1404,13 @@ static int single_batch(mfas_population* p, int32_t k, const mfas_table* tab, in
         else if (g.MB == 2) hipLaunchKernelGGL((k_step<2, false, 2, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
         else hipLaunchKernelGGL((k_step<4, false, 2, false>), dim3(nsw), dim3(STEP_THREADS), lds_need, p->stream, st);
     };
+    if (dlogits) {
+        // The gradient lands in the first-moment slot as m <- m + 1 * (g - m): exact only from m = 0 (1 + (1e-9 - 1) cancels to 0),
+        // and a stale second moment would turn the zero-step's 0 * (m / denom) into 0 * inf.  Whatever this handle has trained
+        // before, candidate k's m and v planes start from zero here (the header documents them as scratch after this call).
+        HIPCHK(hipMemsetAsync(p->plane + p->plane_stride + p->cand_plane_base[k], 0, sizeof(float) * (size_t)p->cand_plane_size[k], p->stream));
+        HIPCHK(hipMemsetAsync(p->plane + 2 * p->plane_stride + p->cand_plane_base[k], 0, sizeof(float) * (size_t)p->cand_plane_size[k], p->stream));
+    }
     // 1. forward partial sums of the batch (no update): the sweep's forward half over this candidate's units
     sweep();
     // 2. the chain: batch-statistics BN (running statistics move like in any train-mode forward), dropout stream of step_index;

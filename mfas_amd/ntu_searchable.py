@@ -63,28 +63,41 @@ class FeatureTap(nn.Module):
 class _TrainModeForward(torch.autograd.Function):
     """Train-mode forward of one batch on the engine WITH an autograd edge to the central parameters: forward =
     mfas_population_forward_train on a scratch population holding the module's parameters; backward = mfas_population_backward on
-    the same population (same dropout stream, same batch statistics) with the incoming dL/dlogits — the engine's own fused
-    backward, not a torch graph.  ntu_searchable.py:206-247 under model.train(True), for callers that write their own loop."""
+    a scratch population of the same state (same dropout stream, same batch statistics) with the incoming dL/dlogits — the
+    engine's own fused backward, not a torch graph.  ntu_searchable.py:206-247 under model.train(True), for callers that write
+    their own loop.  Nothing of the GPU is kept between the two calls (the backward pass runs the batch again anyway): a forward
+    under no_grad, or one whose loss is never backpropagated, holds no device memory."""
 
     @staticmethod
-    def forward(ctx, module, table, n, seed, *params):
+    def _scratch(module, table, n, seed, flat0):
         hp = module.hyper(False)
         hp.B = max(n, 2)
         pop = Population(hp, [module.conf], table.label.device, drop_seeds=[seed & 0xFFFFFFFF])
-        flat0 = module.flat_params()
         pop.set_params(0, flat0)
-        out = pop.forward_train(0, table, 0, n, step=0)
-        if module.args.batchnorm:
-            module.load_flat(pop.get_params(0))      # the moved running statistics (nothing else changed)
-            _bump_bn_counters(module, 1)
-        ctx.pop, ctx.table, ctx.n, ctx.flat0, ctx.module = pop, table, n, flat0, module
+        return pop
+
+    @staticmethod
+    def forward(ctx, module, table, n, seed, *params):
+        flat0 = module.flat_params()
+        pop = _TrainModeForward._scratch(module, table, n, seed, flat0)
+        try:
+            out = pop.forward_train(0, table, 0, n, step=0)
+            if module.args.batchnorm:
+                module.load_flat(pop.get_params(0))      # the moved running statistics (nothing else changed)
+                _bump_bn_counters(module, 1)
+        finally:
+            pop.close()
+        ctx.table, ctx.n, ctx.seed, ctx.flat0, ctx.module = table, n, seed, flat0, module
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        pop, module = ctx.pop, ctx.module
-        pop.set_params(0, ctx.flat0)              # the state the forward saw (its own call moved the running statistics)
-        gflat = pop.backward(0, ctx.table, grad_out, 0, ctx.n, step=0).cpu()
+        module = ctx.module
+        pop = _TrainModeForward._scratch(module, ctx.table, ctx.n, ctx.seed, ctx.flat0)     # the state the forward saw
+        try:
+            gflat = pop.backward(0, ctx.table, grad_out, 0, ctx.n, step=0).cpu()
+        finally:
+            pop.close()
         where = {key: (shape, off) for key, shape, off in flat_layout(module.conf, module.hyper(False))[0]}
         grads = []
         for key, prm in module.named_parameters():
@@ -201,8 +214,11 @@ class Searchable_Skeleton_Image_Net(nn.Module):
 
     def forward(self, tensor_tuple):
         """tensor_tuple = (rgb, ske): dict-likes holding the pooled taps v0..v3 [+ 'vlogit'] and s0..s3
-        [+ 'slogit'] on a HIP device.  Eval mode only: training runs inside the engine
-        (train_sampled_models / train_ntu_track_acc)."""
+        [+ 'slogit'] on a HIP device.  Eval mode: running-statistics BatchNorm, no Dropout (mfas_population_forward).  Train mode:
+        one batch of <= 64 samples with batch statistics and Dropout, differentiable with respect to the central parameters
+        (_TrainModeForward).  The taps are outputs of frozen backbones here (feature tables): no gradient flows into them, and
+        taps that require grad are refused instead of being silently cut off.  The fast path for training stays
+        train_sampled_models / train_ntu_track_acc."""
         image, skeleton = tensor_tuple[0], tensor_tuple[1]
         visual = self.rgbnet(image)
         skel = self.skenet(skeleton)
@@ -212,6 +228,9 @@ class Searchable_Skeleton_Image_Net(nn.Module):
             raise ValueError("forward needs the pooled taps 'v0'.. / 's0'.. of the batch (there are no backbones in this engine)")
         some = next(iter(taps.values()))
         n = some.shape[0]
+        if torch.is_grad_enabled() and any(t.requires_grad for t in taps.values()):
+            raise NotImplementedError("the taps require grad, but this engine's backbones are frozen feature tables: it produces gradients "
+                                      "for central_params() only (train_only_central_params, ntu_searchable.py:27); detach() the taps")
         table = FeatureTable(taps, torch.zeros(n, dtype=torch.int32, device=some.device))
         if self.training:
             # train mode (ntu_searchable.py:206-247 under model.train(True)): batch-statistics BatchNorm — running statistics and
@@ -299,8 +318,9 @@ def _require_loader(x, name, device=None) -> FeatureLoader:
                 if k in ("vlogit", "slogit"):
                     extra.setdefault(k, []).append(v.reshape(v.shape[0], -1).float())
                 elif len(k) >= 2 and k[0] in "sv" and k[1:].isdigit():
-                    if v.dim() > 2:          # GlobalPooling2D semantics (aux_models.py:58-64) for un-pooled maps
-                        v = v.reshape(v.shape[0], v.shape[1], -1).float().mean(2)
+                    if v.dim() > 2:          # GlobalPooling2D (aux_models.py:58-64) for un-pooled maps: the k_pool kernel
+                        from .pooling import global_pool
+                        v = global_pool(v.to(torch.device(device)), torch.float32)
                     taps.setdefault(k, []).append(v)
         lab = torch.as_tensor(batch["label"]).reshape(-1)
         labels.append(lab)
@@ -345,12 +365,13 @@ def make_order_per_candidate(N, epochs, shuffle, seed, device, indices):
     return torch.stack(out).to(torch.int32)
 
 
-def initial_flat_params(args, conf, hp=None) -> torch.Tensor:
+def initial_flat_params(args, conf, hp=None, generator=None) -> torch.Tensor:
     """The flat parameter vector `Searchable_Skeleton_Image_Net(args, conf).flat_params()` would hold right after
     construction — same draws from torch's global RNG in the same order (per cell Linear weight: kaiming_uniform_(a=sqrt(5)),
     bias: U(+-1/sqrt(fan_in)); the classifier likewise; then alpha_i ~ N(0, 0.1)), BatchNorm at its defaults — without
     building the ~20 module objects per candidate (train_sampled_models initialises every sampled candidate this way:
-    ≈ 1 ms per candidate, a fifth of a 50-candidate call's time at R=16)."""
+    ≈ 1 ms per candidate, a fifth of a 50-candidate call's time at R=16).  `generator`: draw from this torch.Generator instead of
+    the global stream (seeded alike it yields the same numbers)."""
     import math
     conf = np.asarray(conf).reshape(-1, 3)
     hp = hp if hp is not None else Hyper.from_args(args)
@@ -367,9 +388,9 @@ def initial_flat_params(args, conf, hp=None) -> torch.Tensor:
     def linear(wkey, bkey):
         w, b = view(wkey), view(bkey)
         fan_in = w.shape[1]
-        w.uniform_(-(math.sqrt(3.0) * (kgain / math.sqrt(fan_in))), math.sqrt(3.0) * (kgain / math.sqrt(fan_in)))   # kaiming_uniform_'s bound, same expression
+        w.uniform_(-(math.sqrt(3.0) * (kgain / math.sqrt(fan_in))), math.sqrt(3.0) * (kgain / math.sqrt(fan_in)), generator=generator)   # kaiming_uniform_'s bound, same expression
         bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
-        b.uniform_(-bound, bound)
+        b.uniform_(-bound, bound, generator=generator)
 
     with torch.no_grad():
         for i, c in enumerate(conf):
@@ -384,7 +405,7 @@ def initial_flat_params(args, conf, hp=None) -> torch.Tensor:
                 view(f"fusion_layers.{i}.2.running_var").fill_(1.0)
         linear("central_classifier.weight", "central_classifier.bias")
         for i in range(len(conf)):
-            nn.init.normal_(view(f"alphas.{i}.alpha_x"), 0.0, 0.1)
+            view(f"alphas.{i}.alpha_x").normal_(0.0, 0.1, generator=generator)      # nn.init.normal_
     return flat
 
 
@@ -392,61 +413,77 @@ ROUNDS_MIN_CANDIDATES = 16         # (a share that does not fit the resident sch
 
 
 def _plan_rounds(hp, confs, mine, device, seed_base, chunk_cols):
-    """The rank's share as ONE population, or as several trained one after the other when the share is too large for the
-    persistent resident schedule (parameters in registers, one launch pair per epoch: <= ~28 conf-4-sized candidates at R <= 16):
-    every round but the last is filled to the resident capacity (a resident round costs 15-21 us per train step almost
-    independently of its size), found by bisection on the engine's own layout decision — asked as a pure query
-    (mfas_population_plan: nothing is allocated; only the populations that train are ever created).  Measured at R=16, B=20 on
-    MI355X: 29...56 candidates take 38-55 us per train step with launches, 36-41 us as two resident rounds.  Candidates are
-    independent and carry their own seeds, so the split changes nothing but the column-chunk summation order (as any change
-    of population size does).  Yields (indices, Population)."""
+    """The rank's share as ONE population, or as several resident rounds trained one after the other (population.split_rounds:
+    the decision is the engine's own layout query, mfas_population_plan — nothing is allocated for it; only the populations
+    that train are ever created).  Candidates are independent and carry their own seeds, so the split changes nothing but the
+    column-chunk summation order (as any change of population size does).  Yields (indices, Population)."""
     if not mine:
         return
+    for pos, planned_resident in popmod.split_rounds(hp, [confs[i] for i in mine], device, chunk_cols, ROUNDS_MIN_CANDIDATES):
+        idx = [mine[j] for j in pos]
+        pop = Population(hp, [confs[i] for i in idx], device, drop_seeds=[(seed_base * 7 + i) & 0xFFFFFFFF for i in idx],
+                         chunk_cols=chunk_cols)
+        if bool(pop.schedule()["persistent"]) != bool(planned_resident) and hp.R <= 16:
+            import warnings      # (MFAS_PERSIST* read at different times, or a plan / create disagreement: results are unaffected)
+            warnings.warn(f"mfas_amd: the layout query planned {'a resident' if planned_resident else 'a launch-per-phase'} round of "
+                          f"{len(idx)} candidates but the population was created {'resident' if not planned_resident else 'launch-per-phase'}")
+        yield idx, pop
 
-    def make(idx):
-        return Population(hp, [confs[i] for i in idx], device, drop_seeds=[(seed_base * 7 + i) & 0xFFFFFFFF for i in idx],
-                          chunk_cols=chunk_cols)
 
-    def resident(idx):
-        return plan_population(hp, [confs[i] for i in idx], device, chunk_cols)["persistent"]
+def _initial_params_threaded(args, confs, group, hp, seed_base, searchable_type, return_model, mods):
+    """Yields (i, flat) for every candidate of `group` in order: its initial flat parameters = what constructing its module under
+    torch.manual_seed(seed_base + 2 + i) draws (ntu_searchable.py:44 builds the model from torch's global stream).  Module-free
+    candidates draw from a PRIVATE torch.Generator seeded the same way (same Mersenne-Twister stream, same numbers:
+    tests/test_host_cpu.py), which makes the fills independent of each other: a small thread pool runs them side by side (torch's
+    uniform_ is serial and releases the GIL; 1 M draws per R=128 candidate) while the caller uploads the finished ones."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    # (the fills are tiny for torch's intra-op pool: with every host core in it their fork/join dominates — 6 ms instead of 0.7 ms
+    #  per candidate on a 256-thread host; the values do not depend on the thread count)
+    nthreads = torch.get_num_threads()
+    if nthreads > 4:
+        torch.set_num_threads(4)
+    try:
+        if return_model or searchable_type is not Searchable_Skeleton_Image_Net:
+            for i in group:
+                with torch.random.fork_rng(devices=[]):
+                    torch.manual_seed(seed_base + 2 + i)   # world-size independent per-candidate stream
+                    m = searchable_type(args, confs[i])
+                if return_model:
+                    mods[i] = m
+                yield i, m.flat_params()
+            return
 
-    if (hp.R > 16 or len(mine) < ROUNDS_MIN_CANDIDATES or os.environ.get("MFAS_NO_ROUNDS") or resident(mine)):
-        yield mine, make(mine)
-        return
-    rounds, rest = [], list(mine)
-    while rest and len(rounds) < 4:
-        if resident(rest):
-            rounds.append(rest)
-            rest = []
-            break
-        lo, hi, best = 1, len(rest) - 1, 0          # largest resident prefix of `rest`
-        while lo <= hi:
-            mid = (lo + hi) // 2
-            if resident(rest[:mid]):
-                best, lo = mid, mid + 1
-            else:
-                hi = mid - 1
-        if best == 0:
-            break
-        if not rounds:
-            nr = -(-len(rest) // best)
-            last = len(rest) - (nr - 1) * best
-            # three or four rounds only pay when the last one is reasonably full (measured: 64 candidates as 28 + 28 + 8: 210 vs
-            # 234 cand/s with launches; 84 as 3 x 28: 255 vs 238)
-            if nr > 4 or (nr >= 3 and last < 0.6 * best):
-                break
-        rounds.append(rest[:best])
-        rest = rest[best:]
-    if rest or not rounds:                              # no resident layout for what is left: one launch-per-phase population
-        yield mine, make(mine)
-        return
-    for g in rounds:
-        yield g, make(g)
+        def one(i):
+            g = torch.Generator()
+            g.manual_seed(seed_base + 2 + i)
+            return i, initial_flat_params(args, confs[i], hp, generator=g)
+
+        workers = max(1, min(8, (os.cpu_count() or 1) // 2, len(group)))
+        if workers == 1:
+            for i in group:
+                yield one(i)
+            return
+        with ThreadPoolExecutor(workers) as ex:
+            yield from ex.map(one, group)
+    finally:
+        if nthreads > 4:
+            torch.set_num_threads(nthreads)
 
 
 def train_sampled_models(sampled_configurations, searchable_type, dataloaders, args, device,
                          return_model=[], premodels=[], preaccuracies=[],
                          train_only_central_params=True, state_dict=dict(), _hp=None, _pos_weight=None):
+    """Drop-in for ntu_searchable.py:23-102 (see _train_sampled_models); the call is one profiler range (roctx marker)."""
+    from . import _lib
+    with _lib.profiler_range(f"train_sampled_models K={len(sampled_configurations)}"):
+        return _train_sampled_models(sampled_configurations, searchable_type, dataloaders, args, device, return_model, premodels,
+                                     preaccuracies, train_only_central_params, state_dict, _hp, _pos_weight)
+
+
+def _train_sampled_models(sampled_configurations, searchable_type, dataloaders, args, device,
+                          return_model=[], premodels=[], preaccuracies=[],
+                          train_only_central_params=True, state_dict=dict(), _hp=None, _pos_weight=None):
     """Drop-in for ntu_searchable.py:23-102.  Every configuration is trained from scratch for
     ``args.epochs`` epochs of {train over dataloaders['train'], eval over dataloaders['dev']} and its best dev
     accuracy returned, in input order.  The whole (per-rank share of the) population trains in lockstep inside
@@ -486,79 +523,78 @@ def train_sampled_models(sampled_configurations, searchable_type, dataloaders, a
                                     return_model, premodels, state_dict)
 
     rank, world = popmod.dist_info()
-    costs = [popmod.candidate_cost(confs[i], hp.R, hp.s_sizes, hp.v_sizes, hp.C) for i in wanted]
-    owner, cap = popmod.shard(costs, world, None if getattr(args, "engine_all_ranks", False) else hp.R)
-    mine = [i for i, o in zip(wanted, owner) if o == rank]
+    wconfs = [confs[i] for i in wanted]
+    owner, cap, _ = popmod.shard_call(wconfs, hp, world, device, bool(getattr(args, "engine_all_ranks", False)))
+    costs = [popmod.candidate_cost(c, hp.R, hp.s_sizes, hp.v_sizes, hp.C) for c in wconfs]
 
-    local_acc_by_idx, models = {}, {}
+    models = {}
     sched = LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, num_batches_per_epoch)
     etas = sched.eta_table(E * nb)
-    order = make_order(N_tr, E, train_l.shuffle, seed_base + 1, device) if (mine and not per_cand) else None
-    for group, pop in _plan_rounds(hp, confs, mine, device, seed_base, int(getattr(args, "engine_chunk_cols", 0))):
-        if _pos_weight is not None:
-            pop.set_pos_weight(_pos_weight)
-        mods = {}
-        if premodels:
-            for j, i in enumerate(group):
-                src = premodels[i].module if getattr(args, "use_dataparallel", False) else premodels[i]
-                m = searchable_type(args, confs[i])
-                m.load_state_dict(src.state_dict())
-                pop.set_params(j, m.flat_params())
-                mods[i] = m
-        elif getattr(args, "engine_init", "torch") == "device":
-            pop.init([(seed_base + 2 + i) & 0x7FFFFFFF for i in group])
-        else:
-            # (the random fills below are tiny: with every host core in torch's pool their fork/join dominates — 6 ms instead of
-            #  0.7 ms per candidate on a 256-thread host; the values do not depend on the thread count)
-            nthreads = torch.get_num_threads()
-            if nthreads > 4:
-                torch.set_num_threads(4)
+    shared_order = {}
+    fail_rank = int(os.environ.get("MFAS_TEST_FAIL_RANK", "-1"))      # test hook: this rank's FIRST share raises (population.train_sharded re-queues it)
+    attempts = [0]
+
+    def train_share(mine):
+        """This rank's share (or a re-queued part of a failed rank's): {candidate index: best dev metric}."""
+        attempts[0] += 1
+        if world > 1 and rank == fail_rank and attempts[0] == 1:
+            raise RuntimeError("MFAS_TEST_FAIL_RANK: simulated failure of this rank's share")
+        acc_by_idx = {}
+        if mine and not per_cand and "o" not in shared_order:
+            shared_order["o"] = make_order(N_tr, E, train_l.shuffle, seed_base + 1, device)
+        order = shared_order.get("o")
+        for group, pop in _plan_rounds(hp, confs, mine, device, seed_base, int(getattr(args, "engine_chunk_cols", 0))):
             try:
+                if _pos_weight is not None:
+                    pop.set_pos_weight(_pos_weight)
+                mods = {}
+                if premodels:
+                    for j, i in enumerate(group):
+                        src = premodels[i].module if getattr(args, "use_dataparallel", False) else premodels[i]
+                        m = searchable_type(args, confs[i])
+                        m.load_state_dict(src.state_dict())
+                        pop.set_params(j, m.flat_params())
+                        mods[i] = m
+                elif getattr(args, "engine_init", "torch") == "device":
+                    pop.init([(seed_base + 2 + i) & 0x7FFFFFFF for i in group])
+                else:
+                    for j, (i, flat0) in enumerate(_initial_params_threaded(args, confs, group, hp, seed_base, searchable_type, return_model, mods)):
+                        assert i == group[j]
+                        pop.set_params(j, flat0)
+                if getattr(args, "verbose", False):
+                    print("Now training: ")
+                    for i in group:
+                        print(confs[i])
+                if getattr(args, "engine_profile", False):
+                    pop.set_profiling(True)
+                if per_cand:
+                    order = make_order_per_candidate(N_tr, E, train_l.shuffle, seed_base + 1, device, group)
+                stats, status = pop.train(train_l.table, dev_l.table, E, etas, order=order,
+                                          snapshot_best=bool(return_model))
+                if getattr(args, "engine_profile", False):
+                    PROFILE.append(pop.sweep_profile() + (pop.schedule(),))
                 for j, i in enumerate(group):
-                    with torch.random.fork_rng(devices=[]):
-                        torch.manual_seed(seed_base + 2 + i)   # world-size independent per-candidate stream
-                        if return_model or searchable_type is not Searchable_Skeleton_Image_Net:
-                            m = searchable_type(args, confs[i])
-                            if return_model:
-                                mods[i] = m
-                            flat0 = m.flat_params()
-                        else:   # same numbers, without the module objects (initial_flat_params)
-                            flat0 = initial_flat_params(args, confs[i], hp)
-                    pop.set_params(j, flat0)
+                    if getattr(args, "verbose", False):
+                        for e in range(E):
+                            print("train Loss: {:.4f} Acc: {:.4f}".format(stats["train_loss_sum"][j, e] / N_tr,
+                                                                          stats["train_corrects"][j, e] / N_tr))
+                            print("dev Loss: {:.4f} Acc: {:.4f}".format(stats["dev_loss_sum"][j, e] / N_dev,
+                                                                        stats["dev_corrects"][j, e] / N_dev))
+                    acc_by_idx[i] = (best_dev_f1(stats[j], bool(status[j]), N_dev) if hp.loss_mode == 1
+                                     else best_dev_accuracy(stats[j], N_dev))
+                    if return_model:
+                        m = mods.get(i) or searchable_type(args, confs[i])
+                        m.load_flat(pop.get_params(j))
+                        _bump_bn_counters(m, E * nb)
+                        m.to(device)
+                        m.train(False)
+                        models[i] = m
             finally:
-                if nthreads > 4:
-                    torch.set_num_threads(nthreads)
-        if getattr(args, "verbose", False):
-            print("Now training: ")
-            for i in group:
-                print(confs[i])
-        if getattr(args, "engine_profile", False):
-            pop.set_profiling(True)
-        if per_cand:
-            order = make_order_per_candidate(N_tr, E, train_l.shuffle, seed_base + 1, device, group)
-        stats, status = pop.train(train_l.table, dev_l.table, E, etas, order=order,
-                                  snapshot_best=bool(return_model))
-        if getattr(args, "engine_profile", False):
-            PROFILE.append(pop.sweep_profile() + (pop.schedule(),))
-        for j, i in enumerate(group):
-            if getattr(args, "verbose", False):
-                for e in range(E):
-                    print("train Loss: {:.4f} Acc: {:.4f}".format(stats["train_loss_sum"][j, e] / N_tr,
-                                                                  stats["train_corrects"][j, e] / N_tr))
-                    print("dev Loss: {:.4f} Acc: {:.4f}".format(stats["dev_loss_sum"][j, e] / N_dev,
-                                                                stats["dev_corrects"][j, e] / N_dev))
-            local_acc_by_idx[i] = (best_dev_f1(stats[j], bool(status[j]), N_dev) if hp.loss_mode == 1
-                                   else best_dev_accuracy(stats[j], N_dev))
-            if return_model:
-                m = mods.get(i) or searchable_type(args, confs[i])
-                m.load_flat(pop.get_params(j))
-                _bump_bn_counters(m, E * nb)
-                m.to(device)
-                m.train(False)
-                models[i] = m
-        pop.close()
-    local_acc = [local_acc_by_idx[i] for i in mine]
-    accs_all = popmod.gather_accuracies(mine, local_acc, K, device, cap=cap)
+                pop.close()
+        return acc_by_idx
+
+    # ONE all_gather of (index, accuracy) pairs (RCCL on the GPU box); a rank whose share fails is re-queued, never waited for
+    accs_all = popmod.train_sharded(wanted, owner, cap, K, costs, train_share, device)
     real_accuracies = [accs_all[i] for i in wanted]
     if return_model:
         # models live on the rank that trained them; other ranks get None placeholders

@@ -51,35 +51,95 @@ def assign(costs: Sequence[int], world: int) -> List[int]:
 
 
 def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: int, device=None,
-                      cap: int | None = None) -> List[float]:
-    """All ranks end up with the K accuracies in input order: ONE all_gather of `cap` (index, accuracy) pairs per rank
-    and one device-to-host copy — latency-bound, a few hundred bytes.  `cap` (the largest per-rank share) is known to
-    every rank from assign(); without it ceil(K/W)+1 is only an upper bound for round-robin-like assignments, so
-    callers that shard with assign() pass it."""
+                      cap: int | None = None, failed: bool = False, strict: bool = True):
+    """All ranks end up with the K accuracies in input order: ONE all_gather of `cap` (index, accuracy) pairs per rank (+ one
+    status row) and one device-to-host copy — latency-bound, a few hundred bytes.  `cap` (the largest per-rank share) is known to
+    every rank from assign(); without it ceil(K/W)+1 is only an upper bound for round-robin-like assignments, so callers that
+    shard with assign() pass it.  `failed`: this rank could not train (all of) its share — it still joins the collective, so
+    nobody hangs.  strict: raise when a candidate was trained by no rank; else return (accuracies with NaN holes, failed ranks)."""
     rank, world = dist_info()
     if world == 1:
-        out = [0.0] * K
+        out = [float("nan")] * K if not strict else [0.0] * K
         for i, a in zip(local_idx, local_acc):
             out[i] = float(a)
-        return out
+        return out if strict else (out, [0] if failed else [])
     backend = dist.get_backend()
     dev = torch.device("cpu") if backend == "gloo" else (device or torch.device("cuda", torch.cuda.current_device()))
     if cap is None:
         cap = K
     assert len(local_idx) <= cap, (len(local_idx), cap)
-    host = np.full((cap, 2), -1.0, np.float64)
+    host = np.full((cap + 1, 2), -1.0, np.float64)
     for j, (i, a) in enumerate(zip(local_idx, local_acc)):
         host[j, 0] = float(i)
         host[j, 1] = float(a)
+    host[cap, 0] = -2.0 if failed else -3.0          # status row
     buf = torch.from_numpy(host).to(dev)
-    allb = torch.empty((world * cap, 2), dtype=torch.float64, device=dev)   # rank-major concatenation
+    allb = torch.empty((world * (cap + 1), 2), dtype=torch.float64, device=dev)   # rank-major concatenation
     dist.all_gather_into_tensor(allb, buf)
     out = [float("nan")] * K
-    for i, a in allb.cpu().numpy():
-        if i >= 0:
-            out[int(i)] = float(a)
-    assert not any(np.isnan(out)), "a candidate was trained by no rank"
-    return out
+    rows = allb.cpu().numpy().reshape(world, cap + 1, 2)
+    bad = [r for r in range(world) if rows[r, cap, 0] == -2.0]
+    for r in range(world):
+        for i, a in rows[r, :cap]:
+            if i >= 0:
+                out[int(i)] = float(a)
+    if strict:
+        if bad or any(np.isnan(out)):
+            raise RuntimeError(f"candidates {[i for i, a in enumerate(out) if np.isnan(a)]} were trained by no rank (failed ranks: {bad})")
+        return out
+    return out, bad
+
+
+def train_sharded(wanted: Sequence[int], owner: Sequence[int], cap: int, K: int, costs: Sequence[int], train_share, device=None):
+    """Run `train_share(indices) -> {index: accuracy}` on this rank's share and gather everyone's results (ONE collective when
+    nothing goes wrong).  A rank whose share raises — out of memory, a kernel error, a persistent-loop timeout — does not take the
+    job down with a hang in the collective: it reports the failure in the gather, and the candidates it could not deliver are
+    RE-QUEUED once over the ranks that did not fail (candidates are independent, /root/reference/models/search/ntu_searchable.py:38-94;
+    per-candidate seeds make the result independent of who trains it).  If the second attempt fails too, or every rank failed,
+    all ranks raise the same RuntimeError.  (A rank that DIES — killed, segfault — cannot be survived inside one process group:
+    torchrun tears the job down.)  Returns the K accuracies (entries outside `wanted` are 0)."""
+    rank, world = dist_info()
+    mine = [i for i, o in zip(wanted, owner) if o == rank]
+    if world == 1:
+        got = train_share(mine)
+        out = [0.0] * K
+        for i in mine:
+            out[i] = float(got[i])
+        return out
+    err, got = None, {}
+    try:
+        got = train_share(mine)
+    except Exception as e:      # noqa: BLE001 — reported through the collective, re-raised below if nobody can take over
+        err = e
+    have = [i for i in mine if i in got]
+    out, bad = gather_accuracies(have, [got[i] for i in have], K, device, cap=cap, failed=err is not None, strict=False)
+    missing = [i for i in wanted if np.isnan(out[i])]
+    if missing:
+        good = [r for r in range(world) if r not in bad]
+        if not good:
+            raise RuntimeError(f"every rank failed to train its share (this rank: {err!r})")
+        cost_of = dict(zip(wanted, costs))
+        own2 = assign([cost_of[i] for i in missing], len(good))
+        mine2 = [i for i, o in zip(missing, own2) if good[o] == rank]
+        cap2 = max([sum(1 for o in own2 if o == j) for j in range(len(good))] + [1])
+        err2, got2 = None, {}
+        if mine2:
+            try:
+                got2 = train_share(mine2)
+            except Exception as e:      # noqa: BLE001
+                err2 = e
+        have2 = [i for i in mine2 if i in got2]
+        out2, bad2 = gather_accuracies(have2, [got2[i] for i in have2], K, device, cap=cap2, failed=err2 is not None, strict=False)
+        for i in missing:
+            out[i] = out2[i]
+        still = [i for i in wanted if np.isnan(out[i])]
+        if still:
+            raise RuntimeError(f"candidates {still} could not be trained: rank(s) {bad} failed, and so did the re-queue on rank(s) {bad2} "
+                               f"(this rank's error: {(err2 or err)!r})")
+        if rank == 0:
+            import warnings
+            warnings.warn(f"mfas_amd: rank(s) {bad} failed to train {len(missing)} candidate(s); re-queued on rank(s) {good}")
+    return [0.0 if np.isnan(a) else a for a in out]
 
 
 # Step-time model of ONE rank's share (microseconds per lock-step train step), from the measured sweeps in DESIGN.md §5a
@@ -131,6 +191,232 @@ def shard(costs: Sequence[int], world: int, R: int | None = None):
     for o in owner:
         counts[o] += 1
     return owner, max(counts + [1])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same model, CALIBRATED on the device it runs on (round 4).  The constants above are what one MI355X box measured; another box
+# (or another device, CU count, geometry: B > 32 and C > 64 have no lean chain and therefore no resident schedule) would make
+# choose_ranks idle ranks for the wrong reasons.  StepModel measures a handful of short trainings (a few hundred train steps each)
+# of a canonical configuration of the call's geometry — the resident schedule at 1 / 8 / 16 / capacity candidates where
+# mfas_population_plan says it exists, the launch-per-phase schedule at three sizes beyond — once per geometry and process, on
+# rank 0, and broadcasts the numbers: every rank must take the same sharding decision.  A rank's share is then priced round by
+# round with the host's own round planner (split_rounds: the engine's layout query, nothing allocated).
+# ------------------------------------------------------------------------------------------------------------------
+def representative_conf(hp) -> np.ndarray:
+    """Canonical 4-cell configuration of a geometry: cell i takes tap i of each modality (cyclically over the declared taps).  For
+    the NTU widths its feature columns (7,552) equal the mean of uniformly sampled L=4 configurations."""
+    s_idx = [j for j, w in enumerate(hp.s_sizes) if w > 0] or [0]
+    v_idx = [j for j, w in enumerate(hp.v_sizes) if w > 0] or [0]
+    return np.array([[s_idx[i % len(s_idx)], v_idx[i % len(v_idx)], i % 2] for i in range(4)], np.int64)
+
+
+def split_rounds(hp, confs, device, chunk_cols: int = 0, min_candidates: int = 16):
+    """How a rank's share trains: ONE population, or several resident rounds one after the other when the share does not fit the
+    resident schedule as a whole (R <= 16: parameters in registers, <= ~28 conf-4-sized candidates) — every round but the last
+    filled to the resident capacity, found by bisection on the engine's own layout decision (mfas_population_plan, a pure query).
+    Returns [(positions into confs, resident?)].  Measured at R=16, B=20 on MI355X: 29..56 candidates take 38-55 us per train step
+    with launches, 36-41 us as two resident rounds; three or four rounds only pay when the last is >= 60 % full."""
+    import os
+    from .engine import plan_population
+    n = len(confs)
+    if n == 0:
+        return []
+
+    def resident(pos):
+        return bool(plan_population(hp, [confs[i] for i in pos], device, chunk_cols)["persistent"])
+
+    everything = list(range(n))
+    if hp.R > 16 or os.environ.get("MFAS_NO_ROUNDS"):
+        return [(everything, hp.R <= 16 and resident(everything))]
+    if resident(everything):
+        return [(everything, True)]
+    if n < min_candidates:
+        return [(everything, False)]
+    rounds, rest = [], everything
+    while rest and len(rounds) < 4:
+        if resident(rest):
+            rounds.append(rest)
+            rest = []
+            break
+        lo, hi, best = 1, len(rest) - 1, 0          # largest resident prefix of `rest`
+        while lo <= hi:
+            mid = (lo + hi) // 2
+            if resident(rest[:mid]):
+                best, lo = mid, mid + 1
+            else:
+                hi = mid - 1
+        if best == 0:
+            break
+        if not rounds:
+            nr = -(-len(rest) // best)
+            last = len(rest) - (nr - 1) * best
+            if nr > 4 or (nr >= 3 and last < 0.6 * best):
+                break
+        rounds.append(rest[:best])
+        rest = rest[best:]
+    if rest or not rounds:
+        return [(everything, False)]
+    return [(g, True) for g in rounds]
+
+
+def _interp(points, x):
+    """Piecewise-linear through sorted (x, y) points; flat below the first, the last segment's slope beyond the last."""
+    if not points:
+        return 0.0
+    if x <= points[0][0] or len(points) == 1:
+        return points[0][1]
+    for (x0, y0), (x1, y1) in zip(points, points[1:]):
+        if x <= x1:
+            return y0 + (y1 - y0) * (x - x0) / (x1 - x0)
+    (x0, y0), (x1, y1) = points[-2], points[-1]
+    return y1 + max(0.0, (y1 - y0) / (x1 - x0)) * (x - x1)
+
+
+class StepModel:
+    """Microseconds per lock-step train step of a share, measured on this device for one geometry."""
+
+    def __init__(self, hp, device, rep_cost: int, resident, stream, calibrated: bool):
+        self.hp, self.device, self.rep_cost = hp, device, rep_cost
+        self.resident = sorted(resident)        # [(candidates of the canonical size, us per step)] of the resident schedule
+        self.stream = sorted(stream)            # the same for launch-per-phase populations
+        self.calibrated = calibrated
+
+    def round_us(self, costs, is_resident: bool) -> float:
+        n_eq = float(sum(costs)) / float(self.rep_cost)       # the round in canonical candidates
+        if is_resident and self.resident:
+            return _interp(self.resident, n_eq)
+        return _interp(self.stream, n_eq)
+
+    def share_us(self, confs, costs) -> float:
+        if not len(confs):
+            return 0.0
+        if self.device is None:                 # no device to ask for layouts: price the share as one round
+            return self.round_us(costs, self.hp.R <= 16 and len(confs) <= (self.resident[-1][0] if self.resident else 0))
+        return sum(self.round_us([costs[i] for i in pos], res) for pos, res in split_rounds(self.hp, confs, self.device))
+
+    def describe(self):
+        return {"calibrated": self.calibrated, "resident_us": self.resident, "launch_per_phase_us": self.stream}
+
+
+_MODELS = {}
+
+
+def _measure_step_us(hp, conf, K, device) -> float:
+    """us per train step of K copies of `conf` trained in lockstep on `device` (difference of a long and a short run)."""
+    import time
+    from .engine import FeatureTable, Population
+    dtype = torch.bfloat16 if hp.tap_bits == 16 else torch.float32      # (a population sized for 16-bit staging refuses f32 tables)
+    T1, T2 = 40, 240
+    N = T2 * hp.B
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    taps = {f"s{j}": torch.rand(N, w, generator=g, device=device).to(dtype) for j, w in enumerate(hp.s_sizes) if w > 0}
+    taps.update({f"v{j}": torch.rand(N, w, generator=g, device=device).to(dtype) for j, w in enumerate(hp.v_sizes) if w > 0})
+    label = torch.randint(0, hp.C, (N,), generator=g, device=device).to(torch.int32)
+    ml = (torch.rand(N, hp.C, generator=g, device=device) < 0.2).float() if hp.loss_mode == 1 else None
+    table = FeatureTable(taps, label, multilabel=ml)
+    etas = np.full(T2, 1e-3)
+    pop = Population(hp, [conf] * K, device, drop_seeds=list(range(K)))
+    try:
+        pop.init(list(range(1, K + 1)))
+        best = {}
+        for T in (T1, T2, T1, T2):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            pop.train(table, None, 1, etas, max_steps=T)
+            best[T] = min(best.get(T, 1e30), time.perf_counter() - t0)
+    finally:
+        pop.close()
+    return max(1.0, (best[T2] - best[T1]) / (T2 - T1) * 1e6)
+
+
+def step_model(hp, device=None) -> StepModel:
+    """The step-time model of this geometry: calibrated on `device` (rank 0 measures, everyone receives the same numbers) when
+    there is one, else the shipped constants.  MFAS_NO_CALIBRATE=1 keeps the constants."""
+    import copy
+    import os
+    key = (hp.R, hp.C, hp.B, bool(hp.bn), bool(hp.alphas), hp.loss_mode, hp.tap_bits, tuple(hp.s_sizes), tuple(hp.v_sizes),
+           bool(hp.order_per_candidate), str(device))
+    if key in _MODELS:
+        return _MODELS[key]
+    rep = representative_conf(hp)
+    rep_cost = candidate_cost(rep, hp.R, hp.s_sizes, hp.v_sizes, hp.C)
+    rank, world = dist_info()
+    use_device = device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available() and not os.environ.get("MFAS_NO_CALIBRATE")
+    res_pts, str_pts, calibrated = [], [], False
+    NPT = 4
+    buf = np.zeros(1 + 4 * NPT, np.float64)
+    if use_device and rank == 0:
+        try:
+            from .engine import plan_population
+            hq = copy.copy(hp)
+            cap = 0
+            if hp.R <= 16:
+                lo, hi = 1, 96
+                while lo <= hi:
+                    mid = (lo + hi) // 2
+                    if plan_population(hq, [rep] * mid, device)["persistent"]:
+                        cap, lo = mid, mid + 1
+                    else:
+                        hi = mid - 1
+            rk = sorted({k for k in (1, 8, 16, cap) if 1 <= k <= cap})[-NPT:]
+            budget = int(1.5e9 // (12 * rep_cost))                     # bound the probe populations' memory
+            sk_all = (cap + 8, 2 * cap + 8, 4 * cap + 16) if cap else (1, 4, 16, 48)
+            sk = sorted({max(1, min(k, budget)) for k in sk_all})[:NPT]
+            res_pts = [(float(k), _measure_step_us(hq, rep, k, device)) for k in rk]
+            str_pts = [(float(k), _measure_step_us(hq, rep, k, device)) for k in sk]
+            buf[0] = 1.0
+            for j, (k, us) in enumerate(res_pts):
+                buf[1 + 2 * j], buf[2 + 2 * j] = k, us
+            for j, (k, us) in enumerate(str_pts):
+                buf[1 + 2 * NPT + 2 * j], buf[2 + 2 * NPT + 2 * j] = k, us
+        except Exception as e:          # the model is an optimisation: without it the call uses the shipped constants
+            import warnings
+            warnings.warn(f"mfas_amd: step-time calibration failed ({e!r}); using the shipped constants")
+            buf[:] = 0.0
+    if use_device and world > 1:
+        backend = dist.get_backend()
+        dev = torch.device("cpu") if backend == "gloo" else torch.device(device)
+        t = torch.from_numpy(buf).to(dev)
+        dist.broadcast(t, src=0)
+        buf = t.cpu().numpy()
+    if buf[0] == 1.0:
+        calibrated = True
+        res_pts = [(buf[1 + 2 * j], buf[2 + 2 * j]) for j in range(NPT) if buf[1 + 2 * j] > 0]
+        str_pts = [(buf[1 + 2 * NPT + 2 * j], buf[2 + 2 * NPT + 2 * j]) for j in range(NPT) if buf[1 + 2 * NPT + 2 * j] > 0]
+    else:                                # the constants of the box this repository was tuned on
+        if hp.R <= 16:
+            res_pts = [(1.0, RESIDENT_STEP_US[0][1])] + [(float(c), us) for c, us in RESIDENT_STEP_US]
+            str_pts = [(float(k), max(38.0, 12.0 + 24.0 * k * rep_cost / STREAM_BYTES_PER_US)) for k in (29, 64, 128)]
+        else:
+            str_pts = [(float(k), predicted_step_us([rep_cost] * k, hp.R)) for k in (1, 4, 16, 48)]
+    m = StepModel(hp, device if use_device else None, rep_cost, res_pts, str_pts, calibrated)
+    _MODELS[key] = m
+    return m
+
+
+def shard_call(confs, hp, world: int, device=None, all_ranks: bool = False):
+    """owner per candidate, the largest per-rank share, and the model used (None with all_ranks): what train_sampled_models shards
+    a call with.  Identical on every rank (the calibration is rank 0's, the layout queries are pure)."""
+    costs = [candidate_cost(c, hp.R, hp.s_sizes, hp.v_sizes, hp.C) for c in confs]
+    used, model = world, None
+    if world > 1 and not all_ranks and costs:
+        model = step_model(hp, device)
+        times = []
+        for w in range(1, world + 1):
+            owner = assign(costs, w)
+            t = 0.0
+            for r in range(w):
+                idx = [i for i, o in enumerate(owner) if o == r]
+                t = max(t, model.share_us([confs[i] for i in idx], [costs[i] for i in idx]))
+            times.append(t)
+        best = min(times)
+        used = next(w for w, t in enumerate(times, 1) if t <= best * 1.03)
+    owner = assign(costs, used)
+    counts = [0] * world
+    for o in owner:
+        counts[o] += 1
+    return owner, max(counts + [1]), model
 
 
 def conf_digest(confs) -> int:

@@ -1,0 +1,184 @@
+"""GPU tests of bench.py ITSELF (the driver's contract) and of the round-4 closures: the self-spawned N > 1 path, the search-sized
+workloads in the N = 1 line, the MM-IMDB-shaped workload, the AddressSanitizer build variant, the calibrated sharder model and
+mfas_population_backward on a handle that has trained before."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from oracle import np_oracle as O
+from tests.helpers import CONFS, engine_hyper
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = ["--epochs", "1", "--n-train", "320", "--n-dev", "160", "--no-cpu-baseline"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs a HIP device"
+    return torch.device("cuda:0")
+
+
+def run_bench(extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]            # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks(dev):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment — the way the driver invokes `--gpus 1` — starts two ranks
+    itself (gloo here: both on this box's one GPU; nccl = RCCL on a multi-GPU node), prints one line, and that line carries the
+    weak headline AND the strong-scaling workloads with per-rank seconds and shares."""
+    line = run_bench(["--gpus", "2", "--backend", "gloo", "--pop", "3", "--steps", "1", "--warmup", "1"] + TINY)
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "gloo"
+    assert line["scaling"] == "weak" and line["config"]["candidates_total_per_step"] == 6 and line["value"] > 0
+    assert len(line["config"]["rank_seconds"]) == 2
+    strong = line["config"]["strong"]
+    for name, K in (("c2", 16), ("c3", 50)):
+        s = strong[name]
+        assert s["candidates"] == K and sum(s["share"]) == K and len(s["rank_seconds"]) == 2 and s["cand_per_s"] > 0
+        assert 1 <= s["ranks_used"] <= 2 and s["step_time_model"]["calibrated"] is True      # the sharder's model was measured on THIS box
+        assert len(s["step_time_model"]["resident_us"]) >= 2 and all(us > 1.0 for _, us in s["step_time_model"]["resident_us"])
+    assert line["config"]["small_pop"] is None and "cpu_baseline" not in line
+
+
+def test_bench_failing_rank_gives_nonzero_exit(dev):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--backend", "nccl",
+                          "--pop", "2", "--steps", "1", "--warmup", "0"] + TINY, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0 and not [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert "GPUs" in res.stderr
+
+
+def test_bench_single_gpu_line_carries_the_search_sized_workloads(dev):
+    line = run_bench(["--pop", "4", "--steps", "1", "--warmup", "0"] + TINY)
+    assert line["n_gpus"] == 1 and line["metric"].startswith("candidate-archs trained/sec") and line["unit"] == "candidates/s"
+    assert line["config"]["engine_init"] == "torch" and line["config"]["other_init"]["engine_init"] == "device"
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-9
+    sp = line["config"]["small_pop"]
+    assert set(sp) == {"c2", "c3", "c1_single", "c1_pop6"}
+    assert sp["c2"]["candidates"] == 16 and sp["c2"]["schedule"]["persistent"] == 1 and sp["c2"]["populations_per_call"] == 1
+    assert sp["c3"]["candidates"] == 50 and sp["c3"]["populations_per_call"] == 2          # two resident rounds
+    for k in ("c2", "c3"):
+        assert sp[k]["cand_per_s"] > 0 and sp[k]["us_per_train_step_incl_dev_eval"] > 0 and 0 < sp[k]["frac_of_hbm_bound"] < 1.5
+    one = sp["c1_single"]
+    assert one["candidates"] == 1 and one["train_steps_per_s"] > 0 and one["kernel_us_per_train_step"] > 0 and one["schedule"]["groups"] == -1
+    assert sp["c1_pop6"]["candidates"] == 6
+
+
+def test_bench_mmimdb_shaped_workload(dev):
+    line = run_bench(["--workload", "c5", "--pop", "24", "--steps", "1", "--warmup", "1", "--epochs", "1", "--n-train", "400", "--n-dev", "200",
+                      "--no-cpu-baseline"])
+    assert "configs[4]" in line["config"]["workload"] and "MM-IMDB" in line["config"]["workload"]
+    assert line["config"]["candidates_total_per_step"] == 24 and 0.0 <= line["config"]["mean_best_dev_f1"] <= 1.0
+    assert line["roofline"]["achieved"] > 0 and line["config"]["hbm_bound_cand_per_s_per_gpu"] > 100
+
+
+def test_asan_build_trains_a_population(dev):
+    """The MFAS_ASAN=1 build variant (host-side AddressSanitizer of the C-ABI library) trains resident and launch-per-phase
+    populations, packs / unpacks parameters and runs the train-mode forward + backward without a report."""
+    import __graft_entry__ as ge
+    ge.build_asan()
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import mfas_amd as M
+from mfas_amd import _lib
+from oracle import np_oracle as O
+assert _lib.LIB_PATH.endswith("libmfas_hip_asan.so")
+dev = torch.device("cuda:0")
+tr = M.FeatureTable.synthetic(200, 1, dev, torch.bfloat16, snr=0.3)
+dv = M.FeatureTable.synthetic(96, 2, dev, torch.bfloat16, snr=0.3)
+rng = np.random.default_rng(1)
+for R, B, bn, K in ((16, 20, False, 5), (128, 16, True, 3), (32, 40, True, 2)):
+    hp = M.Hyper(R=R, B=B, bn=bn, drpt=0.5, tap_bits=16)
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in rng.integers(1, 5, K)]
+    pop = M.Population(hp, confs, dev, drop_seeds=list(range(K)))
+    pop.init(list(range(1, K + 1)))
+    nb = -(-200 // B)
+    stats, status = pop.train(tr, dv, 2, O.eta_sequence(1e-3, 1e-6, 1, 2, 200 / B, 2 * nb), snapshot_best=True)
+    assert not status.any() and np.isfinite(stats["train_loss_sum"]).all()
+    flat = pop.get_params(0)
+    pop.set_params(0, flat)
+    out = pop.forward_train(0, tr, 0, min(B, 16), step=1)
+    g = pop.backward(0, tr, torch.ones_like(out) * 0.01, 0, min(B, 16), step=1)
+    assert torch.isfinite(g).all() and torch.isfinite(out).all()
+    pop.close()
+print("ASAN-TRAIN-OK")
+""" % ROOT
+    res = subprocess.run([sys.executable, "-c", code], env=ge.asan_env(), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "ASAN-TRAIN-OK" in res.stdout, (res.stdout[-1500:], res.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in res.stderr, res.stderr[-4000:]
+
+
+def test_backward_on_a_handle_that_has_trained(dev):
+    """mfas_population_backward leaves the exact gradient in the first-moment slot whatever the handle did before: after training
+    (non-zero Adam moments) it equals the gradient a fresh population gives for the same parameters."""
+    import mfas_amd as M
+    conf = np.array(CONFS["l3"])
+    for R, B, bn in ((16, 20, False), (128, 16, True)):
+        ohp = O.Hyper(R=R, B=B, bn=bn, drpt=0.5)
+        t = O.synth_table(4 * B, 91, snr=0.4)
+        tab = M.FeatureTable.from_numpy(t, dev, torch.float32)
+        pop = M.Population(engine_hyper(ohp), [conf], dev, drop_seeds=[5])
+        pop.set_state_dict(0, O.init_params(conf, ohp, 17, perturb_bn=True))
+        pop.train(tab, None, 1, O.eta_sequence(1e-3, 1e-6, 1, 2, 4.0, 4), max_steps=4)
+        assert float(pop.get_params(0, plane=1).abs().max()) > 0           # the moments are live
+        flat = pop.get_params(0).clone()
+        rng = np.random.default_rng(5)
+        dlog = torch.from_numpy((rng.standard_normal((B, 60)) * 1e-3).astype(np.float32)).to(dev)    # small: would cancel against a stale m
+        got = pop.backward(0, tab, dlog, 0, B, step=9).clone()
+        after = pop.get_params(0)
+        fresh = M.Population(engine_hyper(ohp), [conf], dev, drop_seeds=[5])
+        fresh.set_params(0, flat)
+        want = fresh.backward(0, tab, dlog, 0, B, step=9)
+        assert torch.equal(got, want) and torch.isfinite(got).all() and float(got.abs().max()) > 0
+        layout, _ = M.engine.flat_layout(conf, engine_hyper(ohp))
+        keep = torch.ones_like(flat, dtype=torch.bool)
+        for key, shape, off in layout:
+            if "running" in key:
+                keep[off:off + int(np.prod(shape))] = False
+        assert torch.equal(after[keep], flat[keep])
+        pop.close(); fresh.close()
+
+
+def test_train_mode_forward_holds_no_population(dev):
+    """_TrainModeForward keeps no GPU population between forward and backward: a no_grad forward and a never-backpropagated
+    one leave nothing behind; taps that require grad are refused."""
+    import gc
+    import mfas_amd as M
+    from types import SimpleNamespace
+    args = SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=0.5, inner_representation_size=16, batchnorm=True, alphas=False,
+                           multitask=False, batchsize=16)
+    model = M.Searchable_Skeleton_Image_Net(args, np.array(CONFS["l2"]))
+    model.train(True)
+    t = O.synth_table(16, 3, snr=0.4)
+    x = {k: torch.from_numpy(v).to(dev) for k, v in t.items() if k != "label"}
+    rgb, ske = {k: v for k, v in x.items() if k[0] == "v"}, {k: v for k, v in x.items() if k[0] == "s"}
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        out = model((rgb, ske))
+    assert not out.requires_grad
+    out2 = model((rgb, ske))
+    assert out2.requires_grad and out2.grad_fn is not None
+    ctx = out2.grad_fn
+    assert not hasattr(ctx, "pop")
+    out2.sum().backward()
+    assert model.central_classifier.weight.grad is not None
+    del out, out2, ctx
+    gc.collect()
+    assert torch.cuda.memory_allocated() <= base + (1 << 20)
+    rgb_g = {k: v.clone().requires_grad_(True) for k, v in rgb.items()}
+    with pytest.raises(NotImplementedError):
+        model((rgb_g, ske))

@@ -193,8 +193,11 @@ confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0,
 torch.manual_seed(5)
 accs = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev)
 from mfas_amd import population as P
-costs = [P.candidate_cost(c, 16, M.engine.S_SIZES, M.engine.V_SIZES, 60) for c in confs]
-owner, _ = P.shard(costs, world, None if args.engine_all_ranks else 16)
+hp = M.Hyper.from_args(args)
+hp.multitask, hp.tap_bits = False, 16        # (what train_sampled_models derives for these tables: the same calibrated model)
+owner, _, model = P.shard_call(confs, hp, world, dev, args.engine_all_ranks)
+if model is not None:
+    print("MODEL", json.dumps(model.describe()), flush=True)
 print("RESULT", json.dumps(accs), flush=True)
 print("SHARE", json.dumps([owner.count(r) for r in range(world)]), "BACKEND", dist.get_backend() if world > 1 else "none", flush=True)
 if world > 1:
@@ -222,6 +225,9 @@ def test_population_sharding_two_ranks_matches_single(dev, tmp_path):
     # step is flat up to 8 resident candidates, mfas_amd/population.py) -> the call uses ONE rank, the other only joins the gather
     lazy, shares = _run_dist(script, 2, MFAS_TEST_ALL_RANKS="0")
     assert lazy[0] == lazy[1] == single and shares[0][0] == [7, 0]
+    # a rank whose share fails (hook: rank 1's first attempt raises) is re-queued on the other one — same accuracies, nobody hangs
+    requeued, _ = _run_dist(script, 2, MFAS_TEST_FAIL_RANK="1")
+    assert requeued[0] == requeued[1] == single
 
 
 def _run_dist(script, world, **extra):

@@ -259,3 +259,152 @@ def test_population_gather_gloo(tmp_path, world):
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
         assert b"ok" in out
+
+
+def test_initial_flat_params_private_generator_and_threads():
+    """A private torch.Generator seeded like the global stream yields the module's numbers, and the threaded initialiser of
+    train_sampled_models hands them out in candidate order."""
+    from mfas_amd import ntu_searchable as NS
+    args = mkargs(inner_representation_size=32, alphas=True)
+    rng = np.random.default_rng(3)
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in (1, 4, 2, 3, 4, 1)]
+    want = []
+    for i, c in enumerate(confs):
+        torch.manual_seed(900 + 2 + i)
+        want.append(NS.Searchable_Skeleton_Image_Net(args, c).flat_params())
+    before = torch.get_rng_state()
+    got = list(NS._initial_params_threaded(args, confs, list(range(len(confs))), None, 900, NS.Searchable_Skeleton_Image_Net, [], {}))
+    assert torch.equal(before, torch.get_rng_state())          # the global stream is not consumed
+    assert [i for i, _ in got] == list(range(len(confs)))
+    for (i, f), w in zip(got, want):
+        assert torch.equal(f, w), i
+    mods = {}
+    got_m = list(NS._initial_params_threaded(args, confs, [1, 3], None, 900, NS.Searchable_Skeleton_Image_Net, [1, 3], mods))
+    assert torch.equal(got_m[0][1], want[1]) and torch.equal(got_m[1][1], want[3]) and set(mods) == {1, 3}
+
+
+def test_round_planner_and_shard_call_without_a_device():
+    """population.split_rounds asks the engine's layout query (a pure host function: it works without a GPU and assumes the
+    MI355X's 256 CUs then); shard_call prices shares with the shipped constants when there is no device to calibrate on."""
+    from mfas_amd import Hyper
+    from mfas_amd import population as P
+    hp = Hyper(R=16, B=20, tap_bits=16)
+    c4 = np.array(CONFS["c4"])
+    assert [(len(p), r) for p, r in P.split_rounds(hp, [c4] * 6, "cuda:0")] == [(6, True)]
+    assert [(len(p), r) for p, r in P.split_rounds(hp, [c4] * 28, "cuda:0")] == [(28, True)]
+    r50 = P.split_rounds(hp, [c4] * 50, "cuda:0")
+    assert [(len(p), r) for p, r in r50] == [(28, True), (22, True)] and sorted(sum((p for p, _ in r50), [])) == list(range(50))
+    assert [(len(p), r) for p, r in P.split_rounds(hp, [c4] * 64, "cuda:0")] == [(64, False)]       # 28 + 28 + 8: the third round too empty
+    hp128 = Hyper(R=128, B=16, bn=True, tap_bits=16)
+    assert [(len(p), r) for p, r in P.split_rounds(hp128, [c4] * 6, "cuda:0")] == [(6, False)]
+    hpb = Hyper(R=16, B=48, tap_bits=16)              # B > 32: no lean chain, no resident schedule
+    assert [(len(p), r) for p, r in P.split_rounds(hpb, [c4] * 6, "cuda:0")] == [(6, False)]
+    rep = P.representative_conf(hp)
+    assert sum(O.S_SIZES[s] + O.V_SIZES[v] for s, v, _ in rep) == 7552
+    for K, world, want_used in ((6, 8, 1), (16, 2, 2), (1024, 8, 8)):
+        h = hp if K < 100 else hp128
+        owner, cap, model = P.shard_call([c4] * K, h, world, None, False)
+        assert not model.calibrated and sorted(set(owner)) == list(range(want_used)), (K, world, sorted(set(owner)))
+        assert cap == max(owner.count(r) for r in range(world)) and len(owner) == K
+    owner, cap, model = P.shard_call([c4] * 6, hp, 8, None, True)           # engine_all_ranks
+    assert model is None and sorted(set(owner)) == list(range(6))
+    assert P.shard_call([], hp, 4, None, False)[:2] == ([], 1)
+    assert abs(P._interp([(1.0, 10.0), (3.0, 20.0)], 2.0) - 15.0) < 1e-12 and P._interp([(1.0, 10.0), (3.0, 20.0)], 5.0) == 30.0
+    assert P._interp([(1.0, 10.0), (3.0, 20.0)], 0.5) == 10.0
+
+
+def test_asan_build_variant_runs_the_host_side_queries():
+    """MFAS_ASAN=1 build variant (host-side AddressSanitizer of the C-ABI library): builds, loads under LD_PRELOAD of the sanitizer
+    runtime, and the layout planner + input validation run clean.  (The GPU suite trains a population with it.)"""
+    import __graft_entry__ as ge
+    ge.build_asan()
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from mfas_amd import Hyper, _lib
+from mfas_amd.engine import plan_population
+assert _lib.LIB_PATH.endswith("libmfas_hip_asan.so")
+c4 = np.array([[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]])
+rng = np.random.default_rng(0)
+for R, B in ((16, 20), (16, 16), (128, 16), (32, 40), (200, 64)):
+    hp = Hyper(R=R, B=B, bn=True, tap_bits=16)
+    for K in (1, 7, 28, 29, 130):
+        confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in rng.integers(1, 5, K)]
+        p = plan_population(hp, confs, "cuda:0")
+        assert p["candidates"] == K
+for bad in ([[9, 1, 1]], [[0, 0, 3]], [[0, 8, 0]]):
+    try:
+        plan_population(Hyper(R=16), [np.array(bad)], "cuda:0")
+        raise SystemExit("accepted " + repr(bad))
+    except RuntimeError:
+        pass
+_lib.lib().mfas_range_push(b"x"); _lib.lib().mfas_range_pop()
+print("ASAN-OK", _lib.lib().mfas_source_digest().decode())
+""" % ROOT
+    res = subprocess.run([sys.executable, "-c", code], env=ge.asan_env(), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ASAN-OK mfas-src-digest:" + ge.source_digest() in res.stdout, (res.stdout[-1500:], res.stderr[-3000:])
+    assert "AddressSanitizer" not in res.stderr, res.stderr[-3000:]
+
+
+REQUEUE_WORKER = r"""
+import os, sys, warnings
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from mfas_amd import population as P
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = P.dist_info()
+K = 9
+wanted = [0, 1, 2, 3, 5, 6, 7, 8]          # (candidate 4 not wanted: return_model-style subset)
+costs = [100, 30, 70, 10, 50, 20, 60, 40]
+owner, cap = P.shard(costs, world)
+calls = []
+def share(fail_first_on, always_fail=False):
+    def f(idx):
+        calls.append(list(idx))
+        if always_fail or (rank == fail_first_on and len(calls) == 1):
+            raise RuntimeError("boom")
+        return {{i: 0.01 * (i + 1) for i in idx}}
+    return f
+want = [0.01 * (i + 1) if i in wanted else 0.0 for i in range(K)]
+# 1. nobody fails: one gather
+calls.clear()
+out = P.train_sharded(wanted, owner, cap, K, costs, share(-1))
+assert np.allclose(out, want) and len(calls) == 1, (out, calls)
+# 2. rank 1's share fails: its candidates are re-queued on rank 0, everybody gets every accuracy
+calls.clear()
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    out = P.train_sharded(wanted, owner, cap, K, costs, share(1))
+assert np.allclose(out, want), out
+lost = [i for i, o in zip(wanted, owner) if o == 1]
+if rank == 0:
+    assert len(calls) == 2 and sorted(calls[1]) == sorted(lost), calls
+    assert any("re-queued" in str(x.message) for x in w)
+else:
+    assert len(calls) == 1
+# 3. every rank fails: everybody raises, nobody hangs
+calls.clear()
+try:
+    P.train_sharded(wanted, owner, cap, K, costs, share(-1, always_fail=True))
+    raised = False
+except RuntimeError as e:
+    raised = "every rank failed" in str(e)
+assert raised
+print("rank", rank, "requeue ok", flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_failed_rank_is_requeued_gloo(tmp_path):
+    """population.train_sharded: a rank whose share raises reports it through the collective; its candidates are trained by the
+    ranks that did not fail (failure detection / re-queue; candidates are independent, ntu_searchable.py:38-94)."""
+    script = tmp_path / "worker.py"
+    script.write_text(REQUEUE_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
+        assert b"requeue ok" in out
