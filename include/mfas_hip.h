@@ -116,6 +116,17 @@ int mfas_population_get_params(mfas_population* pop, int32_t k, int32_t plane, f
  * alpha = 0.1*noise) from the hash generator documented in oracle/np_oracle.py:init_params. */
 int mfas_population_init(mfas_population* pop, const uint32_t* seeds /* K, host */);
 
+/* (new, round 4) The reference's OWN initial parameters, drawn on the device: what `searchable_type(args, conf)` — the model
+ * construction at ntu_searchable.py:44 (nn.Linear.reset_parameters per cell and for the classifier, then alpha ~ N(mean, std),
+ * ntu_searchable.py:202-204) — draws from torch's CPU generator after torch.manual_seed(seeds[k]): at::mt19937 and
+ * uniform_real_distribution<float> run per candidate on the GPU, bit for bit the numbers of the host path (the Python mirror checks
+ * that once per process against torch itself and falls back to mfas_population_set_params otherwise).
+ * seeds: HOST uint64[K].  bounds: HOST float[K][2 * (MFAS_MAX_CELLS + 1)] = per cell {weight bound, bias bound} (unused cells: any),
+ * then the classifier's {weight bound, bias bound}: Tensor.uniform_(-bound, bound).  BatchNorm starts at its defaults; Adam state
+ * is zeroed (as mfas_population_set_params does). */
+int mfas_population_init_torch_streams(mfas_population* pop, const uint64_t* seeds, const float* bounds, double alpha_mean,
+                                       double alpha_std);
+
 /* Replaces train_ntu_track_acc (train_searchable/ntu.py:14-89) for the whole population in lockstep:
  * for each epoch: train over `train` in the given sample order (order: device int32 [epochs][N_train],
  * NULL = sequential), then evaluate `dev`.  step_scalars: HOST float2 per train step

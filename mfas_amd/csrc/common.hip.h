@@ -49,6 +49,9 @@ struct SegDesc {          // one workgroup of k_sweep / k_pack
     float init_bound;
     int32_t rb0, seg_nrb; // row-split units: first row block of this unit inside the segment, row blocks of the whole segment
                           // (rows_p = rows of THIS unit; w_off already points at row block rb0 of the chunk)
+    int32_t nsub, _pad3;  // sweep work list only: this workgroup streams `nsub` consecutive column chunks of the segment (chunks
+                          // k0, k0 + cc, ...; their tiles are consecutive in memory) and keeps the forward partial sums in registers
+                          // across them: ONE partial slab per unit instead of one per chunk (0 / 1: a single chunk)
 };
 
 #define TAP_MAX_ITEMS 8

@@ -64,6 +64,8 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
         else chain_body<MB, false>(a.ca, chain_step_of(a.ca), bid, lds);
     }
     else if (bid < a.nchain + a.sa.ntap) sweep_tap_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain, lds);
+    else if (!LEAN && a.sa.desc[bid - a.nchain - a.sa.ntap].nsub > 1)      // multi-chunk feature unit (general chain, 8 row blocks)
+        sweep_multi_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, sweep_step_of(a.sa), bid - a.nchain - a.sa.ntap, lds);
     else sweep_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, sweep_step_of(a.sa), bid - a.nchain - a.sa.ntap, lds);
 }
 
@@ -113,6 +115,8 @@ struct mfas_population {
     int64_t plane_stride = 0, wt_size = 0, step_total = 0;
     CandDev* d_cands = nullptr;
     SegDesc* d_descs = nullptr;
+    SegDesc* d_mdescs = nullptr;         // the same units as the sweep streams them (multi-chunk units merged), candidate-major
+    std::vector<int> mdesc_start;        // K+1
     struct Group { int c0 = 0, nc = 0, ndesc = 0, ntap = 0; SegDesc* d_descs = nullptr; TapDesc* d_taps = nullptr;
                    double alg_state = 0, alg_feat = 0; };
     std::vector<Group> groups;           // 1 or 2 contiguous candidate ranges, each with its own sweep work list
@@ -225,6 +229,8 @@ struct LayoutPlan {
     bool res_ok = false, res_wide = false, lean_ok = false;
     int nres_wg = 0;
     bool resident = false;           // the resident persistent schedule runs (before the byte-size limits, which no resident population reaches)
+    int group = 1;                   // consecutive column chunks one sweep workgroup streams (SegDesc::nsub): ONE forward partial slab per group
+    int group_skip = 0;              // (experiment, MFAS_SUBCHUNK_SKIP=n) every n-th candidate keeps one-chunk units: a fine-grained tail for the work list
 };
 
 static size_t plan_res_lds(const mfas_hyper* hp, const Geo& g, int cc, int nu) {
@@ -307,6 +313,19 @@ static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs
         lp.target = target;
     }
     lp.target = std::max(16, (lp.target / 16) * 16);
+    // Multi-chunk units (round 4): where the planner streams 64-column chunks (R >= 128, >= 28 candidates: the finest, best-balanced
+    // walk of W / m / v) a workgroup takes `group` consecutive chunks and keeps the forward partial sums in registers across them —
+    // the memory walk stays that of 64-column chunks, the partial slabs (8 KB written by the unit and read back by the chain, per
+    // chunk: 8 % of the algorithmic bytes of a conf-4 step at R = 128) and the dy staging shrink by the group factor.  A caller who
+    // fixes chunk_cols gets exactly that decomposition (group 1).
+    lp.group = 1;
+    // (exactly 8 row blocks: wave = row block, one accumulator per wave; K >= 28: neither the same-group launch nor reduce-in-sweep)
+    // (measured, profiles/r04_subchunks.log: uniform groups of 2 / 4 / 8 / 16 chunks are SLOWER — 314 / 320 / 327 / 327 us per launch
+    //  against 299 on the same box — because 4x larger units leave ~4 units per workgroup slot and the launch's tail grows faster
+    //  than the slab traffic shrinks: the default stays one chunk per unit, MFAS_SUBCHUNKS / MFAS_SUBCHUNK_SKIP select the other forms)
+    if (const char* e = getenv("MFAS_SUBCHUNKS"))
+        if (g.nrb == STEP_NW && K >= 28 && !lp.plan_res) lp.group = std::max(1, std::min(64, atoi(e)));
+    if (const char* e = getenv("MFAS_SUBCHUNK_SKIP")) lp.group_skip = atoi(e);
     {
         int mx = 0;
         lp.nfeat = (int)feat_units(lp.target, &mx);
@@ -346,6 +365,25 @@ static int validate_inputs(const mfas_hyper* hp, const int32_t* confs, const int
         }
     }
     return MFAS_OK;
+}
+
+// The sweep's work list: consecutive chunk descriptors of one feature segment that share a partial slab (part_idx) become ONE
+// unit that streams them one after the other (SegDesc::nsub); k_pack / the resident schedule keep the per-chunk descriptors.
+static std::vector<SegDesc> merge_units(const std::vector<SegDesc>& in) {
+    std::vector<SegDesc> out;
+    for (const SegDesc& d : in) {
+        if (!out.empty()) {
+            SegDesc& b = out.back();
+            if (d.kind <= KIND_V && b.kind == d.kind && b.cand == d.cand && b.cell == d.cell && b.part_idx == d.part_idx && b.cc == d.cc &&
+                b.k0 + b.nsub * b.cc == d.k0 && b.w_off + (int64_t)b.nsub * b.rows_p * b.cc == d.w_off) {
+                b.nsub++;
+                continue;
+            }
+        }
+        out.push_back(d);
+        if (out.back().nsub < 1) out.back().nsub = 1;
+    }
+    return out;
 }
 
 #define MFAS_RETRY_NO_PERSIST 12345   // internal: the layout was planned for the resident persistent schedule, which then did not fit
@@ -445,11 +483,13 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                 const int cols_p = widths[j];
                 const int cc = j < 2 ? pick_chunk(cols_p, target) : cols_p;
                 const int nch = cols_p / cc;
+                const int grp = (j < 2 && (lp.group_skip <= 0 || (k % lp.group_skip) != lp.group_skip - 1)) ? lp.group : 1;   // chunks per sweep unit = per partial slab
+                const int nun = (nch + grp - 1) / grp;
                 c.seg_off[i][j] = plane_off;
                 c.seg_cc[i][j] = cc;
                 c.seg_cols[i][j] = cols_p;
-                if (j == 0) c.nch_s[i] = nch;
-                if (j == 1) c.nch_v[i] = nch;
+                if (j == 0) c.nch_s[i] = nun;
+                if (j == 1) c.nch_v[i] = nun;
                 if (j == 2) { c.outT_off[i] = wt_off; }
                 for (int ch = 0; ch < nch; ++ch) {
                     SegDesc d;
@@ -458,14 +498,15 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                     d.k0 = ch * cc; d.cc = cc; d.rows_p = g.Rp; d.width = j < 2 ? widths[j] : g.Rp;
                     d.w_off = plane_off + (int64_t)ch * g.Rp * cc;
                     d.wt_off = j == 2 ? wt_off : -1;
-                    d.part_idx = j < 2 ? (j == 0 ? ch : c.nch_s[i] + ch) : 0;
+                    d.part_idx = j < 2 ? (j == 0 ? ch / grp : c.nch_s[i] + ch / grp) : 0;
+                    d.nsub = 1;
                     d.rows = hp->R; d.cols = true_w[j];
                     d.src_off = c.f_W[i]; d.src_ld = Kin; d.src_col0 = col0[j];
                     d.init_seed = 2 * i; d.init_bound = bound;
                     d.rb0 = 0; d.seg_nrb = g.nrb;
                     p->descs.push_back(d);
                 }
-                if (j < 2) pslot += nch;
+                if (j < 2) pslot += nun;
                 plane_off += (int64_t)g.Rp * cols_p;
                 if (j == 2) wt_off += (int64_t)g.Rp * g.Rp;
                 alg_bytes += 24.0 * hp->R * true_w[j];
@@ -486,7 +527,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             d.rows = hp->C; d.cols = hp->R;
             d.src_off = c.f_Wc; d.src_ld = hp->R; d.src_col0 = 0;
             d.init_seed = 10; d.init_bound = (float)(1.0 / sqrt((double)hp->R));
-            d.rb0 = 0; d.seg_nrb = g.ncb;
+            d.rb0 = 0; d.seg_nrb = g.ncb; d.nsub = 1;
             p->descs.push_back(d);
             plane_off += (int64_t)g.Cp * g.Rp;
             wt_off += (int64_t)g.Cp * g.Rp;
@@ -601,6 +642,19 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     }
     CREATE_CHK(hipMemcpy(p->d_cands, p->cands.data(), sizeof(CandDev) * K, hipMemcpyHostToDevice));
     CREATE_CHK(hipMemcpy(p->d_descs, p->descs.data(), sizeof(SegDesc) * p->descs.size(), hipMemcpyHostToDevice));
+    {
+        std::vector<SegDesc> merged;
+        p->mdesc_start.assign(K + 1, 0);
+        for (int k = 0; k < K; ++k) {
+            p->mdesc_start[k] = (int)merged.size();
+            std::vector<SegDesc> one(p->descs.begin() + p->desc_start[k], p->descs.begin() + p->desc_start[k + 1]);
+            if (lp.group > 1) one = merge_units(one);
+            merged.insert(merged.end(), one.begin(), one.end());
+        }
+        p->mdesc_start[K] = (int)merged.size();
+        CREATE_CHK(hipMalloc(&p->d_mdescs, sizeof(SegDesc) * merged.size()));
+        CREATE_CHK(hipMemcpy(p->d_mdescs, merged.data(), sizeof(SegDesc) * merged.size(), hipMemcpyHostToDevice));
+    }
     {   // candidate groups: two halves balanced by work (descriptor columns), contiguous ranges
         // Two groups (the chain of one runs under the sweep of the other).  Measured on MI355X (cand/s, unfused vs fused):
         // general chain, R=128: 16 candidates 104 vs 96, 20: 103 vs 110, 32: 119 vs 142 -> fused from 20;
@@ -629,7 +683,8 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             double state_bytes = 0;
             for (const SegDesc& d : p->descs) state_bytes += 24.0 * d.cc * d.rows_p;
             const bool two_forced = getenv("MFAS_GROUPS") && atoi(getenv("MFAS_GROUPS")) >= 2;      // (tests: the two-group fused schedule)
-            p->same_group = !p->persist && !p->lean_chain && g.MB <= 2 && (state_bytes <= 260e6 || sgenv == 2) && sgenv != 0 && !two_forced;
+            p->same_group = !p->persist && !p->lean_chain && g.MB <= 2 && (state_bytes <= 260e6 || sgenv == 2) && sgenv != 0 && !two_forced &&
+                            lp.group == 1;      // (multi-chunk units exist in k_step's sweep only)
         }
         if (p->same_group) ngroups = 1;
         int split = K;
@@ -652,6 +707,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                 gr.alg_state += 24.0 * d.rows * std::max(0, std::min(d.cc, d.cols - d.k0));
                 if (d.kind <= KIND_V) gr.alg_feat += (double)hp->B * d.cc;
             }
+            if (lp.group > 1) all = merge_units(all);
             // small R (1, 2 or 4 row blocks): feature segments are regrouped tap-major (sweep_tap_body)
             std::vector<SegDesc> sorted;
             std::vector<TapDesc> taps;
@@ -689,7 +745,8 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             } else {
                 sorted = all;
             }
-            std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) { return x.cc * x.rows_p > y.cc * y.rows_p; });
+            std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) {
+                return (int64_t)x.cc * x.rows_p * std::max(1, x.nsub) > (int64_t)y.cc * y.rows_p * std::max(1, y.nsub); });
             if (p->same_group)   // the order the chain releases the units in
                 std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) {
                     // (the slot each unit waits for: feature units of cell i -> i, OUT_i -> i - 1, HEAD -> the last cell; highest slot first)
@@ -810,7 +867,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     for (hipEvent_t e : p->ev) hipEventDestroy(e);
     hipFree(p->plane); hipFree(p->wt); hipFree(p->stepbuf); hipFree(p->best);
     for (auto& gr : p->groups) { hipFree(gr.d_descs); hipFree(gr.d_taps); }
-    hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_stats); hipFree(p->d_status);
+    hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_mdescs); hipFree(p->d_stats); hipFree(p->d_status);
     hipFree(p->d_seeds); hipFree(p->d_corr); hipFree(p->d_posw);
     hipFree(p->d_red_cnt);
     hipFree(p->d_cellflag);
@@ -866,6 +923,105 @@ extern "C" int mfas_population_init(mfas_population* p, const uint32_t* seeds) {
     hipLaunchKernelGGL(k_vec, dim3(p->K), dim3(256), 0, p->stream, a, -1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->stream));   // seeds is a host buffer
+    return MFAS_OK;
+}
+
+// torch.manual_seed(seeds[k]) + the module's construction draws for every candidate, on the device (k_mt_uniform, pack.hip.h).
+// bounds: per candidate 2 * (MFAS_MAX_CELLS + 1) floats — per cell {weight bound, bias bound}, then the classifier's — as the host
+// computed them (kaiming_uniform_(a = sqrt 5) / 1 / sqrt(fan_in), nn.Linear.reset_parameters); alphas ~ N(alpha_mean, alpha_std)
+// drawn LAST like Searchable_Skeleton_Image_Net.__init__ does (ntu_searchable.py:202-204), from the stream's next raw outputs with
+// at::normal_distribution<double>'s arithmetic (Box-Muller: r = sqrt(-2 log1p(-u2)), theta = 2 pi u1; the sine sample is cached
+// for the next draw) in host double precision / libm, exactly what torch's CPU path evaluates.
+extern "C" int mfas_population_init_torch_streams(mfas_population* p, const uint64_t* seeds, const float* bounds, double alpha_mean,
+                                                  double alpha_std) {
+    if (!p || !seeds || !bounds) return fail(MFAS_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(p->device));
+    const int K = p->K, R = p->hp.R, C = p->hp.C, NB = 2 * (MFAS_MAX_CELLS + 1);
+    int64_t maxp = 0;
+    for (int k = 0; k < K; ++k) maxp = std::max(maxp, p->nparams[k]);
+    const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(K, (64LL << 20) / std::max<int64_t>(maxp, 1)));     // <= 256 MB of flat scratch
+    float* flat = nullptr;
+    MtCand* d_mt = nullptr;
+    uint32_t* d_tail = nullptr;
+    auto cleanup = [&]() { hipFree(flat); hipFree(d_mt); hipFree(d_tail); };
+    hipError_t e = hipMalloc(&flat, sizeof(float) * (size_t)maxp * batch);
+    if (e == hipSuccess) e = hipMalloc(&d_mt, sizeof(MtCand) * batch);
+    if (e == hipSuccess) e = hipMalloc(&d_tail, sizeof(uint32_t) * MT_TAIL * batch);
+    if (e != hipSuccess) { cleanup(); return fail(MFAS_ENOMEM, std::string("init_torch_streams: ") + hipGetErrorString(e)); }
+    std::vector<MtCand> mt(batch);
+    std::vector<uint32_t> tails((size_t)MT_TAIL * batch);
+    std::vector<float> alpha((size_t)MFAS_MAX_CELLS * batch);
+    for (int k0 = 0; k0 < K && e == hipSuccess; k0 += batch) {
+        const int nb = std::min(batch, K - k0);
+        for (int j = 0; j < nb; ++j) {
+            const int k = k0 + j;
+            const CandDev& c = p->cands[k];
+            MtCand& m = mt[j];
+            memset(&m, 0, sizeof(m));
+            m.seed = (uint32_t)(seeds[k] & 0xffffffffULL);
+            m.flat_off = (int64_t)j * maxp;
+            int64_t pos = 0;
+            auto seg = [&](int64_t dst, int64_t n, float b) {
+                m.start[m.nseg] = pos; m.dst[m.nseg] = dst; m.lo[m.nseg] = -b; m.hi[m.nseg] = b;
+                pos += n; ++m.nseg;
+            };
+            for (int i = 0; i < c.L; ++i) {
+                seg(c.f_W[i], (int64_t)R * c.K_in[i], bounds[k * NB + 2 * i]);
+                seg(c.f_b[i], R, bounds[k * NB + 2 * i + 1]);
+            }
+            seg(c.f_Wc, (int64_t)C * R, bounds[k * NB + 2 * MFAS_MAX_CELLS]);
+            seg(c.f_bc, C, bounds[k * NB + 2 * MFAS_MAX_CELLS + 1]);
+            m.start[m.nseg] = pos;
+            m.total = pos;
+        }
+        e = hipMemcpyAsync(d_mt, mt.data(), sizeof(MtCand) * nb, hipMemcpyHostToDevice, p->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(flat, 0, sizeof(float) * (size_t)maxp * nb, p->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_mt_uniform, dim3(nb), dim3(256), 0, p->stream, d_mt, flat, d_tail);
+        e = hipMemcpyAsync(tails.data(), d_tail, sizeof(uint32_t) * MT_TAIL * nb, hipMemcpyDeviceToHost, p->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        if (e != hipSuccess) break;
+        for (int j = 0; j < nb && e == hipSuccess; ++j) {
+            const int k = k0 + j;
+            const CandDev& c = p->cands[k];
+            // BatchNorm defaults (gamma = 1, running_var = 1) and the alphas, then the usual repacking of a flat vector
+            const uint32_t* t = tails.data() + (size_t)j * MT_TAIL;
+            int used = 0;
+            bool cached = false;
+            double cache = 0.0;
+            auto u53 = [&]() {      // uniform_real_distribution<double>: random64() = (first << 32) | second, 53 bits
+                const uint64_t hi = t[used], lo = t[used + 1];
+                used += 2;
+                return (double)(((hi << 32) | lo) & ((1ULL << 53) - 1)) * (1.0 / 9007199254740992.0);
+            };
+            for (int i = 0; i < c.L; ++i) {
+                double z;
+                if (cached) { z = cache; cached = false; }
+                else {
+                    const double u1 = u53(), u2 = u53();
+                    const double r = ::sqrt(-2.0 * ::log1p(-u2)), theta = 2.0 * 3.14159265358979323846 * u1;
+                    cache = r * ::sin(theta);
+                    cached = true;
+                    z = r * ::cos(theta);
+                }
+                alpha[(size_t)j * MFAS_MAX_CELLS + i] = (float)(z * alpha_std + alpha_mean);
+            }
+            float* fk = flat + (int64_t)j * maxp;
+            e = hipMemcpyAsync(fk + c.f_alpha, alpha.data() + (size_t)j * MFAS_MAX_CELLS, sizeof(float) * c.L, hipMemcpyHostToDevice, p->stream);
+            if (e != hipSuccess) break;
+            if (p->hp.bn) {
+                for (int i = 0; i < c.L && e == hipSuccess; ++i) {
+                    hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, p->stream, fk + c.f_bn[i], 1.0f, (int64_t)R);             // gamma
+                    hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, p->stream, fk + c.f_bn[i] + 3 * (int64_t)R, 1.0f, (int64_t)R);   // running_var
+                }
+            }
+            const int rc = mfas_population_set_params(p, k, fk);
+            if (rc) { cleanup(); return rc; }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);       // the scratch is reused by the next batch
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(MFAS_EHIP, std::string("init_torch_streams: ") + hipGetErrorString(e));
     return MFAS_OK;
 }
 
@@ -1379,13 +1535,13 @@ static int single_batch(mfas_population* p, int32_t k, const mfas_table* tab, in
     memset(&st, 0, sizeof(st));
     st.sa.cands = p->d_cands; st.sa.plane = p->plane; st.sa.plane_stride = p->plane_stride; st.sa.wt = p->wt;
     st.sa.stepbuf = p->stepbuf; st.sa.tab = *tab; st.sa.order = nullptr; st.sa.g = g; st.sa.g.order_stride = 0;
-    st.sa.desc = p->d_descs + p->desc_start[k]; st.sa.tdesc = nullptr; st.sa.ntap = 0;
+    st.sa.desc = p->d_mdescs + p->mdesc_start[k]; st.sa.tdesc = nullptr; st.sa.ntap = 0;
     st.sa.do_update = 0; st.sa.do_forward = 1;
     st.sa.pos_n = row0; st.sa.base_n = (int)row0; st.sa.nvalid_n = nrows;
     st.sa.pos_t = row0; st.sa.base_t = (int)row0; st.sa.nvalid_t = nrows;
     st.sa.ac = ac;
     st.nchain = 0;
-    const unsigned nsw = (unsigned)(p->desc_start[k + 1] - p->desc_start[k]);
+    const unsigned nsw = (unsigned)(p->mdesc_start[k + 1] - p->mdesc_start[k]);
     size_t lds_need = p->lds_step;   // (a population laid out for resident units budgets its streaming LDS without them)
     for (int j = p->desc_start[k]; j < p->desc_start[k + 1]; ++j) {
         const SegDesc& d = p->descs[j];

@@ -145,6 +145,86 @@ __global__ void __launch_bounds__(256) k_vec(const PackArgs a, int cand_fixed) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_mt_uniform — torch's CPU random stream on the device (round 4).  The reference builds every candidate from torch's global
+// generator (ntu_searchable.py:44: searchable_type(args, conf) -> nn.Linear.reset_parameters: kaiming_uniform_(a = sqrt 5) on the
+// weight, U(+-1/sqrt(fan_in)) on the bias, both Tensor.uniform_(lo, hi)); train_sampled_models' default initialisation reproduces
+// those draws per candidate under torch.manual_seed(seed_base + 2 + i).  On the host that is 1 M serial Mersenne-Twister draws per
+// R = 128 candidate (0.7-1 ms; 3 % of the headline call, 20 % of a 50-candidate search call at R = 16).  Here one workgroup per
+// candidate runs at::mt19937 itself — seeding (init_with_uint32), the 624-word twist in three dependent phases through LDS, the
+// tempering — and at::uniform_real_distribution<float>: x = (y & (2^24 - 1)) * 2^-24, then x * (hi - lo) + lo, which torch's
+// AVX2 / AVX512 CPU kernels evaluate as ONE fused multiply-add (verified against torch on the host at first use,
+// mfas_amd/ntu_searchable.py; a mismatch falls back to the host path).  The values land in the candidate's FLAT parameter vector
+// (reference state_dict order), from which k_pack / k_vec lay them out like any set_params call; the next 64 raw outputs of each
+// stream go back to the host, which draws the alpha parameters from them (normal_distribution<double>, libm — mfas_hip.hip).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fill(float* p, float v, int64_t n) {
+    for (int64_t i = threadIdx.x; i < n; i += 256) p[i] = v;
+}
+
+#define MT_MAX_SEG 12
+struct MtCand {
+    uint32_t seed;                      // torch.manual_seed(seed): at::mt19937 takes the low 32 bits
+    int32_t nseg;
+    int64_t total;                      // draws of this candidate
+    int64_t start[MT_MAX_SEG + 1];      // first draw of segment j (prefix sums)
+    int64_t dst[MT_MAX_SEG];            // flat-parameter offset of segment j's first element
+    float lo[MT_MAX_SEG], hi[MT_MAX_SEG];
+    int64_t flat_off;                   // this candidate's flat vector inside the scratch buffer
+};
+#define MT_TAIL 64
+
+__global__ void __launch_bounds__(256) k_mt_uniform(const MtCand* cands, float* flat, uint32_t* tails) {
+    __shared__ uint32_t st[2][624];
+    const MtCand& c = cands[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid == 0) {                     // at::mt19937::init_with_uint32
+        uint32_t x = c.seed;
+        st[0][0] = x;
+        for (int j = 1; j < 624; ++j) { x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)j; st[0][j] = x; }
+    }
+    __syncthreads();
+    float* out = flat + c.flat_off;
+    uint32_t* tail = tails + (size_t)blockIdx.x * MT_TAIL;
+    int cur = 0, seg = 0;
+    auto twist = [](uint32_t a, uint32_t b, uint32_t m) {
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        return m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    };
+    for (int64_t pos = 0; pos < c.total + MT_TAIL; pos += 624) {
+        const uint32_t* o = st[cur];
+        uint32_t* n = st[cur ^ 1];
+        if (tid < 227) n[tid] = twist(o[tid], o[tid + 1], o[tid + 397]);                 // i in [0, 227): old words only
+        __syncthreads();
+        if (tid < 227) n[227 + tid] = twist(o[227 + tid], o[228 + tid], n[tid]);        // i in [227, 454): new word i - 227
+        __syncthreads();
+        if (tid < 170) {                                                                 // i in [454, 624): new word i - 227; i = 623 wraps to the NEW word 0
+            const int i = 454 + tid;
+            n[i] = twist(o[i], i == 623 ? n[0] : o[i + 1], n[i - 227]);
+        }
+        __syncthreads();
+        cur ^= 1;
+        for (int j = tid; j < 624; j += 256) {
+            uint32_t y = n[j];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            const int64_t d = pos + j;
+            if (d < c.total) {
+                int sj = seg;                                   // (segments are visited in order: resume from this block's first)
+                while (d >= c.start[sj + 1]) ++sj;
+                const float x = (float)(y & 0xFFFFFFu) * (1.0f / 16777216.0f);
+                out[c.dst[sj] + (d - c.start[sj])] = __builtin_fmaf(x, c.hi[sj] - c.lo[sj], c.lo[sj]);
+            } else if (d < c.total + MT_TAIL) {
+                tail[d - c.total] = y;
+            }
+        }
+        while (seg + 1 < c.nseg && pos + 624 >= c.start[seg + 1]) ++seg;   // the next block starts in (or after) this segment
+        // (n is rewritten two blocks from now; the reads above are done before the next block's barriers release its writers)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_pool — GlobalPooling2D (models/auxiliary/aux_models.py:54-64): mean over all trailing dims of a (B, C, ...) tap.
 // One wave per (b, c) row of `inner` contiguous elements, 16 B per lane per load, f32 accumulation, wave shuffle
 // reduction; pure HBM-bound reduction (the "step before the path" that builds the feature table).

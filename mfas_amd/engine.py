@@ -313,11 +313,13 @@ class Population:
             _lib.check(int(n))
         return int(n)
 
-    def set_params(self, k: int, flat: torch.Tensor):
+    def set_params(self, k: int, flat: torch.Tensor, sync: bool = True):
         flat = flat.to(device=self.device, dtype=torch.float32).contiguous()
         assert flat.numel() == self.param_count(k), (flat.numel(), self.param_count(k))
-        _lib.check(self.lib.mfas_population_set_params(self._h, k, C.c_void_p(flat.data_ptr())))
-        torch.cuda.current_stream(self._idx).synchronize()   # flat may be freed by the caller
+        with torch.cuda.device(self._idx):
+            _lib.check(self.lib.mfas_population_set_params(self._h, k, C.c_void_p(flat.data_ptr())))
+        if sync:   # flat may be freed by the caller (sync=False: the caller keeps it alive until it has synchronised the stream)
+            torch.cuda.current_stream(self._idx).synchronize()
 
     def get_params(self, k: int, plane: int = 0) -> torch.Tensor:
         out = torch.empty(self.param_count(k), dtype=torch.float32, device=self.device)
@@ -345,6 +347,15 @@ class Population:
         s = np.asarray(seeds, np.uint32)
         assert len(s) == self.K
         _lib.check(self.lib.mfas_population_init(self._h, s.ctypes.data))
+
+    def init_torch_streams(self, seeds: Sequence[int], bounds: np.ndarray, alpha_mean: float = 0.0, alpha_std: float = 0.1):
+        """mfas_population_init_torch_streams: every candidate's construction draws under torch.manual_seed(seeds[k]), generated on
+        the device.  bounds: float32 [K][2 * (MAX_CELLS + 1)] (per cell weight / bias bound, then the classifier's)."""
+        s = np.ascontiguousarray(np.asarray(seeds, np.uint64))
+        b = np.ascontiguousarray(np.asarray(bounds, np.float32))
+        assert len(s) == self.K and b.shape == (self.K, 10), (len(s), b.shape)
+        with torch.cuda.device(self._idx):
+            _lib.check(self.lib.mfas_population_init_torch_streams(self._h, s.ctypes.data, b.ctypes.data, float(alpha_mean), float(alpha_std)))
 
     def train(self, train: FeatureTable, dev: Optional[FeatureTable], epochs: int, etas: np.ndarray,
               order: Optional[torch.Tensor] = None, max_steps: int = -1, snapshot_best: bool = False):

@@ -351,21 +351,32 @@ def make_order(N, epochs, shuffle, seed, device):
     return torch.stack([torch.randperm(N, generator=gen, device=device) for _ in range(epochs)]).to(torch.int32)
 
 
+def _mix64(z):
+    """splitmix64's finaliser on int64 tensors (wrapping multiplies; logical right shifts written as arithmetic shift + mask)."""
+    z = (z ^ ((z >> 30) & 0x3FFFFFFFF)) * -4658895280553007687          # 0xBF58476D1CE4E5B9
+    z = (z ^ ((z >> 27) & 0x1FFFFFFFFF)) * -7723592293110705685         # 0x94D049BB133111EB
+    return z ^ ((z >> 31) & 0x1FFFFFFFF)
+
+
 def make_order_per_candidate(N, epochs, shuffle, seed, device, indices):
-    """args.engine_order = "per_candidate": the reference's behaviour — every candidate iterates its OWN freshly shuffled
-    DataLoader each epoch (models/searchable.py:248-250, train_searchable/ntu.py:35).  Candidate i's permutations are seeded by
-    (seed, i), so they do not depend on the world size or on which round / rank trains it.  Returns int32 [len(indices)][E][N]."""
+    """args.engine_order = "per_candidate" (the default): the reference's behaviour — every candidate iterates its OWN freshly
+    shuffled DataLoader each epoch (models/searchable.py:248-250, train_searchable/ntu.py:35).  Candidate i's permutations are a
+    function of (seed, i, epoch) only, so they do not depend on the world size or on which round / rank trains it: every sample
+    position gets a 64-bit counter-based key (seed, candidate, epoch, position -> splitmix64) and the permutation is the argsort of
+    the keys — ONE batched device sort for the whole share instead of K x E randperm calls (a tie between two of N 64-bit keys has
+    probability N^2 / 2^65).  Returns int32 [len(indices)][E][N]."""
     if not shuffle:
         return None
-    out = []
-    for i in indices:
-        gen = torch.Generator(device=device)
-        gen.manual_seed(int(seed) + 1000003 * (int(i) + 1))
-        out.append(torch.stack([torch.randperm(N, generator=gen, device=device) for _ in range(epochs)]))
-    return torch.stack(out).to(torch.int32)
+    cand = torch.as_tensor([int(i) for i in indices], dtype=torch.int64, device=device).view(-1, 1, 1)
+    ep = torch.arange(epochs, dtype=torch.int64, device=device).view(1, -1, 1)
+    pos = torch.arange(N, dtype=torch.int64, device=device).view(1, 1, -1)
+    s64 = int(seed) & 0x7FFFFFFFFFFFFFFF
+    stream = _mix64((cand + 1) * 0x632BE59BD9B4E019 + (ep + 1) * 0x2545F4914F6CDD1D + s64)       # one stream per (seed, candidate, epoch)
+    keys = _mix64(stream + pos * -7046029254386353131)                                            # 0x9E3779B97F4A7C15
+    return torch.argsort(keys, dim=-1).to(torch.int32)
 
 
-def initial_flat_params(args, conf, hp=None, generator=None) -> torch.Tensor:
+def initial_flat_params(args, conf, hp=None, generator=None, out=None) -> torch.Tensor:
     """The flat parameter vector `Searchable_Skeleton_Image_Net(args, conf).flat_params()` would hold right after
     construction — same draws from torch's global RNG in the same order (per cell Linear weight: kaiming_uniform_(a=sqrt(5)),
     bias: U(+-1/sqrt(fan_in)); the classifier likewise; then alpha_i ~ N(0, 0.1)), BatchNorm at its defaults — without
@@ -377,7 +388,12 @@ def initial_flat_params(args, conf, hp=None, generator=None) -> torch.Tensor:
     hp = hp if hp is not None else Hyper.from_args(args)
     layout, n = flat_layout(conf, hp)
     where = {key: (shape, off) for key, shape, off in layout}
-    flat = torch.zeros(n, dtype=torch.float32)
+    if out is None:
+        flat = torch.zeros(n, dtype=torch.float32)
+    else:                       # fill the caller's (pinned) slice
+        flat = out
+        assert flat.numel() == n and flat.dtype == torch.float32
+        flat.zero_()
 
     def view(key):
         shape, off = where[key]
@@ -430,12 +446,71 @@ def _plan_rounds(hp, confs, mine, device, seed_base, chunk_cols):
         yield idx, pop
 
 
-def _initial_params_threaded(args, confs, group, hp, seed_base, searchable_type, return_model, mods):
-    """Yields (i, flat) for every candidate of `group` in order: its initial flat parameters = what constructing its module under
+def torch_init_bounds(conf, hp) -> np.ndarray:
+    """The Tensor.uniform_(-bound, bound) bounds nn.Linear.reset_parameters uses for every cell and for the classifier (weight:
+    kaiming_uniform_(a = sqrt 5), bias: 1 / sqrt(fan_in)), as float32 [2 * (4 + 1)]: what mfas_population_init_torch_streams
+    takes (the expressions of initial_flat_params, evaluated in Python doubles and rounded to float32 like torch does)."""
+    out = np.zeros(10, np.float32)
+    kgain = math.sqrt(2.0 / (1 + math.sqrt(5) ** 2))
+    conf = np.asarray(conf).reshape(-1, 3)
+    fans = [hp.s_sizes[int(c[0])] + hp.v_sizes[int(c[1])] + (hp.R if i else 0) for i, c in enumerate(conf)]
+    for i, fan_in in enumerate(fans):
+        out[2 * i] = math.sqrt(3.0) * (kgain / math.sqrt(fan_in))
+        out[2 * i + 1] = 1.0 / math.sqrt(fan_in)
+    out[8] = math.sqrt(3.0) * (kgain / math.sqrt(hp.R))
+    out[9] = 1.0 / math.sqrt(hp.R)
+    return out
+
+
+_DEVICE_STREAMS_OK = {}      # device -> the device-side Mersenne-Twister init reproduces torch's CPU draws on this host (checked once)
+
+
+def _init_population_device_streams(pop, args, confs, group, hp, seed_base, device) -> bool:
+    """The default initialisation, generated on the GPU: mfas_population_init_torch_streams runs torch's own generator
+    (at::mt19937 + uniform_real_distribution<float>) per candidate under the seeds the host path uses.  Verified ONCE per process
+    and device against torch itself — the first candidate's flat parameters must equal initial_flat_params bit for bit (torch's CPU
+    kernels fuse x * (hi - lo) + lo into one fma on AVX2 / AVX512 hosts; a build that does not would differ in last bits) — and
+    abandoned for the host path when that check fails (MFAS_HOST_INIT=1 forces the host path)."""
+    import os
+    key = str(device)
+    if os.environ.get("MFAS_HOST_INIT") or _DEVICE_STREAMS_OK.get(key) is False:
+        return False
+    seeds = [(seed_base + 2 + i) & 0xFFFFFFFFFFFFFFFF for i in group]
+    bounds = np.stack([torch_init_bounds(confs[i], hp) for i in group])
+    pop.init_torch_streams(seeds, bounds)
+    if key not in _DEVICE_STREAMS_OK:
+        g = torch.Generator()
+        g.manual_seed(seed_base + 2 + group[0])
+        want = initial_flat_params(args, confs[group[0]], hp, generator=g)
+        ok = bool(torch.equal(pop.get_params(0).cpu(), want))
+        _DEVICE_STREAMS_OK[key] = ok
+        if not ok:
+            import warnings
+            warnings.warn("mfas_amd: the device-side torch random stream does not reproduce this host's torch.uniform_ draws; "
+                          "initialising candidates on the host instead")
+            return False
+    return True
+
+
+_STAGING = {}      # device -> pinned host staging buffer of the initial parameters (grow-only: a 128-candidate R=128 call needs 0.5 GB)
+
+
+def _staging(device, n):
+    buf = _STAGING.get(str(device))
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        _STAGING[str(device)] = buf
+    return buf[:n]
+
+
+def _init_population_from_torch(pop, args, confs, group, hp, seed_base, searchable_type, return_model, mods, device):
+    """train_sampled_models' default initialisation: every candidate starts from what constructing its module under
     torch.manual_seed(seed_base + 2 + i) draws (ntu_searchable.py:44 builds the model from torch's global stream).  Module-free
     candidates draw from a PRIVATE torch.Generator seeded the same way (same Mersenne-Twister stream, same numbers:
-    tests/test_host_cpu.py), which makes the fills independent of each other: a small thread pool runs them side by side (torch's
-    uniform_ is serial and releases the GIL; 1 M draws per R=128 candidate) while the caller uploads the finished ones."""
+    tests/test_host_cpu.py), which makes the fills independent of each other: a small thread pool fills the candidates' slices of
+    ONE pinned staging buffer side by side (torch's uniform_ is serial and releases the GIL; 1 M draws per R=128 candidate), one
+    host-to-device copy moves the share, and the per-candidate repacking kernels (mfas_population_set_params) are queued without a
+    host synchronisation in between."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     # (the fills are tiny for torch's intra-op pool: with every host core in it their fork/join dominates — 6 ms instead of 0.7 ms
@@ -445,27 +520,35 @@ def _initial_params_threaded(args, confs, group, hp, seed_base, searchable_type,
         torch.set_num_threads(4)
     try:
         if return_model or searchable_type is not Searchable_Skeleton_Image_Net:
-            for i in group:
+            for j, i in enumerate(group):
                 with torch.random.fork_rng(devices=[]):
                     torch.manual_seed(seed_base + 2 + i)   # world-size independent per-candidate stream
                     m = searchable_type(args, confs[i])
                 if return_model:
                     mods[i] = m
-                yield i, m.flat_params()
+                pop.set_params(j, m.flat_params())
             return
+        sizes = [flat_layout(confs[i], hp)[1] for i in group]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        host = _staging(device, int(offs[-1]))
 
-        def one(i):
+        def one(j):
             g = torch.Generator()
-            g.manual_seed(seed_base + 2 + i)
-            return i, initial_flat_params(args, confs[i], hp, generator=g)
+            g.manual_seed(seed_base + 2 + group[j])
+            initial_flat_params(args, confs[group[j]], hp, generator=g, out=host[offs[j]:offs[j + 1]])
 
         workers = max(1, min(8, (os.cpu_count() or 1) // 2, len(group)))
         if workers == 1:
-            for i in group:
-                yield one(i)
-            return
-        with ThreadPoolExecutor(workers) as ex:
-            yield from ex.map(one, group)
+            for j in range(len(group)):
+                one(j)
+        else:
+            with ThreadPoolExecutor(workers) as ex:
+                list(ex.map(one, range(len(group))))
+        dev_flat = host.to(device, non_blocking=True)
+        for j in range(len(group)):
+            pop.set_params(j, dev_flat[offs[j]:offs[j + 1]], sync=False)
+        if torch.device(device).type == "cuda":
+            torch.cuda.current_stream(device).synchronize()      # the staging buffer is free for the next call; dev_flat may go
     finally:
         if nthreads > 4:
             torch.set_num_threads(nthreads)
@@ -557,10 +640,9 @@ def _train_sampled_models(sampled_configurations, searchable_type, dataloaders, 
                         mods[i] = m
                 elif getattr(args, "engine_init", "torch") == "device":
                     pop.init([(seed_base + 2 + i) & 0x7FFFFFFF for i in group])
-                else:
-                    for j, (i, flat0) in enumerate(_initial_params_threaded(args, confs, group, hp, seed_base, searchable_type, return_model, mods)):
-                        assert i == group[j]
-                        pop.set_params(j, flat0)
+                elif (return_model or searchable_type is not Searchable_Skeleton_Image_Net
+                      or not _init_population_device_streams(pop, args, confs, group, hp, seed_base, device)):
+                    _init_population_from_torch(pop, args, confs, group, hp, seed_base, searchable_type, return_model, mods, device)
                 if getattr(args, "verbose", False):
                     print("Now training: ")
                     for i in group:

@@ -117,6 +117,8 @@ for R, B, bn, K in ((16, 20, False, 5), (128, 16, True, 3), (32, 40, True, 2)):
 print("ASAN-TRAIN-OK")
 """ % ROOT
     res = subprocess.run([sys.executable, "-c", code], env=ge.asan_env(), capture_output=True, text=True, timeout=900)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "asan_train_stderr.log"), "w").write(res.stderr)
     assert res.returncode == 0 and "ASAN-TRAIN-OK" in res.stdout, (res.stdout[-1500:], res.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in res.stderr, res.stderr[-4000:]
 
@@ -182,3 +184,48 @@ def test_train_mode_forward_holds_no_population(dev):
     rgb_g = {k: v.clone().requires_grad_(True) for k, v in rgb.items()}
     with pytest.raises(NotImplementedError):
         model((rgb_g, ske))
+
+
+def test_device_side_torch_streams_equal_the_module_draws(dev, monkeypatch):
+    """train_sampled_models' default initialisation — the numbers `Searchable_Skeleton_Image_Net(args, conf)` draws from torch's CPU
+    generator under torch.manual_seed(seed) (ntu_searchable.py:44) — generated on the GPU (at::mt19937 + uniform_real_distribution
+    in k_mt_uniform, the alphas' normal draws from the stream's next raw words): bit for bit the host path's flat parameters for
+    every candidate, depth, width and seed; and a whole call gives the same accuracies with either path."""
+    import mfas_amd as M
+    from mfas_amd import ntu_searchable as NS
+    from types import SimpleNamespace
+    rng = np.random.default_rng(11)
+    for R, C, bn, alphas in ((16, 60, False, False), (128, 60, True, True), (24, 11, True, False), (200, 33, False, True)):
+        args = SimpleNamespace(vid_len=(8, 32), num_outputs=C, drpt=0.5, inner_representation_size=R, batchnorm=bn, alphas=alphas,
+                               multitask=False, batchsize=16)
+        hp = M.Hyper.from_args(args)
+        confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in (1, 4, 2, 3, 4, 4, 1)]
+        seeds = [int(x) for x in rng.integers(0, 2 ** 31 - 1, len(confs))] 
+        seeds[1] = 2 ** 32 + 5              # (at::mt19937 seeds from the low 32 bits)
+        pop = M.Population(hp, confs, dev)
+        pop.init_torch_streams(seeds, np.stack([NS.torch_init_bounds(c, hp) for c in confs]))
+        for k, c in enumerate(confs):
+            torch.manual_seed(seeds[k])
+            want = NS.Searchable_Skeleton_Image_Net(args, c).flat_params()
+            got = pop.get_params(k).cpu()
+            assert torch.equal(got, want), (R, C, bn, alphas, k, int((got != want).sum()), got.numel())
+            assert float(pop.get_params(k, plane=1).abs().max()) == 0.0          # a fresh optimizer
+        pop.close()
+    # through the driver: host-path call == device-stream call
+    tr = M.FeatureTable.synthetic(320, 1, dev, torch.bfloat16, snr=0.5)
+    dv = M.FeatureTable.synthetic(160, 2, dev, torch.bfloat16, snr=0.5)
+    ld = {"train": M.FeatureLoader(tr, 20, shuffle=True), "dev": M.FeatureLoader(dv, 20, shuffle=False)}
+    args = SimpleNamespace(vid_len=(8, 32), num_outputs=60, drpt=0.5, inner_representation_size=16, batchnorm=False, alphas=True,
+                           multitask=False, weightsharing=False, batchsize=20, eta_max=1e-3, eta_min=1e-6, Ti=1, Tm=2,
+                           use_dataparallel=False, verbose=False, epochs=2)
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in (4, 2, 4, 1, 3)]
+    res = {}
+    for host in ("", "1"):
+        if host:
+            monkeypatch.setenv("MFAS_HOST_INIT", "1")
+        else:
+            monkeypatch.delenv("MFAS_HOST_INIT", raising=False)
+        torch.manual_seed(3)
+        res[host] = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev)
+    assert res[""] == res["1"]
+    assert NS._DEVICE_STREAMS_OK.get(str(dev)) is True

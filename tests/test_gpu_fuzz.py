@@ -66,11 +66,12 @@ def test_random_population_steps(case):
     pop.close()
 
 
-@pytest.mark.parametrize("R,B,K", [(128, 16, 24), (16, 20, 48), (16, 16, 230), (128, 20, 22)])
+@pytest.mark.parametrize("R,B,K", [(128, 16, 24), (16, 20, 48), (16, 16, 230), (128, 20, 22), (128, 16, 30), (256, 16, 28), (128, 20, 29)])
 def test_natural_schedules_vs_oracle(R, B, K):
     """Populations large enough to take the fused two-group schedule (general chain from 20 candidates, lean chain for
     40..223) and the unfused large-population schedule, with the tap-major sweep where it applies: a sample of candidates
-    against the oracle after a few steps."""
+    against the oracle after a few steps.  From 28 candidates at R >= 128 the sweep's units span four 64-column chunks each
+    (multi-chunk units, one partial slab per unit — round 4); R = 256 takes the two-row-blocks-per-wave form of it."""
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(R * 1000 + K)
     # (BatchNorm WITH dropout on ~20-row batches can hit a column whose batch variance is ~0: then 1/sqrt(var + eps)

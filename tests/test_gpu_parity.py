@@ -685,6 +685,55 @@ def test_full_size_properties(dev):
         assert 0 <= a[k]["train_corrects"][0] <= 10000 and 0 <= a[k]["dev_corrects"][0] <= 5600
 
 
+def test_multi_chunk_units(dev, monkeypatch):
+    """Round 4: where the planner streams 64-column chunks (R = 128, >= 28 candidates) a sweep workgroup takes several consecutive
+    chunks and keeps the forward partial sums in registers across them (SegDesc::nsub, sweep_multi_body): one partial slab per
+    UNIT (MFAS_SUBCHUNKS=n; measured slower than one-chunk units on MI355X — the launch's tail grows faster than the slab traffic
+    shrinks — so the default stays factor 1).  (1) the group factor only regroups the k-summation of the forward products: a
+    fixed chunk_cols keeps one-chunk units (bit-identical to factor 1), and factors 3 (ragged last unit) / 4 / 16 (whole segments)
+    agree with factor 1 to rounding after a few steps (a whole training run is chaotic: Adam's first steps are sign-like);
+    (2) schedules on the SAME units stay bit-identical (fused two-group launches vs back-to-back);
+    (3) the train-mode single-batch entry points walk the merged units too (forward logits / gradients agree across factors)."""
+    from mfas_amd import FeatureTable, Hyper, Population
+    hp = Hyper(R=128, C=60, B=16, bn=True, drpt=0.0)
+    rng = np.random.default_rng(4)
+    K = 30
+    confs = [np.array(CONFS["c4"])] * 10 + [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in rng.integers(1, 5, K - 10)]
+    tr = FeatureTable.synthetic(480, 1, dev, torch.bfloat16, snr=0.3)
+    dv = FeatureTable.synthetic(320, 2, dev, torch.bfloat16, snr=0.3)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, 30.0, 60)
+
+    def run(sub, groups=None, cc=0, steps=-1):
+        for key, val in (("MFAS_SUBCHUNKS", sub), ("MFAS_GROUPS", groups)):
+            if val is not None:
+                monkeypatch.setenv(key, str(val))
+            else:
+                monkeypatch.delenv(key, raising=False)
+        pop = Population(hp, confs, dev, drop_seeds=list(range(K)), chunk_cols=cc)
+        pop.init(list(range(1, K + 1)))
+        stats, status = pop.train(tr, dv if steps < 0 else None, 2, etas, max_steps=steps)
+        assert not status.any()
+        w = [pop.get_params(k).cpu().numpy() for k in (0, K - 1)]
+        logits = pop.forward_train(3, tr, 0, 16, step=1).cpu().numpy()
+        grad = pop.backward(3, tr, torch.full((16, 60), 0.01, device=dev), 0, 16, step=1).cpu().numpy()
+        pop.close()
+        return stats, w, logits, grad
+
+    base, dflt, four = run(1), run(None), run(4)
+    assert dflt[0].tobytes() == base[0].tobytes() and all(np.array_equal(a, b) for a, b in zip(dflt[1], base[1]))     # the default is one chunk per unit
+    assert four[0].tobytes() != base[0].tobytes()                                               # factor 4 really regroups the sums
+    fixed = run(None, cc=64)
+    assert fixed[0].tobytes() == base[0].tobytes() and all(np.array_equal(a, b) for a, b in zip(fixed[1], base[1]))   # a caller's chunk_cols: one-chunk units
+    assert run(4, groups=1)[0].tobytes() == run(4, groups=2)[0].tobytes() == four[0].tobytes()   # (2)
+    short = run(1, steps=3)
+    for sub in (3, 4, 16):
+        got = run(sub, steps=3)
+        assert np.allclose(got[0]["train_loss_sum"], short[0]["train_loss_sum"], rtol=1e-4), sub
+        for a, b in zip(got[1], short[1]):
+            assert frac_bad(a, b, 1e-4, 1e-6) < 0.03 and np.abs(a - b).max() <= 3.5e-3, sub     # (an element is off by at most its 3 sign-like first steps)
+        assert rel_err(got[2], short[2]) < 2e-4 and rel_err(got[3], short[3]) < 2e-3, sub         # (3)
+
+
 @pytest.mark.parametrize("K,B,bn,cc,mixed", [(6, 20, False, 256, False), (9, 20, True, 128, True), (7, 16, True, 512, True), (16, 16, False, 1024, False)])
 def test_persistent_resident_schedule_bit_identical_full_size(dev, K, B, bn, cc, mixed):
     """Search-script defaults at full size (R=16, N_train=10,000, N_dev=5,600, bf16 taps, drpt 0.5, shuffled, E=2): the

@@ -262,25 +262,44 @@ def test_population_gather_gloo(tmp_path, world):
 
 
 def test_initial_flat_params_private_generator_and_threads():
-    """A private torch.Generator seeded like the global stream yields the module's numbers, and the threaded initialiser of
-    train_sampled_models hands them out in candidate order."""
+    """A private torch.Generator seeded like the global stream yields the module's numbers, and train_sampled_models' default
+    initialiser (thread pool -> one staging buffer -> set_params per candidate) hands every candidate exactly those."""
     from mfas_amd import ntu_searchable as NS
+    from mfas_amd import Hyper
     args = mkargs(inner_representation_size=32, alphas=True)
+    hp = Hyper.from_args(args)
     rng = np.random.default_rng(3)
     confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in (1, 4, 2, 3, 4, 1)]
     want = []
     for i, c in enumerate(confs):
         torch.manual_seed(900 + 2 + i)
         want.append(NS.Searchable_Skeleton_Image_Net(args, c).flat_params())
+
+    class FakePop:
+        def __init__(self):
+            self.got = {}
+
+        def set_params(self, j, flat, sync=True):
+            self.got[j] = flat.clone()
+
     before = torch.get_rng_state()
-    got = list(NS._initial_params_threaded(args, confs, list(range(len(confs))), None, 900, NS.Searchable_Skeleton_Image_Net, [], {}))
+    pop = FakePop()
+    NS._init_population_from_torch(pop, args, confs, list(range(len(confs))), hp, 900, NS.Searchable_Skeleton_Image_Net, [], {}, "cpu")
     assert torch.equal(before, torch.get_rng_state())          # the global stream is not consumed
-    assert [i for i, _ in got] == list(range(len(confs)))
-    for (i, f), w in zip(got, want):
-        assert torch.equal(f, w), i
-    mods = {}
-    got_m = list(NS._initial_params_threaded(args, confs, [1, 3], None, 900, NS.Searchable_Skeleton_Image_Net, [1, 3], mods))
-    assert torch.equal(got_m[0][1], want[1]) and torch.equal(got_m[1][1], want[3]) and set(mods) == {1, 3}
+    assert sorted(pop.got) == list(range(len(confs)))
+    for j, w in enumerate(want):
+        assert torch.equal(pop.got[j], w), j
+    pop, mods = FakePop(), {}
+    NS._init_population_from_torch(pop, args, confs, [1, 3], hp, 900, NS.Searchable_Skeleton_Image_Net, [1, 3], mods, "cpu")
+    assert torch.equal(pop.got[0], want[1]) and torch.equal(pop.got[1], want[3]) and set(mods) == {1, 3}
+    # per-candidate sample orders: permutations, a function of (seed, candidate, epoch) only
+    o = NS.make_order_per_candidate(500, 3, True, 77, "cpu", [0, 5, 9])
+    assert o.dtype == torch.int32 and tuple(o.shape) == (3, 3, 500)
+    assert all(sorted(o[k, e].tolist()) == list(range(500)) for k in range(3) for e in range(3))
+    assert torch.equal(NS.make_order_per_candidate(500, 3, True, 77, "cpu", [5])[0], o[1])
+    assert not torch.equal(NS.make_order_per_candidate(500, 3, True, 78, "cpu", [5])[0], o[1])
+    assert not torch.equal(o[0, 0], o[0, 1]) and not torch.equal(o[0, 0], o[1, 0])
+    assert NS.make_order_per_candidate(500, 3, False, 77, "cpu", [0]) is None
 
 
 def test_round_planner_and_shard_call_without_a_device():
