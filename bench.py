@@ -246,8 +246,8 @@ def main():
     ap.add_argument("--engine-init", default="torch", choices=["torch", "device"],
                     help="candidate initialisation: torch = train_sampled_models' default (the module's own draws from torch's CPU generator, "
                          "uploaded); device = the engine's hash generator on the GPU")
-    ap.add_argument("--engine-order", default="shared", choices=["shared", "per_candidate"],
-                    help="sample order: one shuffle per epoch shared by the call's candidates, or the reference's per-candidate shuffles")
+    ap.add_argument("--engine-order", default="per_candidate", choices=["shared", "per_candidate"],
+                    help="sample order: the reference's per-candidate shuffles (train_sampled_models' default), or one shuffle per epoch shared by the call's candidates")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(a.gpus))
@@ -423,12 +423,18 @@ def main():
                            "kernel_algorithmic_gbs": (pby / (pms / nl * 1e-3) / 1e9) if nl else None,
                            "schedule": psched, "frac_of_hbm_bound": cps * gb / (HBM_PEAK_GBS * 1e9),
                            "mean_best_dev_acc": float(np.mean(kaccs))}
-    other_init = None
-    if plain and world == 1 and not a.no_small_pop:      # the same workload with the OTHER initialisation path, one call
+    other_init = other_order = None
+    if plain and world == 1 and not a.no_small_pop:      # the same workload with the OTHER initialisation path / sample order, one call each
         oargs = SimpleNamespace(**vars(args))
         oargs.engine_init = "device" if a.engine_init == "torch" else "torch"
         _, rt = timed_calls(lambda: train_fn(confs, stype, loaders, oargs, device), 1)
         other_init = {"engine_init": oargs.engine_init, "cand_per_s": total / max(rt), "ms_per_step": max(rt) * 1e3}
+        oargs = SimpleNamespace(**vars(args))
+        oargs.engine_order = "shared" if a.engine_order == "per_candidate" else "per_candidate"
+        _, rt = timed_calls(lambda: train_fn(confs, stype, loaders, oargs, device), 1)
+        nl, pms, _, _ = profile_summary()
+        other_order = {"engine_order": oargs.engine_order, "cand_per_s": total / max(rt), "ms_per_step": max(rt) * 1e3,
+                       "avg_launch_us": (pms / nl * 1e3) if nl else None}
 
     if rank == 0:
         achieved = bytes_per_launch / (ms / n_launch * 1e-3) / 1e9 if n_launch else None
@@ -490,7 +496,7 @@ def main():
                        "parallelism": f"population-sharded x{world}",
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (a.backend if world > 1 else None),
                        "rank_seconds": rank_dt,
-                       "engine_init": a.engine_init, "engine_order": a.engine_order, "other_init": other_init,
+                       "engine_init": a.engine_init, "engine_order": a.engine_order, "other_init": other_init, "other_order": other_order,
                        "mean_best_dev_acc" if not mm else "mean_best_dev_f1": float(np.mean(accs)),
                        "hbm_bound_cand_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / bytes_cand,
                        "frac_of_hbm_bound": total_trained / dt * bytes_cand / (HBM_PEAK_GBS * 1e9 * world),

@@ -51,9 +51,9 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--random_search", action="store_true", default=False)
     p.add_argument("--engine_init", default="torch", choices=["torch", "device"])
-    p.add_argument("--engine_order", default="shared", choices=["shared", "per_candidate"],
-                   help="shared: one shuffled order per epoch for the whole call (lockstep); per_candidate: every candidate draws its own "
-                        "permutations, as the reference's per-candidate DataLoader(shuffle=True) does (models/searchable.py:248-250)")
+    p.add_argument("--engine_order", default="per_candidate", choices=["shared", "per_candidate"],
+                   help="per_candidate (default): every candidate draws its own permutations, as the reference's per-candidate "
+                        "DataLoader(shuffle=True) does (models/searchable.py:248-250); shared: one shuffled order per epoch for the whole call (lockstep)")
     p.add_argument("--engine_all_ranks", action="store_true", default=False,
                    help="under torchrun: shard every call over ALL ranks (default: only as many ranks as the calibrated step-time model "
                         "says shorten the call, mfas_amd/population.py)")

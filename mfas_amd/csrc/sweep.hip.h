@@ -7,44 +7,33 @@
 //   dW^T = x_t^T dy (4*MB f32 MFMAs; D image == the tile image)  ->  Adam(+L2) on 4 elements/lane in registers  ->
 //   store W, m, v (+ transposed copy T for OUT/HEAD)  ->  y_{t+1} += x_{t+1} W_new^T (4*MB f32 MFMAs) into yacc.
 // ------------------------------------------------------------------------------------------------
-// the W / m / v tiles of one batch: k-blocks kbb, kbb + kbs, ... (SWEEP_U of them) of row block rb
-template <bool NT, int SWEEP_U>
-__device__ __forceinline__ void tile_load(const float* Wp, const float* Mp, const float* Vp, const int rb, const int nkb, const int kbb,
-                                          const int kbs, const bool upd, const int lane, f32x4 (&w4)[SWEEP_U], f32x4 (&m4)[SWEEP_U],
-                                          f32x4 (&v4)[SWEEP_U]) {
-#pragma unroll
-    for (int u = 0; u < SWEEP_U; ++u) {
-        const int kb = kbb + u * kbs;
-        if (kb < nkb) {
-            const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
-            // state larger than the Infinity Cache is streamed once per step: nontemporal (+5 % HBM rate)
-            w4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Wp + off))
-                       : *reinterpret_cast<const f32x4*>(Wp + off);
-            if (upd) {
-                m4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mp + off))
-                           : *reinterpret_cast<const f32x4*>(Mp + off);
-                v4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vp + off))
-                           : *reinterpret_cast<const f32x4*>(Vp + off);
-            }
-        }
-    }
-}
-
-// PRE (round 4): the FIRST batch of this call is already in flight in (w4, m4, v4) — the caller requested it (tile_load) before it
-// staged the batch's table rows and dy through LDS, so that the state's memory latency runs under the staging's instead of behind
-// its barrier (the tiles do not depend on anything staged).  Same loads, same arithmetic: only their issue order moves.
-template <int MB, bool NT, int SWEEP_U, bool COH = false, bool PRE = false>
+template <int MB, bool NT, int SWEEP_U, bool COH = false>
 __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const int rb, const int nkb, const int kb0,
                                          const int kbs, const float* xt, const int ST, const float* xn, const int SN,
                                          const float (&dyf)[MB * 4], const float gsc, const AdamC& ac, const bool upd,
                                          const bool fwd, f32x4 (&yacc)[MB], float* T, const int tstride_rb,
-                                         const int lane, const int nj, f32x4 (&w4)[SWEEP_U], f32x4 (&m4)[SWEEP_U], f32x4 (&v4)[SWEEP_U],
-                                         const bool pre = false) {
+                                         const int lane, const int nj) {
     // nj = ceil(B / 4): batch blocks that hold data (DW_BATCH_LOOP, common.hip.h)
     const int l15 = lane & 15, lg = lane >> 4;
     const float a_ss = ac.ss, a_bc2s = ac.bc2s, a_w1 = ac.w1, a_b2 = ac.b2, a_w2 = ac.w2, a_eps = ac.eps, a_wd = ac.wd;
     for (int kbb = kb0; kbb < nkb; kbb += SWEEP_U * kbs) {
-        if (!(PRE && pre && kbb == kb0)) tile_load<NT, SWEEP_U>(Wp, Mp, Vp, rb, nkb, kbb, kbs, upd, lane, w4, m4, v4);
+        f32x4 w4[SWEEP_U], m4[SWEEP_U], v4[SWEEP_U];
+#pragma unroll
+        for (int u = 0; u < SWEEP_U; ++u) {
+            const int kb = kbb + u * kbs;
+            if (kb < nkb) {
+                const int64_t off = ((int64_t)rb * nkb + kb) * 256 + lane * 4;
+                // state larger than the Infinity Cache is streamed once per step: nontemporal (+5 % HBM rate)
+                w4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Wp + off))
+                           : *reinterpret_cast<const f32x4*>(Wp + off);
+                if (upd) {
+                    m4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mp + off))
+                               : *reinterpret_cast<const f32x4*>(Mp + off);
+                    v4[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vp + off))
+                               : *reinterpret_cast<const f32x4*>(Vp + off);
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < SWEEP_U; ++u) {
             const int kb = kbb + u * kbs;
@@ -89,17 +78,6 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
             }
         }
     }
-}
-
-template <int MB, bool NT, int SWEEP_U, bool COH = false>
-__device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const int rb, const int nkb, const int kb0,
-                                         const int kbs, const float* xt, const int ST, const float* xn, const int SN,
-                                         const float (&dyf)[MB * 4], const float gsc, const AdamC& ac, const bool upd,
-                                         const bool fwd, f32x4 (&yacc)[MB], float* T, const int tstride_rb,
-                                         const int lane, const int nj) {
-    f32x4 w4[SWEEP_U], m4[SWEEP_U], v4[SWEEP_U];
-    tile_run<MB, NT, SWEEP_U, COH, false>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc, T, tstride_rb, lane, nj,
-                                          w4, m4, v4, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -174,19 +152,6 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
     const int64_t sbo = cd.step_off;   // this candidate's step buffers inside a.stepbuf
     const bool red = a.red_cnt != nullptr;
 
-    // Work split: with >= 8 row blocks every wave owns whole row blocks (streams contiguous tiles, no
-    // reduction); with fewer (R < 128, or a row-split unit) the waves split the k blocks and reduce through LDS.
-    const bool split_k = nrb < STEP_NW;
-    const int rb0 = split_k ? 0 : wave, rbs = split_k ? 1 : STEP_NW;
-    const int kb0 = split_k ? wave : 0, kbs = split_k ? STEP_NW : 1;
-    float* Wp = a.plane + d.w_off;
-    float* Mp = Wp + a.plane_stride;
-    float* Vp = Mp + a.plane_stride;
-    // the wave's first batch of W / m / v tiles is requested NOW, before the staging below and its barrier (tile_run, PRE)
-    f32x4 pw[U], pm[U], pv[U];
-    const bool pre = rb0 < nrb;
-    if (pre) tile_load<NT, U>(Wp, Mp, Vp, rb0, nkb, kb0, kbs, upd, lane, pw, pm, pv);
-
     if (upd && feat) {
         const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
         stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, cand_order(a.order, a.g, cd.gidx), st.pos_t, st.base_t, st.nvalid_t, Bp, tid, STEP_THREADS);
@@ -227,12 +192,20 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
     }
     __syncthreads();
 
+    float* Wp = a.plane + d.w_off;
+    float* Mp = Wp + a.plane_stride;
+    float* Vp = Mp + a.plane_stride;
     const AdamC ac = adam_consts(a.ac, upd ? st.ss : 0.f, upd ? st.bc2s : 1.f);
     // alpha scaling of the gradient of S / V columns (aux_models.py:103-111): sigma(alpha_t) as used by this
     // step's forward, published by k_chain (alpha itself has already been stepped); 1.0 when alphas are off
     float gsc = 1.0f;
     if (a.g.alphas && feat && upd) gsc = ldc1<COH>(a.stepbuf + sbo + a.g.sb_gsc + d.cell * 2 + d.kind);
 
+    // Work split: with >= 8 row blocks every wave owns whole row blocks (streams contiguous tiles, no
+    // reduction); with fewer (R < 128, or a row-split unit) the waves split the k blocks and reduce through LDS.
+    const bool split_k = nrb < STEP_NW;
+    const int rb0 = split_k ? 0 : wave, rbs = split_k ? 1 : STEP_NW;
+    const int kb0 = split_k ? wave : 0, kbs = split_k ? STEP_NW : 1;
     // partial slot of this chunk: [seg_nrb][MB][256] in MFMA D layout; this unit owns row blocks rb0 .. rb0 + nrb
     const int64_t part = sbo + a.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * d.seg_nrb * MB) << 8) +
                          (((int64_t)d.rb0 * MB) << 8);
@@ -244,9 +217,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
         f32x4 yacc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        tile_run<MB, NT, U, COH, true>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
-                                       d.wt_off >= 0 ? a.wt + d.wt_off + ((int64_t)(d.k0 >> 4) * d.seg_nrb + d.rb0) * 256 : nullptr, d.seg_nrb, lane, (a.g.B + 3) >> 2,
-                                       pw, pm, pv, pre && rb == rb0);
+        tile_run<MB, NT, U, COH>(Wp, Mp, Vp, rb, nkb, kb0, kbs, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
+                                 d.wt_off >= 0 ? a.wt + d.wt_off + ((int64_t)(d.k0 >> 4) * d.seg_nrb + d.rb0) * 256 : nullptr, d.seg_nrb, lane, (a.g.B + 3) >> 2);
         if (fwd) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -324,7 +296,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
 // each a contiguous [rb][kb][256] block per plane — but dy is staged once, the wave's forward accumulator lives in registers
 // across the chunks, and the unit writes ONE partial slab: the slab traffic (8 KB written per chunk and read back by the chain)
 // and the dy staging shrink by the group factor.  Arithmetic per tile = tile_run's; only the k-summation of the forward partial
-// is regrouped (as with any other chunk size).
+// is regrouped (as with any other chunk size).  OPT-IN (MFAS_SUBCHUNKS=n): measured slower than one-chunk units on MI355X (2 / 4 / 8
+// chunks per unit: 314 / 320 / 327 us per launch against 299, profiles/r04_subchunks_preload_prio.log) although 4-7 % fewer bytes move —
+// the workgroup-wide barrier between chunks makes every wave wait for the slowest, where one-chunk workgroups hand their wave slots
+// to the next workgroup one wave at a time.
 // ------------------------------------------------------------------------------------------------
 template <int MB, bool NT, int U>
 __device__ __forceinline__ void sweep_multi_body(const SweepArgs& a, const SweepStep& st, const int bid, float* lds) {
@@ -353,11 +328,9 @@ __device__ __forceinline__ void sweep_multi_body(const SweepArgs& a, const Sweep
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int rb = wave;            // 8 row blocks, one per wave
-    f32x4 pw[U], pm[U], pv[U];
     for (int sub = 0; sub < nsub; ++sub) {
         const int k0 = d.k0 + sub * cc;
         float* Wp = a.plane + d.w_off + (int64_t)sub * rows_p * cc;
-        tile_load<NT, U>(Wp, Wp + a.plane_stride, Wp + 2 * a.plane_stride, rb, nkb, 0, 1, upd, lane, pw, pm, pv);   // in flight under the staging
         if (sub > 0) __syncthreads();                    // every wave is done with the previous chunk's rows
         if (upd) stage_table(xt, ST, tp, a.tab.dtype, d.width, k0, cc, ord, st.pos_t, st.base_t, st.nvalid_t, Bp, tid, STEP_THREADS);
         if (fwd) stage_table(xn, SN, tp, a.tab.dtype, d.width, k0, cc, ord, st.pos_n, st.base_n, st.nvalid_n, Bp, tid, STEP_THREADS);
@@ -365,8 +338,8 @@ __device__ __forceinline__ void sweep_multi_body(const SweepArgs& a, const Sweep
         float dyf[MB * 4];
 #pragma unroll
         for (int j = 0; j < MB * 4; ++j) dyf[j] = upd ? dyl[(4 * j + lg) * SD + rb * 16 + l15] : 0.f;
-        tile_run<MB, NT, U, false, true>(Wp, Wp + a.plane_stride, Wp + 2 * a.plane_stride, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
-                                         nullptr, d.seg_nrb, lane, (a.g.B + 3) >> 2, pw, pm, pv, true);
+        tile_run<MB, NT, U, false>(Wp, Wp + a.plane_stride, Wp + 2 * a.plane_stride, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc,
+                                   nullptr, d.seg_nrb, lane, (a.g.B + 3) >> 2);
     }
     if (fwd) {
         const int64_t part = sbo + a.g.sb_part + (((int64_t)(cd.part_cell_off[d.cell] + d.part_idx) * d.seg_nrb * MB) << 8);
@@ -395,17 +368,11 @@ __device__ __forceinline__ void sweep_tap_body(const SweepArgs& a, const int bid
     const bool upd = a.do_update != 0;
     const bool fwd = a.do_forward != 0;
     if (!upd && !fwd) return;
-    const int item = wave / nrb, rb = wave - item * nrb;
-    // this wave's first batch of W / m / v tiles is requested before the rows are staged (tile_run, PRE)
-    f32x4 pw[U], pm[U], pv[U];
-    if (item < d.nitems) {
-        const float* W0 = a.plane + d.w_off[item];
-        tile_load<NT, U>(W0, W0 + a.plane_stride, W0 + 2 * a.plane_stride, rb, nkb, 0, 1, upd, lane, pw, pm, pv);
-    }
     const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
     if (upd) stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_t, a.base_t, a.nvalid_t, Bp, tid, STEP_THREADS);
     if (fwd) stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, a.order, a.pos_n, a.base_n, a.nvalid_n, Bp, tid, STEP_THREADS);
     __syncthreads();
+    const int item = wave / nrb, rb = wave - item * nrb;
     if (item >= d.nitems) return;
     const CandDev& cd = a.cands[d.cand[item]];
     float* sb = a.stepbuf + cd.step_off;
@@ -427,8 +394,7 @@ __device__ __forceinline__ void sweep_tap_body(const SweepArgs& a, const int bid
     f32x4 yacc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tile_run<MB, NT, U, false, true>(Wp, Mp, Vp, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc, nullptr, nrb, lane, (a.g.B + 3) >> 2,
-                                     pw, pm, pv, true);
+    tile_run<MB, NT, U>(Wp, Mp, Vp, rb, nkb, 0, 1, xt, ST, xn, SN, dyf, gsc, ac, upd, fwd, yacc, nullptr, nrb, lane, (a.g.B + 3) >> 2);
     if (fwd) {
         float* part = sb + a.g.sb_part + (((int64_t)(cd.part_cell_off[cell] + d.part_idx[item]) * nrb * MB) << 8);
 #pragma unroll

@@ -584,8 +584,11 @@ def _train_sampled_models(sampled_configurations, searchable_type, dataloaders, 
     hp = _hp if _hp is not None else Hyper.from_args(args)
     hp.multitask = False    # ntu_searchable.py:82-84 never forwards multitask to the train loop
     hp.tap_bits = 8 * train_l.table.elem_size() if train_l.table.dtype == dev_l.table.dtype else 0
-    per_cand = getattr(args, "engine_order", "shared") == "per_candidate"      # the reference's independent shuffles (default: lockstep order)
-    if getattr(args, "engine_order", "shared") not in ("shared", "per_candidate"):
+    # sample order: "per_candidate" (default) = the reference's behaviour, every candidate iterates its own freshly shuffled loader
+    # (models/searchable.py:248-250, train_searchable/ntu.py:35); "shared" = one shuffle per epoch for the whole call (lockstep): what
+    # lets the tap-major sweep stage a batch's rows once for several candidates at R < 128 (costs / gains per workload)
+    per_cand = getattr(args, "engine_order", "per_candidate") == "per_candidate"
+    if getattr(args, "engine_order", "per_candidate") not in ("shared", "per_candidate"):
         raise ValueError("args.engine_order must be 'shared' or 'per_candidate'")
     hp.order_per_candidate = per_cand
     if getattr(args, "multitask", False) and _hp is None:

@@ -62,6 +62,7 @@ def test_bench_single_gpu_line_carries_the_search_sized_workloads(dev):
     line = run_bench(["--pop", "4", "--steps", "1", "--warmup", "0"] + TINY)
     assert line["n_gpus"] == 1 and line["metric"].startswith("candidate-archs trained/sec") and line["unit"] == "candidates/s"
     assert line["config"]["engine_init"] == "torch" and line["config"]["other_init"]["engine_init"] == "device"
+    assert line["config"]["engine_order"] == "per_candidate" and line["config"]["other_order"]["engine_order"] == "shared"     # the reference's shuffles are the default
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-9
     sp = line["config"]["small_pop"]

@@ -686,14 +686,14 @@ def test_full_size_properties(dev):
 
 
 def test_multi_chunk_units(dev, monkeypatch):
-    """Round 4: where the planner streams 64-column chunks (R = 128, >= 28 candidates) a sweep workgroup takes several consecutive
-    chunks and keeps the forward partial sums in registers across them (SegDesc::nsub, sweep_multi_body): one partial slab per
-    UNIT (MFAS_SUBCHUNKS=n; measured slower than one-chunk units on MI355X — the launch's tail grows faster than the slab traffic
-    shrinks — so the default stays factor 1).  (1) the group factor only regroups the k-summation of the forward products: a
-    fixed chunk_cols keeps one-chunk units (bit-identical to factor 1), and factors 3 (ragged last unit) / 4 / 16 (whole segments)
-    agree with factor 1 to rounding after a few steps (a whole training run is chaotic: Adam's first steps are sign-like);
-    (2) schedules on the SAME units stay bit-identical (fused two-group launches vs back-to-back);
-    (3) the train-mode single-batch entry points walk the merged units too (forward logits / gradients agree across factors)."""
+    """Round 4 (opt-in, MFAS_SUBCHUNKS=n): where the planner streams 64-column chunks (R = 128, >= 28 candidates) a sweep workgroup
+    may take n consecutive chunks and keep the forward partial sums in registers across them (SegDesc::nsub, sweep_multi_body): one
+    partial slab per UNIT.  Measured slower than one-chunk units on MI355X (profiles/r04_subchunks_preload_prio.log), so the default
+    stays factor 1 — but the arithmetic is pinned: a unit of n chunks sums exactly like ONE chunk of n * 64 columns, so
+    (1) factor 2 == chunk_cols 128 and factor 4 == chunk_cols 256 BIT FOR BIT (statistics of a whole run, parameters, train-mode
+    forward logits and gradients of the single-batch entry points, which walk the merged units too); the default == factor 1 ==
+    chunk_cols 64; (2) schedules on the SAME units stay bit-identical (fused two-group launches vs back-to-back); (3) a ragged
+    factor (3: units of 3, 3, 2 chunks) trains to the same losses within the run-to-run spread of two chunk sizes."""
     from mfas_amd import FeatureTable, Hyper, Population
     hp = Hyper(R=128, C=60, B=16, bn=True, drpt=0.0)
     rng = np.random.default_rng(4)
@@ -703,7 +703,7 @@ def test_multi_chunk_units(dev, monkeypatch):
     dv = FeatureTable.synthetic(320, 2, dev, torch.bfloat16, snr=0.3)
     etas = O.eta_sequence(1e-3, 1e-6, 1, 2, 30.0, 60)
 
-    def run(sub, groups=None, cc=0, steps=-1):
+    def run(sub, groups=None, cc=0):
         for key, val in (("MFAS_SUBCHUNKS", sub), ("MFAS_GROUPS", groups)):
             if val is not None:
                 monkeypatch.setenv(key, str(val))
@@ -711,27 +711,28 @@ def test_multi_chunk_units(dev, monkeypatch):
                 monkeypatch.delenv(key, raising=False)
         pop = Population(hp, confs, dev, drop_seeds=list(range(K)), chunk_cols=cc)
         pop.init(list(range(1, K + 1)))
-        stats, status = pop.train(tr, dv if steps < 0 else None, 2, etas, max_steps=steps)
+        stats, status = pop.train(tr, dv, 2, etas)
         assert not status.any()
-        w = [pop.get_params(k).cpu().numpy() for k in (0, K - 1)]
+        w = [pop.get_params(k).cpu().numpy() for k in (0, K // 2, K - 1)]
         logits = pop.forward_train(3, tr, 0, 16, step=1).cpu().numpy()
         grad = pop.backward(3, tr, torch.full((16, 60), 0.01, device=dev), 0, 16, step=1).cpu().numpy()
         pop.close()
         return stats, w, logits, grad
 
-    base, dflt, four = run(1), run(None), run(4)
-    assert dflt[0].tobytes() == base[0].tobytes() and all(np.array_equal(a, b) for a, b in zip(dflt[1], base[1]))     # the default is one chunk per unit
-    assert four[0].tobytes() != base[0].tobytes()                                               # factor 4 really regroups the sums
-    fixed = run(None, cc=64)
-    assert fixed[0].tobytes() == base[0].tobytes() and all(np.array_equal(a, b) for a, b in zip(fixed[1], base[1]))   # a caller's chunk_cols: one-chunk units
+    def same(a, b):
+        return (a[0].tobytes() == b[0].tobytes() and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+                and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]))
+
+    base, dflt = run(1), run(None)
+    assert same(dflt, base) and same(run(None, cc=64), base)              # the default: one 64-column chunk per unit
+    two, four = run(2), run(4)
+    assert same(two, run(None, cc=128)) and same(four, run(None, cc=256))    # (1) n chunks per unit == one chunk of n * 64 columns
+    assert not same(two, base) and not same(four, two)
     assert run(4, groups=1)[0].tobytes() == run(4, groups=2)[0].tobytes() == four[0].tobytes()   # (2)
-    short = run(1, steps=3)
-    for sub in (3, 4, 16):
-        got = run(sub, steps=3)
-        assert np.allclose(got[0]["train_loss_sum"], short[0]["train_loss_sum"], rtol=1e-4), sub
-        for a, b in zip(got[1], short[1]):
-            assert frac_bad(a, b, 1e-4, 1e-6) < 0.03 and np.abs(a - b).max() <= 3.5e-3, sub     # (an element is off by at most its 3 sign-like first steps)
-        assert rel_err(got[2], short[2]) < 2e-4 and rel_err(got[3], short[3]) < 2e-3, sub         # (3)
+    three = run(3)                                                            # (3)
+    spread = np.abs(four[0]["train_loss_sum"] - base[0]["train_loss_sum"]).max()
+    assert np.abs(three[0]["train_loss_sum"] - base[0]["train_loss_sum"]).max() <= 3.0 * spread + 1.0
+    assert np.abs(three[0]["dev_corrects"].astype(np.int64) - base[0]["dev_corrects"]).max() <= 3 * np.abs(four[0]["dev_corrects"].astype(np.int64) - base[0]["dev_corrects"]).max() + 8
 
 
 @pytest.mark.parametrize("K,B,bn,cc,mixed", [(6, 20, False, 256, False), (9, 20, True, 128, True), (7, 16, True, 512, True), (16, 16, False, 1024, False)])
