@@ -424,7 +424,7 @@ def main():
                            "schedule": psched, "frac_of_hbm_bound": cps * gb / (HBM_PEAK_GBS * 1e9),
                            "mean_best_dev_acc": float(np.mean(kaccs))}
     other_init = other_order = None
-    if plain and world == 1 and not a.no_small_pop:      # the same workload with the OTHER initialisation path / sample order, one call each
+    if world == 1 and not a.no_small_pop and not a.mixed_confs:      # the same workload with the OTHER initialisation path / sample order, one call each
         oargs = SimpleNamespace(**vars(args))
         oargs.engine_init = "device" if a.engine_init == "torch" else "torch"
         _, rt = timed_calls(lambda: train_fn(confs, stype, loaders, oargs, device), 1)

@@ -7,7 +7,7 @@ with the dispatch duration (v_mfma_f32_16x16x4_f32 = 2,048 FLOP per wave instruc
 import csv, glob, json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "1", "--warmup", "0", "--epochs", "1",
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-small-pop", "--steps", "1", "--warmup", "0", "--epochs", "1",
          "--n-train", "2000", "--n-dev", "5600"]
 F32_MFMA_PEAK_TFLOPS = 157.3      # 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz (16x16x4 f32: 2,048 FLOP / 32 cycles)
 

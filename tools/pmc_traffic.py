@@ -8,7 +8,7 @@ Corrections applied: counter unit KB = 1024 B; FETCH_SIZE x2 on gfx950 (confirme
 import csv, glob, json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "1", "--warmup", "0", "--epochs", "1",
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-small-pop", "--steps", "1", "--warmup", "0", "--epochs", "1",
          "--n-train", "2000", "--n-dev", "320"]
 
 
