@@ -391,7 +391,9 @@ def main():
                         "populations_per_call": len(NS.PROFILE) // max(reps, 1),
                         "kernel_us_per_train_step": (pms * 1e3 / (reps * a.epochs * nb)) if (nl and psched.get("persistent")) else None})
         else:
-            owner, _, model = popmod.shard_call(sconfs, M.Hyper.from_args(sargs), world, device, False)
+            shp = M.Hyper.from_args(sargs)          # the geometry key train_sampled_models calibrated its model under
+            shp.multitask, shp.tap_bits, shp.order_per_candidate = False, 8 * train.elem_size(), a.engine_order == "per_candidate"
+            owner, _, model = popmod.shard_call(sconfs, shp, world, device, False)
             ent.update({"share": [owner.count(r) for r in range(world)], "ranks_used": len(set(owner)),
                         "step_time_model": model.describe() if model is not None else None})
         return ent
