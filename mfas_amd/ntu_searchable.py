@@ -367,13 +367,18 @@ def make_order_per_candidate(N, epochs, shuffle, seed, device, indices):
     probability N^2 / 2^65).  Returns int32 [len(indices)][E][N]."""
     if not shuffle:
         return None
-    cand = torch.as_tensor([int(i) for i in indices], dtype=torch.int64, device=device).view(-1, 1, 1)
     ep = torch.arange(epochs, dtype=torch.int64, device=device).view(1, -1, 1)
     pos = torch.arange(N, dtype=torch.int64, device=device).view(1, 1, -1)
     s64 = int(seed) & 0x7FFFFFFFFFFFFFFF
-    stream = _mix64((cand + 1) * 0x632BE59BD9B4E019 + (ep + 1) * 0x2545F4914F6CDD1D + s64)       # one stream per (seed, candidate, epoch)
-    keys = _mix64(stream + pos * -7046029254386353131)                                            # 0x9E3779B97F4A7C15
-    return torch.argsort(keys, dim=-1).to(torch.int32)
+    idx = [int(i) for i in indices]
+    out = torch.empty((len(idx), epochs, N), dtype=torch.int32, device=device)
+    per = max(1, (32 << 20) // max(1, epochs * N))          # <= 32 M keys (256 MB of int64 + the sort's buffers) per slice
+    for k0 in range(0, len(idx), per):
+        cand = torch.as_tensor(idx[k0:k0 + per], dtype=torch.int64, device=device).view(-1, 1, 1)
+        stream = _mix64((cand + 1) * 0x632BE59BD9B4E019 + (ep + 1) * 0x2545F4914F6CDD1D + s64)   # one stream per (seed, candidate, epoch)
+        keys = _mix64(stream + pos * -7046029254386353131)                                        # 0x9E3779B97F4A7C15
+        out[k0:k0 + per] = torch.argsort(keys, dim=-1)
+    return out
 
 
 def initial_flat_params(args, conf, hp=None, generator=None, out=None) -> torch.Tensor:

@@ -11,7 +11,7 @@
 //   F2 / F4  the same WITHOUT the barriers (waves run on independently)
 //   U1 / U4  A with 1 / 4 tiles per plane in flight per wave
 //   I  waves interleaved tile by tile through the chunk;  X  chunk order regrouped per XCD;  H  4-wave workgroups of half a chunk;
-//   P  plain (cached) accesses;  RO / WO  the read half / the write half alone (GB/s printed for the full read + write byte count: double it... no: halve it)
+//   K  16-wave workgroups over two chunks side by side;  G2  8 waves x 8 contiguous tiles (chunk_cols 128);  P  plain (cached) accesses;  RO / WO  the read half / the write half alone (GB/s printed for the full read + write byte count: double it... no: halve it)
 // usage: sweepbench [iters]   -> microseconds per pass over 3 x 266 MB (read + write = 1.6 GB), GB/s
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -160,6 +160,21 @@ __global__ void __launch_bounds__(512, 4) k_wo(float* W, size_t plane, float* sl
     }
 }
 
+// K: 16-wave workgroups (1024 threads), two chunks side by side: every wave still owns 4 tiles, all 64 tiles of the pair in flight together
+__global__ void __launch_bounds__(1024, 4) k_wide(float* W, size_t plane, float* slabs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    stream_tiles<2>(W, plane, (size_t)blockIdx.x * 64 + wave * 4, 4, lane, acc);
+    if (acc[0] == 123.456f) slabs[0] = acc[1];
+}
+// G2: 8-wave workgroups over a 64-tile chunk laid out [rb][8 kb]: every wave streams 8 contiguous tiles (the chunk_cols = 128 layout)
+__global__ void __launch_bounds__(512, 4) k_cc128(float* W, size_t plane, float* slabs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    stream_tiles<2>(W, plane, (size_t)blockIdx.x * 64 + wave * 8, 8, lane, acc);
+    if (acc[0] == 123.456f) slabs[0] = acc[1];
+}
+
 template <int U>
 __global__ void __launch_bounds__(64, 4) k_wave(float* W, size_t plane, float* slabs) {
     const int lane = threadIdx.x;
@@ -205,6 +220,8 @@ int main(int argc, char** argv) {
         RUN("P", hipLaunchKernelGGL(k_plain, dim3(nchunks), dim3(512), 0, 0, W, plane, slabs));
         RUN("RO", hipLaunchKernelGGL(k_ro, dim3(nchunks), dim3(512), 0, 0, W, plane, slabs));
         RUN("WO", hipLaunchKernelGGL(k_wo, dim3(nchunks), dim3(512), 0, 0, W, plane, slabs));
+        RUN("K", hipLaunchKernelGGL(k_wide, dim3(nchunks / 2), dim3(1024), 0, 0, W, plane, slabs));
+        RUN("G2", hipLaunchKernelGGL(k_cc128, dim3(nchunks / 2), dim3(512), 0, 0, W, plane, slabs));
         RUN("U4", hipLaunchKernelGGL((k_wg<4, 0, 1, false>), dim3(nchunks), dim3(512), 0, 0, W, plane, idx, rows, slabs));
     }
     return 0;
