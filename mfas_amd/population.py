@@ -290,8 +290,13 @@ class StepModel:
     def share_us(self, confs, costs) -> float:
         if not len(confs):
             return 0.0
+        cap = self.resident[-1][0] if self.resident else 0.0       # resident capacity in canonical candidates (the largest point measured)
         if self.device is None:                 # no device to ask for layouts: price the share as one round
-            return self.round_us(costs, self.hp.R <= 16 and len(confs) <= (self.resident[-1][0] if self.resident else 0))
+            return self.round_us(costs, self.hp.R <= 16 and len(confs) <= cap)
+        if self.hp.R > 16 or not self.resident:
+            return self.round_us(costs, False)  # no resident schedule in this geometry: one launch-per-phase population
+        if max(len(confs), float(sum(costs)) / float(self.rep_cost)) <= 0.8 * cap:
+            return self.round_us(costs, True)   # comfortably inside the resident capacity: no layout query needed (0.2 ms each)
         return sum(self.round_us([costs[i] for i in pos], res) for pos, res in split_rounds(self.hp, confs, self.device))
 
     def describe(self):
