@@ -244,6 +244,14 @@ __device__ __forceinline__ void adam4(f32x4& w, f32x4& m, f32x4& v, const f32x4 
         w[q] = w1; m[q] = m1; v[q] = v1;
     }
 }
+// (the scalar-argument form the tile loops call: the -DMFAS_ADAM_LIBRARY_FORMS build of the whole library — __graft_entry__.build_variant
+//  — trains with sqrtf() and operator/ in every kernel, for fidelity runs and for the in-situ bit-identity test)
+__device__ __forceinline__ void adam4(f32x4& w, f32x4& m, f32x4& v, const f32x4 g, const float ss, const float bc2s, const float w1,
+                                      const float b2, const float w2, const float eps, const float wd) {
+    AdamC c;
+    c.ss = ss; c.bc2s = bc2s; c.w1 = w1; c.b2 = b2; c.w2 = w2; c.eps = eps; c.wd = wd;
+    adam4(w, m, v, g, c);
+}
 #else
 __device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, const AdamC& c) {
     g = g + c.wd * w;

@@ -230,3 +230,46 @@ def test_device_side_torch_streams_equal_the_module_draws(dev, monkeypatch):
         res[host] = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev)
     assert res[""] == res["1"]
     assert NS._DEVICE_STREAMS_OK.get(str(dev)) is True
+
+
+def test_written_out_adam_equals_the_library_forms_in_situ(dev):
+    """common.hip.h writes Adam's square root and divisions out as correctly-rounding fma sequences (tools/adam_exact.hip checks
+    them in isolation).  Here the WHOLE library is built a second time with -DMFAS_ADAM_LIBRARY_FORMS (sqrtf() and operator/ in
+    every kernel: sweep, resident units, chains) and both builds train the same populations — resident persistent schedule,
+    launch-per-phase lean chain, general chain with BatchNorm, fused two-group launches — from the same start: every parameter, both
+    Adam moments and all statistics must come out bit for bit the same."""
+    import hashlib
+    import __graft_entry__ as ge
+    lib = ge.build_variant("adamlib", ["-DMFAS_ADAM_LIBRARY_FORMS"])
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np, torch
+import mfas_amd as M
+from oracle import np_oracle as O
+dev = torch.device("cuda:0")
+tr = M.FeatureTable.synthetic(640, 1, dev, torch.bfloat16, snr=0.3)
+dv = M.FeatureTable.synthetic(160, 2, dev, torch.bfloat16, snr=0.3)
+rng = np.random.default_rng(2)
+h = hashlib.sha256()
+for R, B, bn, K in ((16, 20, False, 6), (16, 16, True, 40), (128, 16, True, 3), (128, 20, True, 12), (64, 16, False, 5)):
+    hp = M.Hyper(R=R, B=B, bn=bn, drpt=0.5, alphas=(R == 64), tap_bits=16)
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in rng.integers(1, 5, K)]
+    pop = M.Population(hp, confs, dev, drop_seeds=list(range(K)))
+    pop.init(list(range(1, K + 1)))
+    nb = -(-640 // B)
+    stats, status = pop.train(tr, dv, 2, O.eta_sequence(1e-3, 1e-6, 1, 2, 640 / B, 2 * nb))
+    assert not status.any()
+    h.update(stats.tobytes())
+    for k in range(K):
+        for plane in range(3):
+            h.update(pop.get_params(k, plane).cpu().numpy().tobytes())
+    pop.close()
+print("DIGEST", h.hexdigest())
+""" % ROOT
+    out = {}
+    for name, env in (("written-out", {}), ("library", {"MFAS_LIB": lib})):
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, (name, res.stdout[-1000:], res.stderr[-3000:])
+        out[name] = [l for l in res.stdout.splitlines() if l.startswith("DIGEST")][-1]
+    assert out["written-out"] == out["library"], out
