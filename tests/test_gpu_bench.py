@@ -33,19 +33,20 @@ def run_bench(extra, timeout=900):
     return json.loads(lines[0])
 
 
-def test_bench_starts_its_own_ranks(dev):
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_starts_its_own_ranks(dev, world):
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment — the way the driver invokes `--gpus 1` — starts two ranks
     itself (gloo here: both on this box's one GPU; nccl = RCCL on a multi-GPU node), prints one line, and that line carries the
     weak headline AND the strong-scaling workloads with per-rank seconds and shares."""
-    line = run_bench(["--gpus", "2", "--backend", "gloo", "--pop", "3", "--steps", "1", "--warmup", "1"] + TINY)
-    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "gloo"
-    assert line["scaling"] == "weak" and line["config"]["candidates_total_per_step"] == 6 and line["value"] > 0
-    assert len(line["config"]["rank_seconds"]) == 2
+    line = run_bench(["--gpus", str(world), "--backend", "gloo", "--pop", "3", "--steps", "1", "--warmup", "1"] + TINY)
+    assert line["n_gpus"] == world and line["config"]["rccl_ranks"] == world and line["config"]["backend"] == "gloo"
+    assert line["scaling"] == "weak" and line["config"]["candidates_total_per_step"] == 3 * world and line["value"] > 0
+    assert len(line["config"]["rank_seconds"]) == world
     strong = line["config"]["strong"]
     for name, K in (("c2", 16), ("c3", 50)):
         s = strong[name]
-        assert s["candidates"] == K and sum(s["share"]) == K and len(s["rank_seconds"]) == 2 and s["cand_per_s"] > 0
-        assert 1 <= s["ranks_used"] <= 2 and s["step_time_model"]["calibrated"] is True      # the sharder's model was measured on THIS box
+        assert s["candidates"] == K and sum(s["share"]) == K and len(s["share"]) == len(s["rank_seconds"]) == world and s["cand_per_s"] > 0
+        assert 1 <= s["ranks_used"] <= world and s["step_time_model"]["calibrated"] is True      # the sharder's model was measured on THIS box
         assert len(s["step_time_model"]["resident_us"]) >= 2 and all(us > 1.0 for _, us in s["step_time_model"]["resident_us"])
     assert line["config"]["small_pop"] is None and "cpu_baseline" not in line
 
