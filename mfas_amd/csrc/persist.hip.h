@@ -114,6 +114,21 @@ __device__ __forceinline__ void stage_table16(uint16_t* dst, int S16, const void
     }
 }
 
+// LDS-DMA staging of 16-bit table rows (round 4, -DMFAS_RES_DMA builds / default: see MFAS_RES_DMA below).  Each wave stages exactly
+// the k-blocks IT multiplies with — one `global_load_lds_dwordx4` per k-block and batch: 32 rows x 32 bytes = the 64 lanes' 16-byte
+// pieces, landing contiguously in a k-block-major LDS image [kb][row][16 halves] — so the copy needs no VGPRs, no LDS-store pass and
+// NO workgroup barrier (a wave only ever reads what it wrote itself), and it is asynchronous: issued right after a unit's step, it
+// lands while the workgroup already serves its other unit or waits for the chain.  Rows beyond the batch read a zeroed line.
+// (M0 = the wave-uniform LDS destination; saved and restored inside the statement: cdna_hip_programming.md, LDS-DMA recipe.)
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#ifndef MFAS_RES_DMA
+#define MFAS_RES_DMA 1
+#endif
+
 struct ResUnit {              // wave-uniform constants of one resident unit
     int32_t valid, index, cand, cell, kind, cc, nkb, S, width, k0;
     const void* tp;
@@ -179,21 +194,44 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
     const float a_w1 = sa.ac.w1, a_b2 = sa.ac.b2, a_w2 = sa.ac.w2, a_eps = sa.ac.eps, a_wd = sa.ac.wd;   // scalars, not a struct copy (common.hip.h adam4)
 
     // MFMA operand reads from a staged batch: one element (dW: A[i = column][k = batch row]) / four consecutive columns
+    constexpr bool DMA = X16 && (MFAS_RES_DMA != 0);      // k-block-major image [kb][row][16], staged per wave by LDS-DMA
     auto x1 = [&](const float* xb, int S, int row, int col) -> float {
-        if constexpr (X16) return cvt16(as_lds(reinterpret_cast<const uint16_t*>(xb))[row * S + col], dt);
+        if constexpr (DMA) return cvt16(as_lds(reinterpret_cast<const uint16_t*>(xb))[(((col >> 4) * Bp + row) << 4) + (col & 15)], dt);
+        else if constexpr (X16) return cvt16(as_lds(reinterpret_cast<const uint16_t*>(xb))[row * S + col], dt);
         else return as_lds(xb)[row * S + col];
     };
     auto x4of = [&](const float* xb, int S, int row, int col) -> f32x4 {
         if constexpr (X16) {
-            const u32x2 r = *as_lds(reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(xb) + row * S + col));
+            const int at = DMA ? ((((col >> 4) * Bp + row) << 4) + (col & 15)) : (row * S + col);
+            const u32x2 r = *as_lds(reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(xb) + at));
             return (f32x4){cvt16(r.x & 0xFFFFu, dt), cvt16(r.x >> 16, dt), cvt16(r.y & 0xFFFFu, dt), cvt16(r.y >> 16, dt)};
         } else {
             return *as_lds(reinterpret_cast<const f32x4*>(xb + row * S + col));
         }
     };
+    const uint32_t lds_base = (uint32_t)(uintptr_t)as_lds(lds);
+    const void* zeros = a.sync + (size_t)K * PERSIST_SYNC_STRIDE + 48;      // 64 bytes nobody writes during the launch (zeroed before it)
     auto stage = [&](const ResUnit& un, float* dst, int t) {     // rows of batch t -> LDS
         const int nv = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
-        if constexpr (X16)
+        if constexpr (DMA) {
+            // lane -> (row, 16-byte half of the row's 32-byte k-block); this wave's k-blocks only
+            const int r = lane >> 1, half = lane & 1;
+            const int32_t* ord = cand_order(sa.order, sa.g, un.gidx);
+            int64_t row = -1;
+            if (r < nv) row = ord ? (int64_t)ord[a.pos0 + (int64_t)t * a.B + r] : (int64_t)t * a.B + r;
+            const uint32_t dst0 = lds_base + (uint32_t)((dst - lds) << 2);
+            if (r < Bp) {
+#pragma unroll
+                for (int sidx = 0; sidx < NTR; ++sidx) {
+                    const int kb = wave + STEP_NW * sidx;
+                    if (kb < un.nkb) {
+                        const void* src = row >= 0 ? static_cast<const void*>(reinterpret_cast<const uint16_t*>(un.tp) + row * un.width + un.k0 + kb * 16 + half * 8)
+                                                   : zeros;
+                        glds16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(kb * Bp * 32)));
+                    }
+                }
+            }
+        } else if constexpr (X16)
             stage_table16(reinterpret_cast<uint16_t*>(dst), un.S, un.tp, un.width, un.k0, un.cc, cand_order(sa.order, sa.g, un.gidx), a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
         else
             stage_table(dst, un.S, un.tp, sa.tab.dtype, un.width, un.k0, un.cc, cand_order(sa.order, sa.g, un.gidx), a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
@@ -221,6 +259,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
     for (int u = 0; u < NU; ++u) {
         if (U[u].valid) {            // (wave-uniform, workgroup-uniform)
             stage(U[u], lds + res_xbo(U[u], 0), 0);
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the LDS-DMA copy is invisible to the compiler's counters)
             __syncthreads();
             f32x4 yacc[MB];
 #pragma unroll
@@ -301,6 +340,8 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 float gsc = 1.0f;
                 if (sa.g.alphas) gsc = ldc1<true>(sa.stepbuf + un.gsco);
                 const float a_ss = a.scal[2 * (int64_t)(a.gstep0 + t)], a_bc2s = a.scal[2 * (int64_t)(a.gstep0 + t) + 1];
+                // this wave's own LDS-DMA copies (batch t+1, requested after the unit's previous step) have landed: nothing else reads them
+                if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 f32x4 yacc[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
