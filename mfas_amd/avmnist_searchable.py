@@ -33,6 +33,7 @@ def av_hyper(args) -> Hyper:
 class Searchable_Audio_Image_Net(Searchable_Skeleton_Image_Net):
     """conf rows: [audio tap 0..4, image tap 0..2, non-linearity].  Attributes as in the reference (:191-200):
     ``conf, args, rgbnet, audnet, alphas, fusion_layers, central_classifier``."""
+    _construction_is_standard = False      # ([Linear, nl(, Dropout)] cells built by its own _create_fc_layers: candidates are initialised through the module)
 
     def __init__(self, args, conf):
         super().__init__(args, conf)

@@ -117,6 +117,10 @@ class Searchable_Skeleton_Image_Net(nn.Module):
 
     conf: one row per fusion cell: [ske tap, rgb tap, non-linearity (0 ReLU / 1 Sigmoid / 2 LeakyReLU)].
     """
+    # construction draws torch's generator exactly like initial_flat_params restates it (per cell Linear weight, bias; classifier;
+    # then the alphas): train_sampled_models may then initialise candidates of this class without building modules.  A subclass that
+    # constructs differently (other layers, another order) sets this to False.
+    _construction_is_standard = True
 
     def __init__(self, args, conf):
         super().__init__()
@@ -470,23 +474,23 @@ def torch_init_bounds(conf, hp) -> np.ndarray:
 _DEVICE_STREAMS_OK = {}      # device -> the device-side Mersenne-Twister init reproduces torch's CPU draws on this host (checked once)
 
 
-def _init_population_device_streams(pop, args, confs, group, hp, seed_base, device) -> bool:
+def _init_population_device_streams(pop, args, confs, group, hp, seed_base, device, searchable_type) -> bool:
     """The default initialisation, generated on the GPU: mfas_population_init_torch_streams runs torch's own generator
     (at::mt19937 + uniform_real_distribution<float>) per candidate under the seeds the host path uses.  Verified ONCE per process
     and device against torch itself — the first candidate's flat parameters must equal initial_flat_params bit for bit (torch's CPU
     kernels fuse x * (hi - lo) + lo into one fma on AVX2 / AVX512 hosts; a build that does not would differ in last bits) — and
     abandoned for the host path when that check fails (MFAS_HOST_INIT=1 forces the host path)."""
     import os
-    key = str(device)
+    key = (str(device), searchable_type.__name__)
     if os.environ.get("MFAS_HOST_INIT") or _DEVICE_STREAMS_OK.get(key) is False:
         return False
     seeds = [(seed_base + 2 + i) & 0xFFFFFFFFFFFFFFFF for i in group]
     bounds = np.stack([torch_init_bounds(confs[i], hp) for i in group])
     pop.init_torch_streams(seeds, bounds)
     if key not in _DEVICE_STREAMS_OK:
-        g = torch.Generator()
-        g.manual_seed(seed_base + 2 + group[0])
-        want = initial_flat_params(args, confs[group[0]], hp, generator=g)
+        with torch.random.fork_rng(devices=[]):           # the check builds the real module ONCE per class and device
+            torch.manual_seed(seed_base + 2 + group[0])
+            want = searchable_type(args, confs[group[0]]).flat_params()
         ok = bool(torch.equal(pop.get_params(0).cpu(), want))
         _DEVICE_STREAMS_OK[key] = ok
         if not ok:
@@ -524,7 +528,7 @@ def _init_population_from_torch(pop, args, confs, group, hp, seed_base, searchab
     if nthreads > 4:
         torch.set_num_threads(4)
     try:
-        if return_model or searchable_type is not Searchable_Skeleton_Image_Net:
+        if return_model or not getattr(searchable_type, "_construction_is_standard", False):
             for j, i in enumerate(group):
                 with torch.random.fork_rng(devices=[]):
                     torch.manual_seed(seed_base + 2 + i)   # world-size independent per-candidate stream
@@ -648,8 +652,8 @@ def _train_sampled_models(sampled_configurations, searchable_type, dataloaders, 
                         mods[i] = m
                 elif getattr(args, "engine_init", "torch") == "device":
                     pop.init([(seed_base + 2 + i) & 0x7FFFFFFF for i in group])
-                elif (return_model or searchable_type is not Searchable_Skeleton_Image_Net
-                      or not _init_population_device_streams(pop, args, confs, group, hp, seed_base, device)):
+                elif (return_model or not getattr(searchable_type, "_construction_is_standard", False)
+                      or not _init_population_device_streams(pop, args, confs, group, hp, seed_base, device, searchable_type)):
                     _init_population_from_torch(pop, args, confs, group, hp, seed_base, searchable_type, return_model, mods, device)
                 if getattr(args, "verbose", False):
                     print("Now training: ")

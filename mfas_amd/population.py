@@ -232,13 +232,21 @@ def split_rounds(hp, confs, device, chunk_cols: int = 0, min_candidates: int = 1
         return [(everything, True)]
     if n < min_candidates:
         return [(everything, False)]
+    # With per-candidate sample orders (the default) a launch-per-phase population of R <= 16 has no tap-major sweep to fall back on
+    # (no two candidates read the same rows): resident rounds win at EVERY size (R=16, B=20 on MI355X: 128 / 512 conf-4 candidates
+    # 189 / 200 cand/s launch-per-phase against 283-321 in rounds of 28), so the share is cut into as many rounds as it takes.  With a
+    # shared order the tap-major sweep is as fast as the rounds from ~64 candidates on: at most four rounds, the last >= 60 % full.
+    max_rounds = 1 << 30 if hp.order_per_candidate else 4
     rounds, rest = [], everything
-    while rest and len(rounds) < 4:
+    while rest and len(rounds) < max_rounds:
         if resident(rest):
             rounds.append(rest)
             rest = []
             break
         lo, hi, best = 1, len(rest) - 1, 0          # largest resident prefix of `rest`
+        if rounds and len(rounds[-1]) < len(rest) and resident(rest[:len(rounds[-1])]):
+            lo, best = len(rounds[-1]) + 1, len(rounds[-1])          # (later rounds: start from the previous round's size)
+            hi = min(hi, best + 2)
         while lo <= hi:
             mid = (lo + hi) // 2
             if resident(rest[:mid]):
@@ -247,7 +255,7 @@ def split_rounds(hp, confs, device, chunk_cols: int = 0, min_candidates: int = 1
                 hi = mid - 1
         if best == 0:
             break
-        if not rounds:
+        if not rounds and not hp.order_per_candidate:
             nr = -(-len(rest) // best)
             last = len(rest) - (nr - 1) * best
             if nr > 4 or (nr >= 3 and last < 0.6 * best):
