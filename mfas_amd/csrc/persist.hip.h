@@ -114,7 +114,10 @@ __device__ __forceinline__ void stage_table16(uint16_t* dst, int S16, const void
     }
 }
 
-// LDS-DMA staging of 16-bit table rows (round 4, -DMFAS_RES_DMA builds / default: see MFAS_RES_DMA below).  Each wave stages exactly
+// LDS-DMA staging of 16-bit table rows (round 4; OPT-IN: the -DMFAS_RES_DMA=1 build variant, __graft_entry__.build_variant("dma", ...)).
+// Measured on MI355X (profiles/r04_resident_lds_dma_ab.log): +1-2 % at 24-28 equal-sized candidates, but -4...-10 % (and noisy) on
+// mixed-depth populations of 28 — what the search issues — and nothing below 16 candidates: the default stays the cooperative
+// register staging.  Each wave stages exactly
 // the k-blocks IT multiplies with — one `global_load_lds_dwordx4` per k-block and batch: 32 rows x 32 bytes = the 64 lanes' 16-byte
 // pieces, landing contiguously in a k-block-major LDS image [kb][row][16 halves] — so the copy needs no VGPRs, no LDS-store pass and
 // NO workgroup barrier (a wave only ever reads what it wrote itself), and it is asynchronous: issued right after a unit's step, it
@@ -126,7 +129,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 #ifndef MFAS_RES_DMA
-#define MFAS_RES_DMA 1
+#define MFAS_RES_DMA 0
 #endif
 
 struct ResUnit {              // wave-uniform constants of one resident unit

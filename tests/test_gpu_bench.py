@@ -274,3 +274,15 @@ print("DIGEST", h.hexdigest())
         assert res.returncode == 0, (name, res.stdout[-1000:], res.stderr[-3000:])
         out[name] = [l for l in res.stdout.splitlines() if l.startswith("DIGEST")][-1]
     assert out["written-out"] == out["library"], out
+
+
+def test_lds_dma_staging_variant(dev):
+    """The -DMFAS_RES_DMA=1 build variant (resident units stage their 16-bit rows by per-wave LDS-DMA into a k-block-major image, no
+    barrier; opt-in: measured a wash to a loss) must train bit-identically to the launch-per-phase schedule like the default
+    build does: the persistent-schedule tests run on it in a subprocess."""
+    import __graft_entry__ as ge
+    lib = ge.build_variant("dma", ["-DMFAS_RES_DMA=1"])
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                          "persistent_resident_schedule_bit_identical_full_size or (persistent_schedule_fuzz_bit_identical and (0 or 7 or 13))"],
+                         env=dict(os.environ, MFAS_LIB=lib), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0 and " passed" in res.stdout and "failed" not in res.stdout, (res.stdout[-2000:], res.stderr[-2000:])
