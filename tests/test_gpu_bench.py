@@ -286,3 +286,31 @@ def test_lds_dma_staging_variant(dev):
                           "persistent_resident_schedule_bit_identical_full_size or (persistent_schedule_fuzz_bit_identical and (0 or 7 or 13))"],
                          env=dict(os.environ, MFAS_LIB=lib), capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0 and " passed" in res.stdout and "failed" not in res.stdout, (res.stdout[-2000:], res.stderr[-2000:])
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_device_side_torch_streams_fuzz(dev, case):
+    """Random geometries (odd tap widths, R, classes, depth, huge / tiny seeds) for the device-side construction draws: equal to
+    building the module under torch.manual_seed(seed), bit for bit, for every candidate."""
+    import mfas_amd as M
+    from mfas_amd import ntu_searchable as NS
+    from types import SimpleNamespace
+    rng = np.random.default_rng(500 + case)
+    widths = [16, 24, 40, 64, 100, 128, 200, 256, 1000]
+    args = SimpleNamespace(vid_len=(8, 32), num_outputs=int(rng.choice([2, 7, 23, 60, 101])), drpt=0.5,
+                           inner_representation_size=int(rng.choice([1, 8, 16, 24, 100, 128, 256])), batchnorm=bool(rng.integers(0, 2)),
+                           alphas=bool(rng.integers(0, 2)), multitask=False, batchsize=16,
+                           s_sizes=tuple(int(x) for x in rng.choice(widths, 4)), v_sizes=tuple(int(x) for x in rng.choice(widths, 4)))
+    hp = M.Hyper.from_args(args)
+    K = int(rng.integers(1, 40))
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in rng.integers(1, 5, K)]
+    seeds = [int(x) for x in rng.integers(0, 2 ** 63 - 1, K)]
+    seeds[0] = 0
+    pop = M.Population(hp, confs, dev)
+    pop.init_torch_streams(seeds, np.stack([NS.torch_init_bounds(c, hp) for c in confs]))
+    for k in rng.permutation(K)[:6]:
+        torch.manual_seed(seeds[k])
+        want = NS.Searchable_Skeleton_Image_Net(args, confs[k]).flat_params()
+        got = pop.get_params(int(k)).cpu()
+        assert torch.equal(got, want), (case, int(k), int((got != want).sum()), got.numel())
+    pop.close()
