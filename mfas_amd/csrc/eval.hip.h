@@ -16,17 +16,58 @@ struct EvalArgs {
     DevStats* stats;      // optional: dev_corr / dev_loss of stats[cand*E + epoch]
     long long* corr_out;  // optional single counter
     const float* pos_w;   // loss_mode 1
+    int32_t nblk, ncand;  // row tiles per candidate, candidates of this launch (the 1-D grid of the B3 build)
 };
 
 #define EVAL_CE 128   // staged feature columns per pass
 
 // MSP: 0, or the number of row blocks (1 / 2) when the m-blocks are split over the waves.  XB (with MSP): bf16 table rows stay 16-bit
 // in the LDS tile (half the store instructions, no store conflicts: 8 consecutive lanes write 128 contiguous bytes) and are widened by
-// the wave that reads them (each element is read by exactly one wave under the split)
-template <int MBE, int NRBW, int MSP = 0, bool XB = false>
-__global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs a) {
+// the wave that reads them (each element is read by exactly one wave under the split).
+// B3 (bf16 tables, two row blocks per wave: R = 72 .. 128): the feature products run on the bf16 matrix pipe at 16x the f32 rate and
+// stay exact — the table rows ARE bf16, and every f32 weight is split into three bf16 terms hi + mid + lo that sum to it exactly
+// (8 + 8 + 8 significant bits, by truncation), so each of the three v_mfma_f32_16x16x32_bf16 per k-block pair accumulates exact
+// products in f32 like the f32 MFMA does; only the summation order differs (hi terms, then mid, then lo, per 32 columns).
+// The rows stay 16-bit in LDS and are the A operand as they lie.  Cell-to-cell and head products (f32 activations) keep the f32 MFMA.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// two f32 weight tiles (k-blocks kA, kB of one row block; lane: row l15, k = 4 lg .. 4 lg + 3 of each) -> three B operands
+__device__ __forceinline__ void split3_bf16(const f32x4 wA, const f32x4 wB, u32x4& hi, u32x4& mid, u32x4& lo) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float w = e < 4 ? wA[e] : wB[e - 4];
+        h[e] = __float_as_uint(w) & 0xFFFF0000U;
+        const float r1 = w - __uint_as_float(h[e]);          // exact: <= 16 significant bits left
+        m[e] = __float_as_uint(r1) & 0xFFFF0000U;
+        const float r2 = r1 - __uint_as_float(m[e]);         // exact: <= 8 significant bits left = one bf16
+        l[e] = __float_as_uint(r2);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                            // element 2e in the low half, 2e + 1 in the high half
+        hi[e] = (h[2 * e] >> 16) | h[2 * e + 1];
+        mid[e] = (m[2 * e] >> 16) | m[2 * e + 1];
+        lo[e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xFFFF0000U);
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16_k32(const u32x4 a8, const u32x4 b8, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), c, 0, 0, 0);
+}
+
+template <int MBE, int NRBW, int MSP = 0, bool XB = false, bool B3 = false>
+__global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1)) k_eval(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int cand = a.cand0 + blockIdx.y;
+    // B3: a 1-D grid whose consecutive workgroups (dealt round-robin to the 8 XCDs) belong to 8 different candidates, so that all
+    // row tiles of one candidate run on ONE XCD and its W (3.9 MB at R = 128, re-read by every tile) stays in that XCD's 4 MB L2
+    // instead of six candidates' W thrashing every L2; the candidates past the last full group of 8 keep the plain order
+    int cand_i = blockIdx.y, tile_i = blockIdx.x;
+    if constexpr (B3) {
+        const int per8 = 8 * a.nblk, id = blockIdx.x, grp = id / per8, r = id - grp * per8;
+        if (grp < (a.ncand >> 3)) { cand_i = grp * 8 + (r & 7); tile_i = r >> 3; }
+        else { const int rem = id - (a.ncand >> 3) * per8; cand_i = (a.ncand >> 3) * 8 + rem / a.nblk; tile_i = rem - (rem / a.nblk) * a.nblk; }
+    }
+    const int cand = a.cand0 + cand_i;
     const CandDev& cd = a.cands[cand];
     const Geo& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -40,7 +81,8 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
     // LDS kept to <= 80 KiB so that two workgroups share a CU (one stages features while the other runs MFMAs):
     // ONE activation buffer (extra barrier per cell) and the logits alias the feature staging tile.
     float* xs = lds;                     // [ME][SS]   feature staging tile; later the logits [ME][SC]
-    float* xo_l = xs + ME * (XB ? max((EVAL_CE + 8) / 2, SC) : max(SS, SC)); // [ME][SX]   out_{i-1} -> out_i (XB: the row tile is half as wide)
+    constexpr bool X16 = XB || B3;       // table rows stay 16-bit in the LDS tile
+    float* xo_l = xs + ME * (X16 ? max((EVAL_CE + 8) / 2, SC) : max(SS, SC)); // [ME][SX]   out_{i-1} -> out_i (16-bit rows: the row tile is half as wide)
     float* lg_l = xs;
     const float* W = a.plane;
     // wave -> (row block, m-blocks).  R >= 64: wave w owns row blocks w, w+4, ... and all MBE m-blocks of the rows.  With one or
@@ -49,13 +91,14 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
     // products in the same order, so the logits are bit-identical under either mapping.
     static_assert(MSP == 0 || (NRBW == 1 && (MSP == 1 || MSP == 2)), "m-block split: one or two row blocks");
     static_assert(!XB || MSP > 0, "16-bit LDS rows: with the m-block split only");
+    static_assert(!B3 || (NRBW == 2 && MSP == 0 && !XB), "bf16 x 3 products: the two-row-blocks-per-wave build");
     constexpr int SSH = EVAL_CE + 8;       // row stride of the 16-bit tile in elements: ds_read_b64 of (row l15, columns 4 lg ..) conflict-free
     uint16_t* xh = reinterpret_cast<uint16_t*>(lds);
     constexpr int NPI = MSP ? (MBE * MSP >= 4 ? MBE * MSP / 4 : 1) : MBE;        // accumulators (m-blocks) per wave and row block
     const int rbw = MSP ? wave % MSP : wave;                       // (NRBW == 1) this wave's row block
     const int mb0 = MSP ? wave / MSP : 0;
     constexpr int mbs = MSP ? 4 / MSP : 1;
-    const int64_t brow = a.row0 + (int64_t)blockIdx.x * ME;
+    const int64_t brow = a.row0 + (int64_t)tile_i * ME;
     const int nvalid = (int)min((int64_t)ME, a.row0 + a.nrows - brow);
 
     // register-staged table rows (16-bit tables, NRBW <= 2 path): e = tid + 256 u walks [ME rows][nc / 8 vectors of 8 columns]
@@ -85,7 +128,7 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
             if (vpr == 16) { b = e >> 4; c = (e & 15) << 3; }
             else { b = e / vpr; c = (e - b * vpr) << 3; }
             if (b < ME) {
-                if constexpr (XB) {
+                if constexpr (X16) {
                     *as_lds(reinterpret_cast<u32x4*>(xh + b * SSH + c)) = (u32x4){raw[u].x, raw[u].y, raw[u].z, raw[u].w};
                     continue;
                 }
@@ -144,10 +187,102 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
             // (weight chunk, k-block inside it) of this eval chunk's first k-block, carried along instead of dividing per tile
             const int nkb_c = cc >> 4;
             int wch = 0, wkb = 0;
+            // B3: the weight tiles of a chunk are requested a whole chunk ahead — each pair of tile registers is refilled with the
+            // next chunk's pair right after its split (no second register set).  k-blocks past the segment's end re-read tile 0 and
+            // a wave without a second row block (R < 128) works on its last one: no branch inside a full chunk, so that the
+            // compiler's wait counts are exact and no refill is waited for before its chunk comes up
+            f32x4 wt[(B3 ? EVAL_CE / 16 : 1)][NRBW];
+            // (wave-uniform addressing: segment base + tile offset in scalar registers, the lane's 16 bytes as the vector offset)
+            const float* wseg = W + cd.seg_off[i][sv];
+            int rbo[NRBW];
+#pragma unroll
+            for (int j = 0; j < NRBW; ++j) rbo[j] = min(__builtin_amdgcn_readfirstlane(wave) + 4 * j, nrb - 1) * nkb_c * 256;
+            // offsets of the EVAL_CE / 16 k-block tiles that start at k-block kb_ of weight chunk ch_ (row block 0); n_ok of them exist
+            auto tiles_ld = [&](int ch_, int kb_, const int n_ok, const int kbl, const int j) -> f32x4 {
+                kb_ += kbl;                                       // kbl < 8 <= 2 nkb_c: at most two wraps (chunks are >= 64 columns)
+                if (kb_ >= nkb_c) { kb_ -= nkb_c; ++ch_; }
+                if (kb_ >= nkb_c) { kb_ -= nkb_c; ++ch_; }
+                const int o = kbl < n_ok ? ch_ * Rp * cc + kb_ * 256 + rbo[j] : rbo[j];
+                return *reinterpret_cast<const f32x4*>(wseg + o + lane * 4);
+            };
+            if constexpr (B3) {
+                if (cols > 0) {          // first chunk: rows and tiles, in the order the loop refills them
+                    rows_load(tp, tw, 0, min(EVAL_CE, cols));
+#pragma unroll
+                    for (int kp = 0; kp < EVAL_CE / 32; ++kp)
+#pragma unroll
+                        for (int j = 0; j < NRBW; ++j) {
+                            wt[2 * kp][j] = tiles_ld(0, 0, min(EVAL_CE, cols) >> 4, 2 * kp, j);
+                            wt[2 * kp + 1][j] = tiles_ld(0, 0, min(EVAL_CE, cols) >> 4, 2 * kp + 1, j);
+                        }
+                }
+            }
             for (int c0 = 0; c0 < cols; c0 += EVAL_CE, wkb += EVAL_CE / 16) {
                 while (wkb >= nkb_c) { wkb -= nkb_c; ++wch; }
                 const int nc = min(EVAL_CE, cols - c0);
-                if constexpr (NRBW <= 2) {
+                if constexpr (B3) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    __syncthreads();
+                    rows_store(nc);
+                    __syncthreads();
+                    // the next chunk's rows (the last chunk requests its own again: no branch around the loads)
+                    const bool more = c0 + EVAL_CE < cols;
+                    const int nkn = more ? min(EVAL_CE, cols - c0 - EVAL_CE) >> 4 : 0;   // k-blocks of the next chunk
+                    rows_load(tp, tw, more ? c0 + EVAL_CE : c0, more ? nkn << 4 : nc);
+                    const int nkbl = nc >> 4;
+                    int nch = wch, nkb0 = wkb + EVAL_CE / 16;            // the next chunk's first k-block
+                    while (nkb0 >= nkb_c) { nkb0 -= nkb_c; ++nch; }
+                    auto rows8 = [&](const int k0, const bool two, u32x4 (&a8)[MBE]) {
+#pragma unroll
+                        for (int mb = 0; mb < MBE; ++mb) {
+                            const uint16_t* xr = xh + (mb * 16 + l15) * SSH + k0 * 16 + 4 * lg;
+                            const u32x2 r0 = *as_lds(reinterpret_cast<const u32x2*>(xr));
+                            u32x2 r1 = *as_lds(reinterpret_cast<const u32x2*>(xr + 16));     // (inside the tile's row stride either way)
+                            if (!two) r1 = (u32x2){0u, 0u};                                    // an odd last k-block: zeros on both operands
+                            a8[mb] = (u32x4){r0[0], r0[1], r1[0], r1[1]};
+                        }
+                    };
+                    auto prods = [&](const int j, const u32x4 (&a8)[MBE], const u32x4 hi, const u32x4 mid, const u32x4 lo) {
+#pragma unroll
+                        for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = mfma_bf16_k32(a8[mb], hi, acc[j][mb]);
+#pragma unroll
+                        for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = mfma_bf16_k32(a8[mb], mid, acc[j][mb]);
+#pragma unroll
+                        for (int mb = 0; mb < MBE; ++mb) acc[j][mb] = mfma_bf16_k32(a8[mb], lo, acc[j][mb]);
+                    };
+                    if (nkbl == EVAL_CE / 16) {
+#pragma unroll
+                        for (int kp = 0; kp < EVAL_CE / 32; ++kp) {
+                            const int k0 = 2 * kp;
+                            u32x4 a8[MBE];
+                            rows8(k0, true, a8);
+#pragma unroll
+                            for (int j = 0; j < NRBW; ++j) {
+                                u32x4 hi, mid, lo;
+                                split3_bf16(wt[k0][j], wt[k0 + 1][j], hi, mid, lo);
+                                wt[k0][j] = tiles_ld(nch, nkb0, nkn, k0, j);
+                                wt[k0 + 1][j] = tiles_ld(nch, nkb0, nkn, k0 + 1, j);
+                                prods(j, a8, hi, mid, lo);
+                            }
+                        }
+                    } else {                 // the segment's last, partial chunk: nothing to request
+#pragma unroll
+                        for (int kp = 0; kp < EVAL_CE / 32; ++kp) {
+                            const int k0 = 2 * kp;
+                            if (k0 < nkbl) {
+                                const bool two = k0 + 1 < nkbl;
+                                u32x4 a8[MBE];
+                                rows8(k0, two, a8);
+#pragma unroll
+                                for (int j = 0; j < NRBW; ++j) {
+                                    u32x4 hi, mid, lo;
+                                    split3_bf16(wt[k0][j], two ? wt[k0 + 1][j] : (f32x4){0.f, 0.f, 0.f, 0.f}, hi, mid, lo);
+                                    prods(j, a8, hi, mid, lo);
+                                }
+                            }
+                        }
+                    }
+                } else if constexpr (NRBW <= 2) {
                     // this chunk's weight tiles are requested BEFORE the feature staging so that their L2 latency
                     // overlaps the staging barriers (8 k-blocks x NRBW row blocks = up to 64 VGPRs)
                     f32x4 wt[EVAL_CE / 16][NRBW];
@@ -318,7 +453,7 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
             a.logits[(brow - a.row0 + b) * C + c] = lg_l[b * SC + c];
         }
     }
-    if (tid < ME) {   // ME <= 64: exactly wave 0
+    if (tid < ME) {   // one lane per row (ME <= 64: wave 0)
         float loss = 0.f;
         long long corr = 0;
         if (tid < nvalid && g.loss_mode == 1) {
@@ -369,7 +504,7 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : 1) k_eval(const EvalArgs 
             loss += __shfl_xor(loss, o);
             corr += __shfl_xor(corr, o);
         }
-        if (tid == 0) {
+        if (lane == 0) {
             if (a.stats) {
                 DevStats& st = a.stats[(int64_t)cand * a.E + a.epoch];
                 atomicAdd(reinterpret_cast<unsigned long long*>(&st.dev_corr), (unsigned long long)corr);

@@ -128,6 +128,7 @@ struct mfas_population {
     size_t lds_step = 0, lds_chain = 0, lds_eval = 0;
     bool vec_in_lds = false;
     int mbe = 4, nrbw = 1;
+    bool eval_b3_ok = true;   // every feature segment is cut into chunks of >= 64 columns (k_eval's bf16 x 3 build addresses tiles under that)
     bool yf_in_lds = false;
     bool lean_chain = false;        // chain_lean (R <= 16, C <= 64, B <= 32) in standalone and fused launches
     bool nontemporal = false;
@@ -487,6 +488,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                 const int nun = (nch + grp - 1) / grp;
                 c.seg_off[i][j] = plane_off;
                 c.seg_cc[i][j] = cc;
+                if (j < 2 && cc < 64) p->eval_b3_ok = false;
                 c.seg_cols[i][j] = cols_p;
                 if (j == 0) c.nch_s[i] = nun;
                 if (j == 1) c.nch_v[i] = nun;
@@ -1036,15 +1038,18 @@ static int check_table(const mfas_population* p, const mfas_table* t, bool need_
     return MFAS_OK;
 }
 
-template <int MBE, int NRBW, int MSP = 0, bool XB = false>
+template <int MBE, int NRBW, int MSP = 0, bool XB = false, bool B3 = false>
 static hipError_t launch_eval_t(mfas_population* p, const EvalArgs& a, int ncand, hipStream_t st) {
     const int ME = MBE * 16;
     // (16-bit row tile: half the width, more workgroups per CU)
-    const size_t lds = XB ? ((size_t)ME * std::max((EVAL_CE + 8) / 2, p->g.Cp + 4) + (size_t)ME * (p->g.Rp + 8)) * 4 : p->lds_eval;
-    hipError_t e = set_lds(k_eval<MBE, NRBW, MSP, XB>, lds);
+    const size_t lds = (XB || B3) ? ((size_t)ME * std::max((EVAL_CE + 8) / 2, p->g.Cp + 4) + (size_t)ME * (p->g.Rp + 8)) * 4 : p->lds_eval;
+    hipError_t e = set_lds(k_eval<MBE, NRBW, MSP, XB, B3>, lds);
     if (e != hipSuccess) return e;
     const unsigned nblk = (unsigned)((a.nrows + ME - 1) / ME);
-    hipLaunchKernelGGL((k_eval<MBE, NRBW, MSP, XB>), dim3(nblk, ncand), dim3(256), lds, st, a);
+    EvalArgs b = a;
+    b.nblk = (int32_t)nblk;
+    b.ncand = ncand;
+    hipLaunchKernelGGL((k_eval<MBE, NRBW, MSP, XB, B3>), B3 ? dim3(nblk * (unsigned)ncand) : dim3(nblk, ncand), dim3(256), lds, st, b);
     return hipGetLastError();
 }
 
@@ -1056,6 +1061,12 @@ static hipError_t launch_eval(mfas_population* p, const EvalArgs& a, int ncand, 
         return xb ? launch_eval_t<M, 1, S, true>(p, a, ncand, st) : launch_eval_t<M, 1, S, false>(p, a, ncand, st);
     EV_SPLIT(4, 1) EV_SPLIT(4, 2) EV_SPLIT(2, 1) EV_SPLIT(2, 2) EV_SPLIT(1, 1) EV_SPLIT(1, 2)
 #undef EV_SPLIT
+    // two row blocks per wave (R = 72 .. 128), bf16 tables: exact bf16 x 3 feature products on the bf16 matrix pipe
+    if (a.tab.dtype == MFAS_DT_BF16 && p->nrbw == 2 && p->eval_b3_ok && !getenv("MFAS_EVAL_NO_B3")) {
+        if (p->mbe == 4) return launch_eval_t<4, 2, 0, false, true>(p, a, ncand, st);
+        if (p->mbe == 2) return launch_eval_t<2, 2, 0, false, true>(p, a, ncand, st);
+        if (p->mbe == 1) return launch_eval_t<1, 2, 0, false, true>(p, a, ncand, st);
+    }
 #define EV_CASE(M, N) if (p->mbe == M && p->nrbw == N) return launch_eval_t<M, N>(p, a, ncand, st);
     EV_CASE(4, 1) EV_CASE(4, 2) EV_CASE(4, 4) EV_CASE(4, 8)
     EV_CASE(2, 1) EV_CASE(2, 2) EV_CASE(2, 4) EV_CASE(2, 8)

@@ -744,3 +744,56 @@ def test_small_r_eval_mapping_is_bit_identical(dev, R, bn, alphas, K, mixed, dt)
     s_new, s_old = run(False), run(True)
     assert s_new.tobytes() == s_old.tobytes()
     assert (s_old["dev_corrects"] > 0).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,bn,alphas,K,mixed,widths", [(128, True, False, 5, False, None), (96, False, True, 6, True, None),
+                                                        (128, True, True, 4, True, (64, 208, 96, 1024)), (72, True, False, 3, True, (160, 64, 512, 80))])
+def test_bf16x3_eval_products_match_f32_products(dev, R, bn, alphas, K, mixed, widths):
+    """R = 72 .. 128 over bf16 tables: the dev pass runs the feature products as three bf16 MFMAs per 32 columns (every f32 weight =
+    hi + mid + lo bf16 terms, exactly; the rows are bf16 as stored) instead of f32 MFMAs (eval.hip.h, B3).  Every product is exact
+    either way and only the f32 summation order differs, so against the f32-product build of the same kernel (MFAS_EVAL_NO_B3=1):
+    logits agree to f32 round-off of a 1,000-term sum, the dev loss sums to 1e-6 relative, and the dev corrects may differ only
+    through a last-bit tie (<= 1 row per candidate and epoch).  Ragged dev size, mixed depths and taps, widths that leave an odd
+    last k-block / a partial last 128-column chunk, alphas incl. a sigma(alpha) == 1 cell, the eval-mode forward of the C ABI."""
+    import os
+    import torch
+    import mfas_amd as M
+    rng = np.random.default_rng(13)
+    N, Nd, E, B = 320, 700 + 29, 2, 16
+    kw = {} if widths is None else {"s_sizes": widths, "v_sizes": widths[::-1]}
+    hp = M.Hyper(R=R, C=60, B=B, bn=bn, drpt=0.5, alphas=alphas, tap_bits=16, **kw)
+    confs = [np.array(CONFS["c4"])] * K
+    if mixed:
+        confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in rng.integers(1, 5, K)]
+    okw = {} if widths is None else {"s_sizes": widths, "v_sizes": widths[::-1]}
+    ta = M.FeatureTable.from_numpy(O.synth_table(N, 3, snr=0.6, **okw), dev, torch.bfloat16)
+    tb = M.FeatureTable.from_numpy(O.synth_table(Nd, 4, snr=0.6, **okw), dev, torch.bfloat16)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, E * (-(-N // B)))
+    order = M.ntu_searchable.make_order(N, E, True, 5, dev)
+
+    def run(f32_products):
+        if f32_products:
+            os.environ["MFAS_EVAL_NO_B3"] = "1"
+        try:
+            pop = M.Population(hp, confs, dev, drop_seeds=list(range(40, 40 + K)))
+            pop.init(list(range(1, K + 1)))
+            if alphas:      # one cell with sigma(alpha) == 1 exactly
+                flat = pop.get_params(0, 0)
+                flat[0] = 30.0
+                pop.set_params(0, flat)
+            stats, status = pop.train(ta, tb, E, etas, order=order)
+            logits = [pop.forward(k, tb, row0=3, nrows=Nd - 5).cpu().numpy() for k in range(K)]
+            pop.close()
+        finally:
+            os.environ.pop("MFAS_EVAL_NO_B3", None)
+        assert not status.any()
+        return stats, logits
+
+    (s_new, l_new), (s_old, l_old) = run(False), run(True)
+    assert s_new["train_loss_sum"].tobytes() == s_old["train_loss_sum"].tobytes()      # training does not depend on the dev pass
+    assert np.abs(s_new["dev_corrects"] - s_old["dev_corrects"]).max() <= 1
+    np.testing.assert_allclose(s_new["dev_loss_sum"], s_old["dev_loss_sum"], rtol=1e-6)
+    for a, b in zip(l_new, l_old):
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max())
+    assert (s_old["dev_corrects"] > 0).any()
