@@ -70,8 +70,9 @@ def test_random_population_steps(case):
 def test_natural_schedules_vs_oracle(R, B, K):
     """Populations large enough to take the fused two-group schedule (general chain from 20 candidates, lean chain for
     40..223) and the unfused large-population schedule, with the tap-major sweep where it applies: a sample of candidates
-    against the oracle after a few steps.  From 28 candidates at R >= 128 the sweep's units span four 64-column chunks each
-    (multi-chunk units, one partial slab per unit — round 4); R = 256 takes the two-row-blocks-per-wave form of it."""
+    against the oracle after a few steps.  The cases from 28 candidates at R >= 128 are the sizes at which the opt-in multi-chunk sweep
+    units apply (MFAS_SUBCHUNKS, test_gpu_parity.py::test_multi_chunk_units); by default they run one-chunk units, R = 256 with two row
+    blocks per wave."""
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(R * 1000 + K)
     # (BatchNorm WITH dropout on ~20-row batches can hit a column whose batch variance is ~0: then 1/sqrt(var + eps)
