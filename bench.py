@@ -271,18 +271,60 @@ def main():
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a HIP device (torch.cuda.device_count() == 0)")
-    if world > ndev and a.backend == "nccl":
+    # N > 1: gloo and RCCL print connection banners to STDOUT; the contract is ONE line there.  Everything this process (and the
+    # libraries under it) writes to fd 1 goes to stderr instead, and rank 0 writes the JSON line to the original stdout at the end.
+    out_fd = None
+    if world > 1:
+        sys.stdout.flush()
+        out_fd = os.dup(1)
+        os.dup2(2, 1)
+    force_fail = bool(os.environ.get("MFAS_TEST_RCCL_FAIL"))     # test hook: exercise the fallback below on a 1-GPU box
+    if world > ndev and a.backend == "nccl" and not force_fail:
         raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, {ndev} visible (one process per GPU); "
                          "--backend gloo shares GPUs between ranks (tests only)")
     local = local % ndev
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    group, backend_note = None, None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
+        # The default group is gloo (control plane: barriers, the agreement below); the population's collectives — one gather of
+        # a few hundred bytes per call, two small broadcasts — go over an RCCL group created next to it and probed with one
+        # all_reduce.  If RCCL cannot start on this node (every rank agrees on that over gloo) the run still measures: the data
+        # path has no collective, so the gather falls back to gloo and the line says so in `backend` / `backend_note`.
+        gloo_ok = True
+        try:
             dist.init_process_group("gloo")
+        except Exception as e:          # noqa: BLE001 - no gloo control plane: RCCL alone, as the default group
+            if a.backend != "nccl":
+                raise
+            gloo_ok = False
+            backend_note = f"gloo control plane unavailable ({type(e).__name__}); RCCL is the default group"
+            dist.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl" and gloo_ok:
+            ok, err = 1, ""
+            try:
+                if force_fail and os.environ["MFAS_TEST_RCCL_FAIL"] != "real":     # ("real": let RCCL itself refuse the shared GPU)
+                    raise RuntimeError("forced by MFAS_TEST_RCCL_FAIL")
+                group = dist.new_group(backend="nccl")
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe, group=group)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"RCCL probe all_reduce returned {probe.item()} for {world} ranks")
+            except Exception as e:      # noqa: BLE001 - whatever RCCL raises, the fallback is the same
+                ok, err = 0, f"{type(e).__name__}: {str(e)[:200]}"
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                from mfas_amd import population as _pm
+                _pm.set_group(group)
+            else:
+                group = None
+                a.backend = "gloo"
+                backend_note = "RCCL could not start on this node; accuracies gathered over gloo" + (f" ({err})" if err else " (another rank failed)")
+                if rank == 0:
+                    print("bench.py: " + backend_note, file=sys.stderr)
 
     import mfas_amd as M
     from mfas_amd import ntu_searchable as NS
@@ -332,9 +374,9 @@ def main():
     def rank_times(dt_local):
         if world == 1:
             return [dt_local]
-        t = torch.tensor([dt_local], dtype=torch.float64, device=device if a.backend == "nccl" else "cpu")
+        t = torch.tensor([dt_local], dtype=torch.float64, device=device if dist.get_backend(group) == "nccl" else "cpu")
         allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
+        dist.all_gather(allt, t, group=group)
         return [float(x.item()) for x in allt]
 
     def profile_summary():
@@ -496,7 +538,7 @@ def main():
                        "candidates_total_per_step": total,
                        "candidates_per_gpu_per_step": (a.pop if a.total_pop == 0 else f"{total // world}..{-(-total // world)}"),
                        "parallelism": f"population-sharded x{world}",
-                       "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (a.backend if world > 1 else None),
+                       "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (a.backend if world > 1 else None), "backend_note": backend_note,
                        "rank_seconds": rank_dt,
                        "engine_init": a.engine_init, "engine_order": a.engine_order, "other_init": other_init, "other_order": other_order,
                        "mean_best_dev_acc" if not mm else "mean_best_dev_f1": float(np.mean(accs)),
@@ -513,7 +555,11 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline and not mm:     # (the CPU restatements are NTU-shaped: the c5 line carries none)
             line["cpu_baseline"] = cpu_baseline(train, dev, a)
-        print(json.dumps(line), flush=True)
+        if out_fd is None:
+            print(json.dumps(line), flush=True)
+        else:
+            sys.stdout.flush()
+            os.write(out_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

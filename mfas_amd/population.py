@@ -15,6 +15,17 @@ import torch
 import torch.distributed as dist
 
 
+_GROUP = None      # the process group the sharded calls talk over; None = torch.distributed's default group
+
+
+def set_group(group):
+    """Route the population's collectives (the accuracy gather, the seed / digest and calibration broadcasts) over `group`
+    instead of the default process group — e.g. an RCCL group created next to a gloo default group (bench.py does that so that a
+    node whose RCCL cannot start still measures: the data path has no collective, the gather is a few hundred bytes)."""
+    global _GROUP
+    _GROUP = group
+
+
 def dist_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -63,7 +74,7 @@ def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: i
         for i, a in zip(local_idx, local_acc):
             out[i] = float(a)
         return out if strict else (out, [0] if failed else [])
-    backend = dist.get_backend()
+    backend = dist.get_backend(_GROUP)
     dev = torch.device("cpu") if backend == "gloo" else (device or torch.device("cuda", torch.cuda.current_device()))
     if cap is None:
         cap = K
@@ -75,7 +86,7 @@ def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: i
     host[cap, 0] = -2.0 if failed else -3.0          # status row
     buf = torch.from_numpy(host).to(dev)
     allb = torch.empty((world * (cap + 1), 2), dtype=torch.float64, device=dev)   # rank-major concatenation
-    dist.all_gather_into_tensor(allb, buf)
+    dist.all_gather_into_tensor(allb, buf, group=_GROUP)
     out = [float("nan")] * K
     rows = allb.cpu().numpy().reshape(world, cap + 1, 2)
     bad = [r for r in range(world) if rows[r, cap, 0] == -2.0]
@@ -388,10 +399,10 @@ def step_model(hp, device=None) -> StepModel:
             warnings.warn(f"mfas_amd: step-time calibration failed ({e!r}); using the shipped constants")
             buf[:] = 0.0
     if use_device and world > 1:
-        backend = dist.get_backend()
+        backend = dist.get_backend(_GROUP)
         dev = torch.device("cpu") if backend == "gloo" else torch.device(device)
         t = torch.from_numpy(buf).to(dev)
-        dist.broadcast(t, src=0)
+        dist.broadcast(t, src=0, group=_GROUP)
         buf = t.cpu().numpy()
     if buf[0] == 1.0:
         calibrated = True
@@ -451,11 +462,11 @@ def broadcast_seed(seed: int, device=None, confs=None) -> int:
     rank, world = dist_info()
     if world == 1:
         return int(seed)
-    backend = dist.get_backend()
+    backend = dist.get_backend(_GROUP)
     dev = torch.device("cpu") if backend == "gloo" else (device or torch.device("cuda", torch.cuda.current_device()))
     mine = conf_digest(confs) if confs is not None else 0
     t = torch.tensor([int(seed), mine], dtype=torch.int64, device=dev)
-    dist.broadcast(t, src=0)
+    dist.broadcast(t, src=0, group=_GROUP)
     seed0, dig0 = (int(x) for x in t.cpu().tolist())
     if confs is not None and dig0 != mine:
         raise RuntimeError(f"rank {rank}: sampled_configurations differ from rank 0's (digest {mine:#x} vs {dig0:#x}); "

@@ -30,6 +30,8 @@ def run_bench(extra, timeout=900):
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]            # exactly ONE JSON line, from rank 0
+    if "--gpus" in extra:                                  # N > 1: and nothing else on stdout (gloo / RCCL banners go to stderr)
+        assert res.stdout.strip() == lines[0], res.stdout[-2000:]
     return json.loads(lines[0])
 
 
@@ -49,6 +51,31 @@ def test_bench_starts_its_own_ranks(dev, world):
         assert 1 <= s["ranks_used"] <= world and s["step_time_model"]["calibrated"] is True      # the sharder's model was measured on THIS box
         assert len(s["step_time_model"]["resident_us"]) >= 2 and all(us > 1.0 for _, us in s["step_time_model"]["resident_us"])
     assert line["config"]["small_pop"] is None and "cpu_baseline" not in line
+
+
+@pytest.mark.parametrize("mode", ["1", "real"])
+def test_bench_measures_when_rccl_cannot_start(dev, mode):
+    """The N > 1 line must not depend on RCCL coming up: the default group is gloo, the population's collectives go over an RCCL
+    group that is probed with one all_reduce, and when the probe fails on any rank every rank agrees over gloo to gather there
+    instead — the line says so.  mode "1": the failure is raised by the hook; mode "real": two ranks really create the RCCL
+    communicator on this box's ONE GPU and RCCL itself refuses it (ncclInvalidUsage: duplicate GPU) — on a box with two GPUs the
+    probe passes and the line stays on RCCL."""
+    env_keep = os.environ.get("MFAS_TEST_RCCL_FAIL")
+    os.environ["MFAS_TEST_RCCL_FAIL"] = mode
+    try:
+        line = run_bench(["--gpus", "2", "--backend", "nccl", "--pop", "2", "--steps", "1", "--warmup", "0", "--no-small-pop"] + TINY, timeout=600)
+    finally:
+        if env_keep is None:
+            os.environ.pop("MFAS_TEST_RCCL_FAIL", None)
+        else:
+            os.environ["MFAS_TEST_RCCL_FAIL"] = env_keep
+    assert line["n_gpus"] == 2 and line["value"] > 0 and len(line["config"]["rank_seconds"]) == 2
+    if mode == "real" and torch.cuda.device_count() >= 2:
+        assert line["config"]["backend"] == "nccl" and line["config"]["backend_note"] is None
+    else:
+        assert line["config"]["backend"] == "gloo" and "RCCL could not start" in line["config"]["backend_note"]
+        if mode == "real":
+            assert "NCCL" in line["config"]["backend_note"] or "nccl" in line["config"]["backend_note"]
 
 
 def test_bench_failing_rank_gives_nonzero_exit(dev):

@@ -242,6 +242,13 @@ try:
 except RuntimeError:
     drift = True
 assert drift == (rank != 0), (rank, drift)
+# the same collectives over an explicit group next to the default one (bench.py: an RCCL group beside a gloo control plane)
+g = dist.new_group(backend="gloo")
+P.set_group(g)
+out = P.gather_accuracies(mine, acc, K, cap=cap)
+assert np.allclose(out, [0.01 * (i + 1) for i in range(K)]), out
+assert P.broadcast_seed(99 + rank, confs=confs) == 99
+P.set_group(None)
 print("rank", rank, "ok", mine, flush=True)
 dist.destroy_process_group()
 """
