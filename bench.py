@@ -220,6 +220,8 @@ def self_spawn(n):
 
 
 def main():
+    # (before anything touches the HIP runtime: the host driver only supports dmabuf IPC, RCCL across processes needs this)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
