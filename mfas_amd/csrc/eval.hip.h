@@ -197,23 +197,30 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
             int rbo[NRBW];
 #pragma unroll
             for (int j = 0; j < NRBW; ++j) rbo[j] = min(__builtin_amdgcn_readfirstlane(wave) + 4 * j, nrb - 1) * nkb_c * 256;
-            // offsets of the EVAL_CE / 16 k-block tiles that start at k-block kb_ of weight chunk ch_ (row block 0); n_ok of them exist
-            auto tiles_ld = [&](int ch_, int kb_, const int n_ok, const int kbl, const int j) -> f32x4 {
-                kb_ += kbl;                                       // kbl < 8 <= 2 nkb_c: at most two wraps (chunks are >= 64 columns)
-                if (kb_ >= nkb_c) { kb_ -= nkb_c; ++ch_; }
-                if (kb_ >= nkb_c) { kb_ -= nkb_c; ++ch_; }
-                const int o = kbl < n_ok ? ch_ * Rp * cc + kb_ * 256 + rbo[j] : rbo[j];
-                return *reinterpret_cast<const f32x4*>(wseg + o + lane * 4);
+            // scalar offsets (row block 0) of the EVAL_CE / 16 k-block tiles that start at k-block kb_ of weight chunk ch_; n_ok of them
+            // exist, the others point at tile 0 (any chunk width: the walk wraps into the next weight chunk as often as it must)
+            int toff[EVAL_CE / 16];
+            auto tile_offsets = [&](int ch_, int kb_, const int n_ok) {
+#pragma unroll
+                for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl) {
+                    toff[kbl] = kbl < n_ok ? ch_ * Rp * cc + kb_ * 256 : 0;
+                    ++kb_;
+                    if (kb_ == nkb_c) { kb_ = 0; ++ch_; }
+                }
+            };
+            auto tiles_ld = [&](const int kbl, const int j) -> f32x4 {
+                return *reinterpret_cast<const f32x4*>(wseg + toff[kbl] + rbo[j] + lane * 4);
             };
             if constexpr (B3) {
                 if (cols > 0) {          // first chunk: rows and tiles, in the order the loop refills them
                     rows_load(tp, tw, 0, min(EVAL_CE, cols));
+                    tile_offsets(0, 0, min(EVAL_CE, cols) >> 4);
 #pragma unroll
                     for (int kp = 0; kp < EVAL_CE / 32; ++kp)
 #pragma unroll
                         for (int j = 0; j < NRBW; ++j) {
-                            wt[2 * kp][j] = tiles_ld(0, 0, min(EVAL_CE, cols) >> 4, 2 * kp, j);
-                            wt[2 * kp + 1][j] = tiles_ld(0, 0, min(EVAL_CE, cols) >> 4, 2 * kp + 1, j);
+                            wt[2 * kp][j] = tiles_ld(2 * kp, j);
+                            wt[2 * kp + 1][j] = tiles_ld(2 * kp + 1, j);
                         }
                 }
             }
@@ -232,6 +239,7 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
                     const int nkbl = nc >> 4;
                     int nch = wch, nkb0 = wkb + EVAL_CE / 16;            // the next chunk's first k-block
                     while (nkb0 >= nkb_c) { nkb0 -= nkb_c; ++nch; }
+                    tile_offsets(nch, nkb0, nkn);
                     auto rows8 = [&](const int k0, const bool two, u32x4 (&a8)[MBE]) {
 #pragma unroll
                         for (int mb = 0; mb < MBE; ++mb) {
@@ -260,8 +268,8 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
                             for (int j = 0; j < NRBW; ++j) {
                                 u32x4 hi, mid, lo;
                                 split3_bf16(wt[k0][j], wt[k0 + 1][j], hi, mid, lo);
-                                wt[k0][j] = tiles_ld(nch, nkb0, nkn, k0, j);
-                                wt[k0 + 1][j] = tiles_ld(nch, nkb0, nkn, k0 + 1, j);
+                                wt[k0][j] = tiles_ld(k0, j);
+                                wt[k0 + 1][j] = tiles_ld(k0 + 1, j);
                                 prods(j, a8, hi, mid, lo);
                             }
                         }

@@ -128,7 +128,6 @@ struct mfas_population {
     size_t lds_step = 0, lds_chain = 0, lds_eval = 0;
     bool vec_in_lds = false;
     int mbe = 4, nrbw = 1;
-    bool eval_b3_ok = true;   // every feature segment is cut into chunks of >= 64 columns (k_eval's bf16 x 3 build addresses tiles under that)
     bool yf_in_lds = false;
     bool lean_chain = false;        // chain_lean (R <= 16, C <= 64, B <= 32) in standalone and fused launches
     bool nontemporal = false;
@@ -488,7 +487,6 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                 const int nun = (nch + grp - 1) / grp;
                 c.seg_off[i][j] = plane_off;
                 c.seg_cc[i][j] = cc;
-                if (j < 2 && cc < 64) p->eval_b3_ok = false;
                 c.seg_cols[i][j] = cols_p;
                 if (j == 0) c.nch_s[i] = nun;
                 if (j == 1) c.nch_v[i] = nun;
@@ -1062,7 +1060,7 @@ static hipError_t launch_eval(mfas_population* p, const EvalArgs& a, int ncand, 
     EV_SPLIT(4, 1) EV_SPLIT(4, 2) EV_SPLIT(2, 1) EV_SPLIT(2, 2) EV_SPLIT(1, 1) EV_SPLIT(1, 2)
 #undef EV_SPLIT
     // two row blocks per wave (R = 72 .. 128), bf16 tables: exact bf16 x 3 feature products on the bf16 matrix pipe
-    if (a.tab.dtype == MFAS_DT_BF16 && p->nrbw == 2 && p->eval_b3_ok && !getenv("MFAS_EVAL_NO_B3")) {
+    if (a.tab.dtype == MFAS_DT_BF16 && p->nrbw == 2 && !getenv("MFAS_EVAL_NO_B3")) {
         if (p->mbe == 4) return launch_eval_t<4, 2, 0, false, true>(p, a, ncand, st);
         if (p->mbe == 2) return launch_eval_t<2, 2, 0, false, true>(p, a, ncand, st);
         if (p->mbe == 1) return launch_eval_t<1, 2, 0, false, true>(p, a, ncand, st);
