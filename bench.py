@@ -469,7 +469,7 @@ def main():
                            "kernel_algorithmic_gbs": (pby / (pms / nl * 1e-3) / 1e9) if nl else None,
                            "schedule": psched, "frac_of_hbm_bound": cps * gb / (HBM_PEAK_GBS * 1e9),
                            "mean_best_dev_acc": float(np.mean(kaccs))}
-    other_init = other_order = None
+    other_init = other_order = other_both = None
     if world == 1 and not a.no_small_pop and not a.mixed_confs:      # the same workload with the OTHER initialisation path / sample order, one call each
         oargs = SimpleNamespace(**vars(args))
         oargs.engine_init = "device" if a.engine_init == "torch" else "torch"
@@ -481,6 +481,14 @@ def main():
         nl, pms, _, _ = profile_summary()
         other_order = {"engine_order": oargs.engine_order, "cand_per_s": total / max(rt), "ms_per_step": max(rt) * 1e3,
                        "avg_launch_us": (pms / nl * 1e3) if nl else None}
+        # both switched = what rounds 1-3 timed (device hash init + one shared sample order): the like-for-like line across rounds
+        oargs = SimpleNamespace(**vars(args))
+        oargs.engine_init = "device" if a.engine_init == "torch" else "torch"
+        oargs.engine_order = "shared" if a.engine_order == "per_candidate" else "per_candidate"
+        _, rt = timed_calls(lambda: train_fn(confs, stype, loaders, oargs, device), 1)
+        nl, pms, _, _ = profile_summary()
+        other_both = {"engine_init": oargs.engine_init, "engine_order": oargs.engine_order, "cand_per_s": total / max(rt),
+                      "ms_per_step": max(rt) * 1e3, "avg_launch_us": (pms / nl * 1e3) if nl else None}
 
     if rank == 0:
         achieved = bytes_per_launch / (ms / n_launch * 1e-3) / 1e9 if n_launch else None
@@ -542,7 +550,7 @@ def main():
                        "parallelism": f"population-sharded x{world}",
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (a.backend if world > 1 else None), "backend_note": backend_note,
                        "rank_seconds": rank_dt,
-                       "engine_init": a.engine_init, "engine_order": a.engine_order, "other_init": other_init, "other_order": other_order,
+                       "engine_init": a.engine_init, "engine_order": a.engine_order, "other_init": other_init, "other_order": other_order, "other_both": other_both,
                        "mean_best_dev_acc" if not mm else "mean_best_dev_f1": float(np.mean(accs)),
                        "hbm_bound_cand_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / bytes_cand,
                        "frac_of_hbm_bound": total_trained / dt * bytes_cand / (HBM_PEAK_GBS * 1e9 * world),

@@ -91,6 +91,8 @@ def test_bench_single_gpu_line_carries_the_search_sized_workloads(dev):
     assert line["n_gpus"] == 1 and line["metric"].startswith("candidate-archs trained/sec") and line["unit"] == "candidates/s"
     assert line["config"]["engine_init"] == "torch" and line["config"]["other_init"]["engine_init"] == "device"
     assert line["config"]["engine_order"] == "per_candidate" and line["config"]["other_order"]["engine_order"] == "shared"     # the reference's shuffles are the default
+    ob = line["config"]["other_both"]                      # rounds 1-3's configuration, for the like-for-like comparison across rounds
+    assert ob["engine_init"] == "device" and ob["engine_order"] == "shared" and ob["cand_per_s"] > 0
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-9
     sp = line["config"]["small_pop"]
