@@ -53,6 +53,7 @@ struct StepArgs {
     SweepArgs sa;
     ChainArgs ca;
     int32_t nchain, _pad;
+    GatherArgs ga;          // nblocks gather workgroups (one per chain candidate) right after the chain blocks
 };
 
 template <int MB, bool NT, int WPE, bool LEAN>
@@ -63,10 +64,11 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
         if constexpr (LEAN) { chain_lean<MB, 0, (WPE >= 4 ? 8 : 16)>(a.ca, chain_step_of(a.ca), bid, lds); chain_lean_tail<MB, 0>(a.ca, chain_step_of(a.ca), bid, lds); }
         else chain_body<MB, false>(a.ca, chain_step_of(a.ca), bid, lds);
     }
-    else if (bid < a.nchain + a.sa.ntap) sweep_tap_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain, lds);
-    else if (!LEAN && a.sa.desc[bid - a.nchain - a.sa.ntap].nsub > 1)      // multi-chunk feature unit (general chain, 8 row blocks)
-        sweep_multi_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, sweep_step_of(a.sa), bid - a.nchain - a.sa.ntap, lds);
-    else sweep_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, sweep_step_of(a.sa), bid - a.nchain - a.sa.ntap, lds);
+    else if (bid < a.nchain + a.ga.nblocks) gather_body(a.ga, a.ga.cands[bid - a.nchain], a.sa.g, a.sa.tab, a.sa.order, (int)threadIdx.x);
+    else if (bid < a.nchain + a.ga.nblocks + a.sa.ntap) sweep_tap_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, bid - a.nchain - a.ga.nblocks, lds);
+    else if (!LEAN && a.sa.desc[bid - a.nchain - a.ga.nblocks - a.sa.ntap].nsub > 1)      // multi-chunk feature unit (general chain, 8 row blocks)
+        sweep_multi_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, sweep_step_of(a.sa), bid - a.nchain - a.ga.nblocks - a.sa.ntap, lds);
+    else sweep_body<MB, NT, SweepU<MB, WPE>::v>(a.sa, sweep_step_of(a.sa), bid - a.nchain - a.ga.nblocks - a.sa.ntap, lds);
 }
 
 // Same-group fused launch (small populations with the general chain, R >= 128): chain blocks AND sweep blocks of the SAME
@@ -145,6 +147,9 @@ struct mfas_population {
     bool persist = false;
     int n_cus = 0;
     uint32_t* d_red_cnt = nullptr;  // reduce-in-sweep arrival counters [K][4] (small populations, general chain)
+    int lp_group = 1;               // chunks per sweep unit of this layout (multi-chunk units: opt-in)
+    char* d_gather = nullptr;       // gathered rows [K][2 parities][taps][Bp][width] (two-group schedule, per-candidate orders; sweep.hip.h)
+    size_t gather_cap = 0;
     bool red_in_sweep = false;
     bool res_wide = false;          // resident units of more than 512 columns (16-bit staging): f32 tables cannot be trained
     bool same_group = false;        // one launch per step: chain blocks + sweep blocks of the same candidates, per-cell dy flags (k_step_same)
@@ -687,6 +692,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                             lp.group == 1;      // (multi-chunk units exist in k_step's sweep only)
         }
         if (p->same_group) ngroups = 1;
+        p->lp_group = lp.group;
         int split = K;
         if (ngroups == 2) {
             double tot = 0, run = 0;
@@ -870,6 +876,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_mdescs); hipFree(p->d_stats); hipFree(p->d_status);
     hipFree(p->d_seeds); hipFree(p->d_corr); hipFree(p->d_posw);
     hipFree(p->d_red_cnt);
+    hipFree(p->d_gather);
     hipFree(p->d_cellflag);
     hipFree(p->d_sync); hipFree(p->d_need); hipFree(p->d_scal); hipFree(p->d_trace); hipFree(p->d_pdescs);
     delete p;
@@ -1214,9 +1221,57 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     std::vector<double> ev_bytes;
     int64_t nlaunch = 0;
 
+    // Gathered rows (sweep.hip.h, gather_body): two-group streaming schedule + per-candidate sample orders.  The rows of batch
+    // t + 1 of group g are gathered by the launch that carries chain(g, t) (t >= 1) — the launch BEFORE sweep(g, t), which stages
+    // them as x_{t+1} and, a step later, as x_t; batches 0 and 1 are gathered by the group's forward-only prologue launch.
+    int64_t Tcur = 0;
+    bool use_gather = false;
+    int64_t g_par_stride = 0, g_cand_stride = 0;
+    auto setup_gather = [&]() -> hipError_t {
+        use_gather = NG == 2 && !p->persist && order && p->g.order_stride > 0 && p->lp_group == 1 && !getenv("MFAS_NO_GATHER");
+        if (!use_gather) return hipSuccess;
+        int64_t totw = 0;
+        for (int u = 0; u < MFAS_MAX_TAPS; ++u) totw += p->g.sw[u] + p->g.vw[u];
+        g_par_stride = totw * p->g.Bp * (train->dtype == MFAS_DT_F32 ? 4 : 2);
+        g_cand_stride = 2 * g_par_stride;
+        const size_t need = (size_t)g_cand_stride * K;
+        if (p->gather_cap < need) {
+            hipFree(p->d_gather); p->d_gather = nullptr; p->gather_cap = 0;
+            hipError_t e = hipMalloc(&p->d_gather, need);
+            if (e != hipSuccess) { use_gather = false; (void)hipGetLastError(); return hipSuccess; }   // an optimisation: train without it
+            p->gather_cap = need;
+        }
+        if (getenv("MFAS_GATHER_VERBOSE")) fprintf(stderr, "[gather] on: %d candidates, %.1f MB of gathered rows\n", K, (double)need / 1e6);
+        return hipSuccess;
+    };
+    HIPCHK(setup_gather());
+    auto gather_set = [&](GatherArgs& ga, int s, int64_t ep, int64_t t) {
+        ga.pos[s] = ep * N + t * B; ga.base[s] = (int)(t * B);
+        ga.nvalid[s] = (int)std::min<int64_t>(B, N - t * B); ga.par[s] = (int)(t & 1);
+    };
+
     // one fused launch: sweep of group gs at step ts (gs < 0: none) + chain of group gc at step tc (gc < 0: none)
     auto step = [&](int gs, int upd, int fwd, int64_t ep, int64_t ts, int gc, int64_t tc) {
         unsigned nsw = 0, nch = 0;
+        st.ga.nblocks = 0; st.ga.nsets = 0; st.sa.gather = nullptr;
+        if (use_gather) {
+            GatherArgs& ga = st.ga;
+            ga.buf = p->d_gather; ga.cand_stride = g_cand_stride; ga.par_stride = g_par_stride;
+            int gg = -1;
+            if (gs >= 0 && !upd && fwd && ts == 0) {                    // prologue of group gs: batches 0 and 1
+                gg = gs;
+                gather_set(ga, 0, ep, 0); ga.nsets = 1;
+                if (Tcur > 1) { gather_set(ga, 1, ep, 1); ga.nsets = 2; }
+            } else if (gc >= 0 && gs >= 0 && tc >= 1 && tc + 1 < Tcur) { // chain(gc, tc) rides with a sweep: batch tc + 1 of group gc
+                gg = gc;
+                gather_set(ga, 0, ep, tc + 1); ga.nsets = 1;
+            }
+            if (gg >= 0) { ga.cands = p->d_cands + p->groups[gg].c0; ga.nblocks = p->groups[gg].nc; }
+            if (gs >= 0 && upd) {
+                st.sa.gather = p->d_gather; st.sa.g_cand_stride = g_cand_stride; st.sa.g_par_stride = g_par_stride;
+                st.sa.g_par_t = (int)(ts & 1); st.sa.g_par_n = (int)((ts + 1) & 1);
+            }
+        }
         if (gs >= 0) {
             SweepArgs& s = st.sa;
             s.desc = p->groups[gs].d_descs;
@@ -1266,13 +1321,13 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             st.sa.cellflag = p->d_cellflag; st.ca.cellflag = p->d_cellflag;
             st.sa.flag_target = st.ca.flag_target = (uint32_t)st.ca.gstep + 1u;
             st.sa.flag_status = p->d_status;
-            if (g.MB == 1) { if (p->nontemporal) hipLaunchKernelGGL((k_step_same<1, true>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st);
-                             else hipLaunchKernelGGL((k_step_same<1, false>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st); }
-            else { if (p->nontemporal) hipLaunchKernelGGL((k_step_same<2, true>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st);
-                   else hipLaunchKernelGGL((k_step_same<2, false>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st); }
+            if (g.MB == 1) { if (p->nontemporal) hipLaunchKernelGGL((k_step_same<1, true>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st);
+                             else hipLaunchKernelGGL((k_step_same<1, false>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st); }
+            else { if (p->nontemporal) hipLaunchKernelGGL((k_step_same<2, true>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st);
+                   else hipLaunchKernelGGL((k_step_same<2, false>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st); }
             st.sa.cellflag = nullptr; st.ca.cellflag = nullptr;
         } else {
-#define STEP_LAUNCH(M, T, W, F) hipLaunchKernelGGL((k_step<M, T, W, F>), dim3(nch + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
+#define STEP_LAUNCH(M, T, W, F) hipLaunchKernelGGL((k_step<M, T, W, F>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
 #define STEP_PICK(M, W) do { if (p->nontemporal) { if (p->lean_chain) STEP_LAUNCH(M, true, W, true); else STEP_LAUNCH(M, true, W, false); } \
                              else { if (p->lean_chain) STEP_LAUNCH(M, false, W, true); else STEP_LAUNCH(M, false, W, false); } } while (0)
         // MB == 2: the two-workgroups-per-CU build unless a co-scheduled chain would bound the launch (see SweepU)
@@ -1381,6 +1436,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         int64_t T = nb;
         if (max_steps >= 0) T = std::min<int64_t>(nb, max_steps - done);
         if (T <= 0) break;
+        Tcur = T;
         RangeGuard epoch_range("epoch " + std::to_string(ep));
         if (p->persist) {
             HIPCHK(persist_epoch(ep, T));
@@ -1390,6 +1446,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
                 rc = persist_fallback(p);
                 if (rc) return rc;
                 HIPCHK(init_args());
+                HIPCHK(setup_gather());
                 aborts[ep] = 0;
             } else if (aborts[ep]) {
                 HIPCHK(hipStreamSynchronize(p->stream));

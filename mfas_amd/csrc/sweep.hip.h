@@ -85,6 +85,9 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
 // over a chunk of `cc` columns: x_t / x_{t+1} / dy are staged ONCE in LDS, then every wave streams whole
 // row blocks (contiguous 1 KiB tiles), requesting the W/m/v tiles of 4 k-blocks before consuming them.
 // ------------------------------------------------------------------------------------------------
+#define STEP_NW 8
+#define STEP_THREADS (STEP_NW * 64)
+
 struct SweepArgs {
     const SegDesc* desc;
     const TapDesc* tdesc;   // tap-major work list (may be empty)
@@ -110,7 +113,80 @@ struct SweepArgs {
     const uint32_t* cellflag;
     uint32_t flag_target;
     int32_t* flag_status;
+    // gathered rows (two-group streaming schedule with per-candidate sample orders, see gather_body): when set, a feature unit
+    // stages x_t / x_{t+1} from its candidate's gathered copy [parity][tap][Bp][width] instead of from the table through the order
+    const char* gather;
+    int64_t g_cand_stride, g_par_stride;   // bytes between two candidates' buffers / between the two parities of one
+    int32_t g_par_t, g_par_n;              // parity that holds the rows of batch t / of batch t + 1
 };
+
+// byte offset of tap (kind, tap)'s [Bp][width] block inside one parity of a candidate's gathered rows (S taps first, then V)
+__device__ __forceinline__ int64_t gather_tap_off(const Geo& g, const int kind, const int tap, const int eb) {
+    int64_t o = 0;
+#pragma unroll
+    for (int u = 0; u < MFAS_MAX_TAPS; ++u) {
+        if (kind == KIND_V || u < tap) o += g.sw[u];
+        if (kind == KIND_V && u < tap) o += g.vw[u];
+    }
+    return o * g.Bp * eb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather_body — one workgroup per candidate of the group whose CHAIN runs in this launch: copies the candidate's OWN table rows of
+// its next batch(es) (per-candidate sample order) into its gathered buffer, tap by tap for the taps its configuration uses — the
+// table is read in whole-row pieces of 256 B .. 4 KB instead of the 128-byte pieces the feature units would fetch one by one
+// (240 K random 128-byte reads per launch cost the HBM far more than their bytes), and every row is read from the table once
+// instead of twice (as x_{t+1} of one step and x_t of the next).  The sweep of this group runs in the NEXT launch.
+// ------------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const CandDev* cands;                  // the group's candidates (one workgroup each)
+    char* buf;
+    int64_t cand_stride, par_stride;       // bytes
+    int64_t pos[2];
+    int32_t base[2], nvalid[2], par[2];
+    int32_t nsets, nblocks;
+};
+
+__device__ __forceinline__ void gather_body(const GatherArgs& ga, const CandDev& cd, const Geo& g, const mfas_table& tab,
+                                            const int32_t* order, const int tid) {
+    const int eb = tab.dtype == MFAS_DT_F32 ? 4 : 2;
+    const int32_t* ordp = cand_order(order, g, cd.gidx);
+    uint32_t used = 0;            // bit kind * 4 + tap
+    for (int i = 0; i < cd.L; ++i) used |= (1u << cd.conf[i][0]) | (1u << (MFAS_MAX_TAPS + cd.conf[i][1]));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (s >= ga.nsets) break;
+        char* dst0 = ga.buf + (int64_t)cd.gidx * ga.cand_stride + (int64_t)ga.par[s] * ga.par_stride;
+        for (int kt = 0; kt < 2 * MFAS_MAX_TAPS; ++kt) {
+            if (!((used >> kt) & 1u)) continue;
+            const int kind = kt < MFAS_MAX_TAPS ? KIND_S : KIND_V, tap = kt & (MFAS_MAX_TAPS - 1);
+            const int w = kind == KIND_S ? g.sw[tap] : g.vw[tap];
+            const char* src0 = reinterpret_cast<const char*>(kind == KIND_S ? tab.s[tap] : tab.v[tap]);
+            char* dst = dst0 + gather_tap_off(g, kind, tap, eb);
+            const int vpr = (w * eb) >> 4, nvec = ga.nvalid[s] * vpr;      // 16-byte vectors per row (widths are multiples of 16 elements)
+            for (int e0 = tid; e0 < nvec; e0 += 4 * STEP_THREADS) {
+                u32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * STEP_THREADS;
+                    if (e < nvec) {
+                        const int b = e / vpr, c = e - b * vpr;
+                        const int64_t row = ordp ? (int64_t)ordp[ga.pos[s] + b] : (int64_t)(ga.base[s] + b);
+                        v[u] = *reinterpret_cast<const u32x4*>(src0 + (row * w) * eb + ((int64_t)c << 4));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * STEP_THREADS;
+                    if (e < nvec) {
+                        const int b = e / vpr, c = e - b * vpr;
+                        *reinterpret_cast<u32x4*>(dst + ((int64_t)b * w) * eb + ((int64_t)c << 4)) = v[u];
+                    }
+                }
+            }
+        }
+    }
+}
 
 // what changes from one train step to the next (k_step takes it from the launch arguments, the persistent loop computes it)
 struct SweepStep {
@@ -127,8 +203,6 @@ __device__ __forceinline__ SweepStep sweep_step_of(const SweepArgs& a) {
     return s;
 }
 
-#define STEP_NW 8
-#define STEP_THREADS (STEP_NW * 64)
 
 template <int MB, bool NT, int U, bool COH = false>
 __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& st, const int bid, float* lds) {
@@ -152,6 +226,11 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
     const int64_t sbo = cd.step_off;   // this candidate's step buffers inside a.stepbuf
     const bool red = a.red_cnt != nullptr;
 
+    if (!COH && a.gather && feat) {      // the candidate's rows were gathered a launch ago (gather_body): rows 0 .. B-1 of its own copy
+        const char* gb = a.gather + (int64_t)cd.gidx * a.g_cand_stride + gather_tap_off(a.g, d.kind, d.tap, a.tab.dtype == MFAS_DT_F32 ? 4 : 2);
+        if (upd) stage_table(xt, ST, gb + (int64_t)a.g_par_t * a.g_par_stride, a.tab.dtype, d.width, d.k0, cc, nullptr, 0, 0, st.nvalid_t, Bp, tid, STEP_THREADS);
+        if (fwd) stage_table(xn, SN, gb + (int64_t)a.g_par_n * a.g_par_stride, a.tab.dtype, d.width, d.k0, cc, nullptr, 0, 0, st.nvalid_n, Bp, tid, STEP_THREADS);
+    } else {
     if (upd && feat) {
         const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
         stage_table(xt, ST, tp, a.tab.dtype, d.width, d.k0, cc, cand_order(a.order, a.g, cd.gidx), st.pos_t, st.base_t, st.nvalid_t, Bp, tid, STEP_THREADS);
@@ -159,6 +238,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
     if (fwd) {
         const void* tp = d.kind == KIND_S ? a.tab.s[d.tap] : a.tab.v[d.tap];
         stage_table(xn, SN, tp, a.tab.dtype, d.width, d.k0, cc, cand_order(a.order, a.g, cd.gidx), st.pos_n, st.base_n, st.nvalid_n, Bp, tid, STEP_THREADS);
+    }
     }
     if constexpr (COH) {
         if (upd && a.cellflag) {   // the table rows above are in flight while the chain of this launch gets to this cell's dy

@@ -685,6 +685,66 @@ def test_full_size_properties(dev):
         assert 0 <= a[k]["train_corrects"][0] <= 10000 and 0 <= a[k]["dev_corrects"][0] <= 5600
 
 
+@pytest.mark.parametrize("R,B,K,N,dt,mixed,alphas,max_steps", [
+    (128, 16, 6, 16 * 5 + 7, "bf16", False, False, -1),     # ragged last batch
+    (128, 20, 5, 43, "f32", True, True, -1),                # f32 table, mixed depths / taps, alphas
+    (32, 16, 7, 16, "bf16", True, False, -1),               # one batch per epoch
+    (64, 8, 4, 16, "f16", True, False, -1),                 # two batches per epoch
+    (128, 16, 4, 80, "bf16", True, False, 7),               # cut by max_steps inside the second epoch
+])
+def test_gathered_rows_bit_identical(dev, capfd, R, B, K, N, dt, mixed, alphas, max_steps):
+    """Two-group streaming schedule with per-candidate sample orders (the headline's): every candidate's OWN rows of the next batch
+    are gathered into a contiguous per-candidate copy by the launch that carries its chain, and the feature units of the next
+    launch stage x_t / x_{t+1} from that copy (sweep.hip.h, gather_body).  Against staging from the table through the order
+    (MFAS_NO_GATHER=1) everything must be bit-identical: W, m, v of every candidate and all statistics."""
+    import os
+    from mfas_amd import FeatureTable, Hyper, Population
+    rng = np.random.default_rng(R + N)
+    E = 3
+    hp = Hyper(R=R, C=60, B=B, bn=bool(R >= 64), drpt=0.5, alphas=alphas, tap_bits=32 if dt == "f32" else 16, order_per_candidate=True)
+    confs = [np.array(CONFS["c4"])] * K
+    if mixed:
+        confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in rng.integers(1, 5, K)]
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dt]
+    tr = FeatureTable.from_numpy(O.synth_table(N, 3, snr=0.6), dev, tdt)
+    dv = FeatureTable.from_numpy(O.synth_table(50, 4, snr=0.6), dev, tdt)
+    nb = -(-N // B)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, E * nb)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    order = torch.stack([torch.stack([torch.randperm(N, generator=g, device=dev) for _ in range(E)]) for _ in range(K)]).to(torch.int32)
+
+    def run(gather):
+        os.environ["MFAS_GROUPS"] = "2"
+        if not gather:
+            os.environ["MFAS_NO_GATHER"] = "1"
+        try:
+            pop = Population(hp, confs, dev, drop_seeds=list(range(70, 70 + K)))
+            sched = pop.schedule()
+            pop.init(list(range(1, K + 1)))
+            stats, status = pop.train(tr, dv, E, etas, order=order, max_steps=max_steps)
+            planes = [[pop.get_params(k, pl).cpu().numpy().tobytes() for pl in range(3)] for k in range(K)]
+            pop.close()
+        finally:
+            del os.environ["MFAS_GROUPS"]
+            os.environ.pop("MFAS_NO_GATHER", None)
+        assert not status.any() and sched["groups"] == 2 and not sched["persistent"]
+        return stats, planes
+
+    os.environ["MFAS_GATHER_VERBOSE"] = "1"
+    try:
+        capfd.readouterr()
+        s1, p1 = run(True)
+        assert "[gather] on" in capfd.readouterr().err        # the path under test really ran
+        s0, p0 = run(False)
+        assert "[gather] on" not in capfd.readouterr().err
+    finally:
+        del os.environ["MFAS_GATHER_VERBOSE"]
+    assert s1.tobytes() == s0.tobytes()
+    assert p1 == p0
+    assert (s0["train_loss_sum"] > 0).any()
+
+
 def test_multi_chunk_units(dev, monkeypatch):
     """Round 4 (opt-in, MFAS_SUBCHUNKS=n): where the planner streams 64-column chunks (R = 128, >= 28 candidates) a sweep workgroup
     may take n consecutive chunks and keep the forward partial sums in registers across them (SegDesc::nsub, sweep_multi_body): one
