@@ -691,6 +691,7 @@ def test_full_size_properties(dev):
     (32, 16, 7, 16, "bf16", True, False, -1),               # one batch per epoch
     (64, 8, 4, 16, "f16", True, False, -1),                 # two batches per epoch
     (128, 16, 4, 80, "bf16", True, False, 7),               # cut by max_steps inside the second epoch
+    (128, 16, 24, 10000, "bf16", False, False, -1),         # BASELINE configs[1]'s table size, 24 conf-4 candidates (two natural groups)
 ])
 def test_gathered_rows_bit_identical(dev, capfd, R, B, K, N, dt, mixed, alphas, max_steps):
     """Two-group streaming schedule with per-candidate sample orders (the headline's): every candidate's OWN rows of the next batch
@@ -706,7 +707,11 @@ def test_gathered_rows_bit_identical(dev, capfd, R, B, K, N, dt, mixed, alphas, 
     if mixed:
         confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in rng.integers(1, 5, K)]
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dt]
-    tr = FeatureTable.from_numpy(O.synth_table(N, 3, snr=0.6), dev, tdt)
+    if N >= 5000:
+        E = 2
+        tr = FeatureTable.synthetic(N, 1, dev, tdt, snr=0.15)
+    else:
+        tr = FeatureTable.from_numpy(O.synth_table(N, 3, snr=0.6), dev, tdt)
     dv = FeatureTable.from_numpy(O.synth_table(50, 4, snr=0.6), dev, tdt)
     nb = -(-N // B)
     etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, E * nb)
