@@ -135,9 +135,12 @@ def cpu_baseline(train, dev, args, budget_s=24.0):
         import subprocess
         runs = []
         ncpu = os.cpu_count() or 1
-        # 8 threads: a FULL epoch (about 6-10 s); all host cores: whatever fits 15 s (eager per-op dispatch does not scale to
-        # hundreds of threads — the survey measured 1.24x from 1 to 8).  Each run is a subprocess with a hard timeout.
-        for nt_t, budget in sorted({(1, 40.0), (min(8, ncpu), 60.0), (ncpu, 15.0)}):
+        # 1 / 8 / 32 threads, a FULL epoch each where it fits the box (about 6-10 s at 8 threads).  Eager per-op dispatch does not
+        # scale to hundreds of threads (the survey measured 1.24x from 1 to 8; round 4's all-cores leg spent its whole 15 s box on
+        # ONE train step of a 256-thread host and could never win): thread counts are capped at 32.  Each run is a subprocess with
+        # a hard timeout.
+        top = min(32, ncpu)
+        for nt_t, budget in sorted({(1, 40.0), (min(8, ncpu), 60.0), (top, 30.0)}):
             cmd = [sys.executable, "-m", "oracle.torch_restatement", "--n-train", str(len(train)), "--n-dev", str(len(dev)),
                    "--R", str(args.R), "--B", str(args.batch), "--bn", str(int(not args.no_bn)), "--drpt", str(args.drpt),
                    "--threads", str(nt_t), "--budget", str(budget)]
@@ -156,7 +159,7 @@ def cpu_baseline(train, dev, args, budget_s=24.0):
                               "runs": runs,
                               "sample": f"one epoch ({nb} train steps of B={args.batch} + {len(dev)} dev rows) of conf-4 R={args.R} in PyTorch-CPU "
                                         f"eager (restatement of the reference loop incl. its per-step optimizer state_dict round trip) on "
-                                        f"same-shaped synthetic tables, per thread count (1 / {min(8, ncpu)} / {ncpu}: runs[], time-boxed to 40 / 60 / 15 s, "
+                                        f"same-shaped synthetic tables, per thread count (1 / {min(8, ncpu)} / {top}: runs[], time-boxed to 40 / 60 / 30 s, "
                                         f"runs[].full_epoch says whether the epoch completed), fastest reported, x E={args.epochs}; host has {ncpu} logical cores"}
     except Exception as e:   # the baseline is a report, never a reason to lose the bench line
         out["torch_eager"] = {"error": repr(e)}
@@ -243,6 +246,7 @@ def main():
     ap.add_argument("--total-pop", type=int, default=0, help="strong scaling: this many candidates IN TOTAL, sharded over the ranks")
     ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c3", "c5"], help="named BASELINE workloads (see the module docstring)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling workloads (config.strong) reported next to the weak headline")
+    ap.add_argument("--no-search", action="store_true", help="N = 1: skip the end-to-end configs[3] search schedule (config.search_c3, ~10 s outside the timed region)")
     ap.add_argument("--no-small-pop", action="store_true", help="N = 1: skip the search-sized workloads (config.small_pop) reported next to the headline")
     ap.add_argument("--snr", type=float, default=0.12, help="planted-signal strength of the synthetic taps (BASELINE.md section 2: 0.12)")
     ap.add_argument("--engine-init", default="torch", choices=["torch", "device"],
@@ -469,6 +473,26 @@ def main():
                            "kernel_algorithmic_gbs": (pby / (pms / nl * 1e-3) / 1e9) if nl else None,
                            "schedule": psched, "frac_of_hbm_bound": cps * gb / (HBM_PEAK_GBS * 1e9),
                            "mean_best_dev_acc": float(np.mean(kaccs))}
+    search_c3 = None
+    if plain and world == 1 and not a.no_small_pop and a.R == 128 and not a.no_bn and not a.no_search:
+        # BASELINE configs[3] END TO END on this one GPU (outside the timed region, ~10 s): the reference's full EPNAS schedule at its own
+        # search flags (main_searchable_ntu.py: --num_samples 50 --search_iterations 5 --max_fusions 4, R=16, B=20, drpt 0.5, no
+        # batchnorm, E epochs per candidate) — 20 train_sampled_models calls, 982 candidates — with the seeded controller (surrogate on
+        # the CPU, decision for decision the reference's: golden G8 / G9), split into candidate training and controller time
+        import main_searchable_ntu as MS
+        from mfas_amd.search import NTUSearcher
+        from mfas_amd.search.searcher import timed_search
+        sa = MS.parse_args(["--num_samples", "50", "--search_iterations", "5", "--max_fusions", "4", "--epochs", str(a.epochs),
+                            "--no-verbose", "--drpt", str(a.drpt), "--engine_init", a.engine_init, "--engine_order", a.engine_order])
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(max(1, sa.controller_threads))
+        try:
+            _, search_c3 = timed_search(NTUSearcher(sa, device, {"train": train, "dev": dev}), seed=0)
+        finally:
+            torch.set_num_threads(nthr)
+        search_c3["workload"] = (f"BASELINE configs[3] end to end on 1 GPU: full EPNAS schedule (50 confs/iter x 5 surrogate iterations x 4 "
+                                 f"progression levels, R=16, B=20, no batchnorm, drpt {a.drpt}, E={a.epochs}, N_train={a.n_train}, N_dev={a.n_dev}), "
+                                 f"seeded controller (seed 0), surrogate on {sa.controller_threads} CPU threads")
     other_init = other_order = other_both = None
     if world == 1 and not a.no_small_pop and not a.mixed_confs:      # the same workload with the OTHER initialisation path / sample order, one call each
         oargs = SimpleNamespace(**vars(args))
@@ -506,7 +530,19 @@ def main():
         # process.  When the committed passes of exactly this workload exist they are quoted WITH their source; else null.
         traffic = mfma = traffic_src = mfma_src = None
         headline = plain and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1
-        for tag in ("r04", "r03", "r02", "r01"):
+        prof_avg_us = prof_src = None
+        for tag in ("r05", "r04", "r03", "r02", "r01"):      # the committed rocprofv3 --kernel-trace --stats average of the headline kernel (builder's box)
+            cp = os.path.join(ROOT, "profiles", f"{tag}_bench_pop128_kernel_stats.csv")
+            if headline and prof_avg_us is None and os.path.exists(cp):
+                try:
+                    import csv
+                    rows = [r for r in csv.DictReader(open(cp)) if r.get("Name", "").startswith("void k_step<") or r.get("Name", "").startswith("k_step<")]
+                    top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+                    prof_avg_us = float(top["AverageNs"]) / 1e3
+                    prof_src = f"profiles/{tag}_bench_pop128_kernel_stats.csv ({top['Name'][:48]}, {top['Calls']} calls; rocprofv3 --kernel-trace --stats of this command on the builder's box)"
+                except Exception:
+                    prof_avg_us = None
+        for tag in ("r05", "r04", "r03", "r02", "r01"):
             tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
             if headline and traffic is None and os.path.exists(tp):
                 try:
@@ -554,11 +590,12 @@ def main():
                        "mean_best_dev_acc" if not mm else "mean_best_dev_f1": float(np.mean(accs)),
                        "hbm_bound_cand_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / bytes_cand,
                        "frac_of_hbm_bound": total_trained / dt * bytes_cand / (HBM_PEAK_GBS * 1e9 * world),
-                       "small_pop": small, "strong": strong},
+                       "small_pop": small, "strong": strong, "search_c3": search_c3},
             "roofline": {"bound": "hbm", "kernel": kernel, "schedule": sched,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": n_launch, "avg_launch_us": (ms / n_launch * 1e3) if n_launch else None,
+                         "profile_box_avg_us": prof_avg_us, "profile_box_source": prof_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "stream_probe": stream, "frac_of_stream_probe": (achieved / stream) if (achieved and stream) else None,
                          "mfma_util_pct_from_profile": mfma, "mfma_util_source": mfma_src},

@@ -284,6 +284,74 @@ __device__ __forceinline__ void softmax_rows(const ChainArgs& a, const ChainStep
     else softmax_rows_nc<MB, 8>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, ord);
 }
 
+// Lean form of the same loss (round 5) for the lean chain's case — C <= 64 classes, no multitask: EIGHT lanes per batch row
+// (threads [0, 8 Bp): one wave per SIMD at Bp = 32), every lane owns eight CONSECUTIVE classes (two ds_read_b128 of logits, two
+// ds_write_b128 of dlogits); masks instead of exec-masked branches; independent per-class work in the lane (issue-bound, not a
+// dependent chain) and three DPP stages per row reduction instead of four; exp through v_exp_f32 on (x - max) * log2(e) (absolute
+// error <= 1e-7 of the probability: dlogits = p - onehot is an absolute quantity); both divisions through the correctly rounding
+// sequences of common.hip.h with ONE reciprocal per row; and no arg-max: the row counts as correct iff the label's logit equals the
+// row maximum and no EARLIER class does (= "first maximum is the label", torch.max(dim=1) on ties).
+// softmax_rows_nc spent ~4,300 shader cycles of a ~20,000-cycle R = 16 chain here (profiles/r04_chain_phases.log): ~500 issued
+// instructions per lane in one dependent string, two waves per SIMD.  Same results up to the summation order of the row's exp() terms.
+template <int MB>
+__device__ __forceinline__ void softmax_rows_lean(const ChainArgs& a, float* lg_l, const int SC, float* red_l, const int* lab_l,
+                                                  const int nvalid, const float nf, const int tid) {
+    constexpr int Bp = MB * 16;
+    const int C = a.g.C;
+    const int b = tid >> 3, sub = tid & 7, c0 = sub * 8;
+    float* row = lg_l + b * SC;
+    const bool ok = b < nvalid;
+    const int lab = lab_l[b];
+    const bool inrow = c0 < a.g.Cp;       // (Cp = 16 / 32 / 48 / 64: lanes beyond the padded row neither read nor write it)
+    f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;
+    if (inrow) {
+        xa = *reinterpret_cast<const f32x4*>(row + c0);
+        xb = *reinterpret_cast<const f32x4*>(row + c0 + 4);
+    }
+    const float xlab = row[lab];
+    float xv[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        xv[q] = c0 + q < C ? xa[q] : -3.0e38f;
+        xv[4 + q] = c0 + 4 + q < C ? xb[q] : -3.0e38f;
+    }
+    const float mx = row_max<8>(fmaxf(fmaxf(fmaxf(xv[0], xv[1]), fmaxf(xv[2], xv[3])), fmaxf(fmaxf(xv[4], xv[5]), fmaxf(xv[6], xv[7]))));
+    f32x4 ea, eb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ea[q] = __builtin_amdgcn_exp2f((xv[q] - mx) * 1.44269504088896341f);
+        eb[q] = __builtin_amdgcn_exp2f((xv[4 + q] - mx) * 1.44269504088896341f);
+    }
+    const float se = row_sum<8>(((ea[0] + ea[1]) + (ea[2] + ea[3])) + ((eb[0] + eb[1]) + (eb[2] + eb[3])));
+    float early = 0.f;                    // an earlier class than the label attains the maximum
+#pragma unroll
+    for (int q = 0; q < 8; ++q) early = (c0 + q < lab && xv[q] == mx) ? 1.0f : early;
+    early = row_max<8>(early);
+    if (sub == 0) {
+        const float lse = mx + __builtin_amdgcn_logf(se) * 0.693147180559945309f;
+        red_l[b] = ok ? -(xlab - lse) : 0.f;
+        red_l[Bp + b] = (ok && xlab == mx && early == 0.f) ? 1.f : 0.f;
+    }
+    const f32x4 se4 = (f32x4)(se), rse4 = (f32x4)(rcp_refined(se)), nf4 = (f32x4)(nf), rnf4 = (f32x4)(rcp_refined(nf));
+    f32x4 da = div_by4(ea, se4, rse4), db = div_by4(eb, se4, rse4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        da[q] = c0 + q == lab ? da[q] - 1.0f : da[q];
+        db[q] = c0 + 4 + q == lab ? db[q] - 1.0f : db[q];
+    }
+    da = div_by4(da, nf4, rnf4);
+    db = div_by4(db, nf4, rnf4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        da[q] = (ok && c0 + q < C) ? da[q] : 0.f;
+        db[q] = (ok && c0 + 4 + q < C) ? db[q] : 0.f;
+    }
+    if (inrow) {
+        *reinterpret_cast<f32x4*>(row + c0) = da;
+        *reinterpret_cast<f32x4*>(row + c0 + 4) = db;
+    }
+}
+
 #ifdef MFAS_CHAIN_TIMING
 #define CT_STAMP(slot) do { if (threadIdx.x == 0 && bid == 0 && cs.gstep == 3) a.status[64 + (slot)] = (int32_t)(__builtin_readcyclecounter() - ct0); } while (0)
 #else
@@ -891,10 +959,22 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     // every load below is UNCONDITIONAL (indices clamped to something valid): with a statically known number of loads in
     // flight the compiler can wait for exactly the ones it consumes instead of draining the whole queue at first use
     f32x4 p8[PB];
+    if constexpr (RES) {
+        // resident chain: only the slabs that exist (wave-uniform count -> scalar branches).  The unconditional form below re-requests
+        // slab 0 for every missing one — 16 requests per thread for the 2-4 slabs per cell of 256...1024-column units: 128 KB of
+        // requests through this one CU's memory pipeline per step for 30-60 KB of partial sums, on the critical path.
+        const int nch_u = __builtin_amdgcn_readfirstlane(nch);
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            p8[u] = z4;
+            if (u < nch_u) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)u * MB) << 8));
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
         const int uu = u < nch ? u : 0;
         p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)uu * MB) << 8));
+    }
     }
     const int vi = tid < nvec ? tid : 0;   // nvec = 4 * 96 + Cp <= 448: one element of the vector block per thread
     float vw = 0.f, vm = 0.f, vv = 0.f;
@@ -923,30 +1003,52 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     }
     const int r = l15;
     const bool colok = r < R;
-    // phase 0: reduce the sweep's column-chunk partial sums (fixed order) into LDS; stage the vector block
-    if (has_item) {
-        f32x4 accS = z4, accV = z4;
+    // phase 0: reduce the sweep's column-chunk partial sums (fixed order) into LDS; stage the vector block.
+    // Resident chain (round 5): only cell 0's sums are waited for here — the waves that hold the slabs of cells 1..L-1 (the cell
+    // index is wave-uniform) consume theirs at the end of cell 0's forward, so the 3/4 of the slab bytes that cell 0 does not need
+    // stream into this CU while cell 0 is computed instead of in front of it (the chain spent ~5,000 of ~14,000 cycles per step
+    // between "units have arrived" and "sums in LDS": profiles/r04_chain_phases.log, slot 0).
+// (a macro, not a lambda: with the slab registers captured by reference the closure keeps p8[] addressable and the whole array
+//  lands in scratch memory — 272 bytes per lane, measured: entry 5,400 -> 15,900 cycles)
+#define LEAN_CONSUME() do { \
+        f32x4 accS = z4, accV = z4; \
+_Pragma("unroll") \
+        for (int u = 0; u < PB; ++u) \
+            if (u < nch) { \
+                if (u < ns) accS += p8[u]; else accV += p8[u]; \
+            } \
+        for (int ch0 = PB; ch0 < nch; ch0 += PB) { \
+_Pragma("unroll") \
+            for (int u = 0; u < PB; ++u) \
+                if (ch0 + u < nch) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)(ch0 + u) * MB) << 8)); \
+_Pragma("unroll") \
+            for (int u = 0; u < PB; ++u) \
+                if (ch0 + u < nch) { \
+                    if (ch0 + u < ns) accS += p8[u]; else accV += p8[u]; \
+                } \
+        } \
+        if (g.alphas) { \
+            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS; \
+            *reinterpret_cast<f32x4*>(yf_l + sav_plane + tid * 4) = accV; \
+        } else { \
+            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS + accV; \
+        } \
+    } while (0)
+    // dropout keep-bits of this lane's element in every cell (a few dozen integer instructions: issued under the slab loads)
+    const int ew = wave, emb = ew >> 2, eq = ew & 3;
+    const bool eact = ew < MB * 4;
+    const int eb = emb * 16 + 4 * lg + eq;                  // this lane's batch row
+    uint32_t ekeep = 0xFu;
+    if (g.use_drop) {
+        ekeep = 0u;
 #pragma unroll
-        for (int u = 0; u < PB; ++u)
-            if (u < nch) {
-                if (u < ns) accS += p8[u]; else accV += p8[u];
-            }
-        for (int ch0 = PB; ch0 < nch; ch0 += PB) {
-#pragma unroll
-            for (int u = 0; u < PB; ++u)
-                if (ch0 + u < nch) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)(ch0 + u) * MB) << 8));
-#pragma unroll
-            for (int u = 0; u < PB; ++u)
-                if (ch0 + u < nch) {
-                    if (ch0 + u < ns) accS += p8[u]; else accV += p8[u];
-                }
-        }
-        if (g.alphas) {
-            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS;
-            *reinterpret_cast<f32x4*>(yf_l + sav_plane + tid * 4) = accV;
-        } else {
-            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS + accV;
-        }
+        for (int i = 0; i < MFAS_MAX_CELLS; ++i)
+            if (drop_keep(h0, i, (uint32_t)(eb * R + r), g.drop_thr)) ekeep |= 1u << i;
+    }
+    if constexpr (RES) {
+        if (has_item && pi == 0) LEAN_CONSUME();
+    } else {
+        if (has_item) LEAN_CONSUME();
     }
     if constexpr (!RES) {
         if (tid < nvec) { vec_l[tid] = vw; vec_l[nvec + tid] = vm; vec_l[2 * nvec + tid] = vv; }
@@ -972,20 +1074,10 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     // lane, then one workgroup barrier hands out_i to the next cell.  BatchNorm's batch statistics and the backward's column
     // sums are exchanged through LDS (fixed order over the waves).  What each lane needs again in the backward (activation,
     // x-hat, alpha difference) stays in its registers.
-    const int ew = wave, emb = ew >> 2, eq = ew & 3;
-    const bool eact = ew < MB * 4;
-    const int eb = emb * 16 + 4 * lg + eq;                  // this lane's batch row
     float* bnw = ll.scr;                                     // [2][8][16] cross-wave column sums
     float* gv2 = ll.scr + 256;                               // [cell][dgamma | dbeta][16]
     auto sel4 = [&](const f32x4& v4) -> float { return eq == 0 ? v4[0] : (eq == 1 ? v4[1] : (eq == 2 ? v4[2] : v4[3])); };
     float av[MFAS_MAX_CELLS], xhs[MFAS_MAX_CELLS], dsv[MFAS_MAX_CELLS];
-    uint32_t ekeep = 0xFu;
-    if (g.use_drop) {
-        ekeep = 0u;
-#pragma unroll
-        for (int i = 0; i < MFAS_MAX_CELLS; ++i)
-            if (drop_keep(h0, i, (uint32_t)(eb * R + r), g.drop_thr)) ekeep |= 1u << i;
-    }
 #pragma unroll
     for (int i = 0; i < MFAS_MAX_CELLS; ++i) {
         av[i] = 0.f; xhs[i] = 0.f; dsv[i] = 0.f;
@@ -1066,6 +1158,9 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                 if (!(colok && eb < nvalid)) o = 0.0f;
                 xo_l[i * Bp * SX + eb * SX + r] = o;
             }
+            if constexpr (RES) {
+                if (i == 0 && has_item && pi > 0) LEAN_CONSUME();     // the other cells' sums (see phase 0)
+            }
             if (i + 1 < L) lds_barrier();     // (the last cell's hand-off is the barrier below)
         }
     }
@@ -1114,6 +1209,8 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
         }
     } else if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
+    } else if (!g.multitask) {
+        if (tid < 8 * Bp) softmax_rows_lean<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
     } else if (tid < LPR * Bp) {
         softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
     }
@@ -1130,25 +1227,34 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             const bool from_head = (i == L - 1);
             float gr = 0.f;
             if (g.bn) gr = vecW[vbl + VEC_G * Rp + r] * rstd_l[i * Rp + r];
+            if (from_head) {
+                // d_out = dlogits . Wc (round 5): every wave used to run all four class blocks' products for its row block — 16 MFMAs per
+                // wave, 32 per SIMD at 32 cycles of matrix pipe each, the longest phase of the backward (profiles/r04_chain_phases.log:
+                // 2,236 cycles against ~1,000 for the other cells).  Now wave (row block emb, class block eq) runs ONE block's four
+                // products and parks the 16 x 16 partial in the (dead) reduced-sums plane; after the barrier every element owner adds
+                // the four partials of its row block, (0 + 2) + (1 + 3).
+                if (eact) {
+                    f32x4 pt = z4;
+                    if (eq < ncb) {
+                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(lg_l + (emb * 16 + l15) * SC + eq * 16 + 4 * lg);
+                        f32x4 wt4;
+                        if constexpr (RES) wt4 = *reinterpret_cast<const f32x4*>(ll.own + ((3 * LEAN_OWN_TILES + 3 + eq) << 8) + lane * 4);
+                        else wt4 = pick4(tHT, eq);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) pt = MFMA16(x4[q], wt4[q], pt);
+                    }
+                    *reinterpret_cast<f32x4*>(yf_l + (ew << 8) + lane * 4) = pt;
+                }
+                lds_barrier();
+            }
             float d = 0.f;
             if (eact) {
                 f32x4 acc = z4;
-                if (from_head) {   // d_out = dlogits . Wc: even / odd class blocks in two chains
-                    f32x4 acc2 = z4;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (u < ncb) {
-                            const f32x4 x4 = *reinterpret_cast<const f32x4*>(lg_l + (emb * 16 + l15) * SC + u * 16 + 4 * lg);
-                            f32x4 wt4;
-                            if constexpr (RES) wt4 = *reinterpret_cast<const f32x4*>(ll.own + ((3 * LEAN_OWN_TILES + 3 + u) << 8) + lane * 4);
-                            else wt4 = tHT[u];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                if (u & 1) acc2 = MFMA16(x4[q], wt4[q], acc2);
-                                else acc = MFMA16(x4[q], wt4[q], acc);
-                            }
-                        }
-                    acc += acc2;
+                if (from_head) {
+                    const float* pp = yf_l + ((emb * 4) << 8) + lane * 4;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 256);
+                    const f32x4 p2 = *reinterpret_cast<const f32x4*>(pp + 512), p3 = *reinterpret_cast<const f32x4*>(pp + 768);
+                    acc = (p0 + p2) + (p1 + p3);
                 } else {
                     f32x4 w;
                     if constexpr (RES) w = *reinterpret_cast<const f32x4*>(ll.own + ((3 * LEAN_OWN_TILES + i) << 8) + lane * 4);

@@ -288,9 +288,11 @@ static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs
         // smallest units first (fewest tiles per wave on the critical path); two units per workgroup before 1024-column units
         // (measured: 16 candidates, 1024-column units: 34.8 us per step)
         // (two 256-column units per workgroup before one 512-column unit: 9..15 candidates 15.7-16.2 vs 18.0-18.7 us per step)
-        const int opts[6][2] = {{128, 1}, {256, 1}, {256, 2}, {512, 1}, {512, 2}, {1024, 1}};
+        // (round 5: 128-column units are out — twice the partial slabs through the chain's one CU for half the tiles per wave:
+        //  3 / 4 candidates 23.9 / 23.7 us per step against 18.8 / 18.8 with 256-column units, profiles/r05_popsweep_units.log)
+        const int opts[5][2] = {{256, 1}, {256, 2}, {512, 1}, {512, 2}, {1024, 1}};
         int pick = -1;
-        for (int o = 0; o < 6 && pick < 0; ++o)
+        for (int o = 0; o < 5 && pick < 0; ++o)
             if (res_fits(opts[o][0], opts[o][1], feat_units(opts[o][0], nullptr))) pick = o;
         if (pick >= 0) { lp.target = opts[pick][0]; lp.nu = opts[pick][1]; }
         else lp.plan_res = false;

@@ -156,3 +156,54 @@ class MMIMDBSearcher(_TableSearcher):
     shuffle = {"train": True, "dev": False}
     model_type = mmimdb.Searchable_Text_Image_Net
     methods_module = mmimdb
+
+
+def timed_search(searcher, seed=0, surrogate_device="cpu"):
+    """Run `searcher.search()` under fixed seeds (torch / numpy / random: every decision of the controller is then a function of
+    the accuracies the engine returns) with the wall time split into candidate training and controller / surrogate, and a digest
+    of the decision stream (every configuration list the controller asked to be trained, in order).  Returns
+    (surrogate dataset, report dict).  Used by `main_searchable_ntu.py --timing`, by bench.py's `config.search_c3` entry (BASELINE
+    configs[3]: --num_samples 50 --search_iterations 5 --max_fusions 4 -> 20 calls, 982 candidates) and by the GPU test of that schedule."""
+    import hashlib
+    import random
+    import time
+    methods = searcher._methods()
+    inner = methods["train_sampled_fun"]
+    spent = {"train_s": 0.0, "calls": 0, "candidates": 0, "call_sizes": []}
+    h = hashlib.sha256()
+    first = hashlib.sha256()
+
+    def timed(confs, *a, **kw):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = inner(confs, *a, **kw)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        spent["train_s"] += time.perf_counter() - t
+        blob = b"".join(np.ascontiguousarray(np.asarray(c, np.int64)).tobytes() + b"|" for c in confs)
+        if spent["calls"] == 0:
+            first.update(blob)
+        h.update(blob)
+        spent["calls"] += 1
+        spent["candidates"] += len(confs)
+        spent["call_sizes"].append(len(confs))
+        return out
+
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)                # tools.sample_k_configurations_directly draws depths with random.randint
+    searcher._methods = lambda: dict(methods, train_sampled_fun=timed)
+    try:
+        t0 = time.perf_counter()
+        data = searcher.search(surrogate_device=surrogate_device)
+        total = time.perf_counter() - t0
+    finally:
+        del searcher._methods        # (the instance attribute shadowing the class method)
+    k_best, k_accs, _ = data.get_k_best(1)
+    rep = {"candidates": spent["candidates"], "calls": spent["calls"], "call_sizes": spent["call_sizes"], "total_s": total,
+           "train_s": spent["train_s"], "controller_s": total - spent["train_s"],
+           "cand_per_s": spent["candidates"] / max(spent["train_s"], 1e-9), "cand_per_s_end_to_end": spent["candidates"] / max(total, 1e-9),
+           "best_dev_acc": float(k_accs[0]) if len(k_accs) else None, "seed": seed,
+           "first_call_digest": first.hexdigest()[:16], "decision_digest": h.hexdigest()[:16]}
+    return data, rep

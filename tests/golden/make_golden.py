@@ -1091,6 +1091,128 @@ def g18cmerge():
          best_acc=np.concatenate([p["best_acc"] for p in parts]), trials=trials, rel=parts[0]["rel"], meta=parts[0]["meta"])
 
 
+# ------------------------------------------------------------------ G19 the search-default regime at FULL size (BASELINE configs[2])
+def sampled_l4(n):
+    """bench.py's configs[2] / configs[3] populations: L=4 confs sampled like the controller does at progression level 3
+    (np.random.seed(0); rows drawn from the reference's own get_possible_layer_configurations(0))."""
+    np.random.seed(0)
+    layer = ntu.get_possible_layer_configurations(0)
+    return [np.array([layer[i] for i in np.random.choice(len(layer), 4)]) for _ in range(n)]
+
+
+G19_SNR = 0.12
+
+
+def _g19_tables():
+    ttr = dict(O.synth_table(10000, 1, snr=G19_SNR, quant="bf16"), vlogit=np.zeros((10000, 60), np.float32), slogit=np.zeros((10000, 60), np.float32))
+    tdv = dict(O.synth_table(5600, 2, snr=G19_SNR, quant="bf16"), vlogit=np.zeros((5600, 60), np.float32), slogit=np.zeros((5600, 60), np.float32))
+    return ttr, tdv
+
+
+def g19b():
+    """BASELINE configs[2] exactly as bench.py runs it (`--workload c2` / `small_pop.c2`), through the unchanged reference:
+    ONE train_sampled_models call on the 16 np.random.seed(0) L=4 confs at the search script's defaults
+    (main_searchable_ntu.py:26-47,56; models/searchable.py:90,120): R=16, no batchnorm, drpt 0.5, B=20, E=10,
+    N=10,000/5,600, bf16-rounded taps at snr 0.12, shuffled train order.  torch.manual_seed(1900 + seed) for the reference's
+    OWN dropout (Philox) / shuffle streams; candidate i of seed s starts from init_params(conf_i, hp, 19000 + 100 s + i).
+    Splittable: G19_SEED0=a G19_NS=n -> g19b_part_<a>.npz (git-ignored); `g19bmerge`.
+    Committed: `for a in 0 4 ... 28; do G19_SEED0=$a G19_NS=4 python make_golden.py g19b & done; wait; python make_golden.py g19bmerge`."""
+    NS = int(os.environ.get("G19_NS", "32"))
+    seed0 = int(os.environ.get("G19_SEED0", "0"))
+    E = int(os.environ.get("G19_E", "10"))
+    K = int(os.environ.get("G19_K", "16"))
+    ttr, tdv = _g19_tables()
+    confs = sampled_l4(16)[:K]
+    args = mkargs(inner_representation_size=16, batchnorm=False, drpt=0.5, epochs=E, batchsize=20)
+    torch.set_num_threads(1)
+    loaders = {"train": ShuffleLoader(ttr, 20), "dev": ListLoader(tdv, 20)}
+    bests, hists = [], []
+    import time
+    meta = np.array([10000, 5600, G19_SNR, 16, 20, E, 0, 0.5])   # N,Ndev,snr,R,B,epochs,bn,drpt
+    part = os.path.join(HERE, f"g19b_part_{seed0:03d}.npz")
+    if "G19_SEED0" in os.environ and os.path.exists(part):        # resume a part that was interrupted (every seed is independent)
+        old = np.load(part)
+        if np.array_equal(old["meta"], meta) and np.array_equal(old["confs"], np.array(confs)) and int(old["seeds"][0]) == seed0:
+            bests, hists = list(old["best_acc"]), list(old["dev_acc"])
+    for seed in range(seed0 + len(bests), seed0 + NS):
+        t0 = time.time()
+        torch.manual_seed(1900 + seed)
+        accs, _, hist = run_tsm(confs, args, loaders, 19000 + 100 * seed)
+        bests.append(accs)
+        hists.append(hist.reshape(K, 2 * E, 3)[:, 1::2, 2])     # [cand][epoch] dev accuracy as printed (4 decimals)
+        print("g19b seed", seed, "%.0fs" % (time.time() - t0), np.round(accs, 4), flush=True)
+        if "G19_SEED0" in os.environ and not os.environ.get("G19_PROBE"):
+            np.savez_compressed(part, best_acc=np.array(bests), dev_acc=np.array(hists), seeds=np.arange(seed0, seed0 + len(bests)),
+                                confs=np.array(confs), meta=meta)
+    if os.environ.get("G19_PROBE"):
+        return
+    arrs = dict(best_acc=np.array(bests), dev_acc=np.array(hists), seeds=np.arange(seed0, seed0 + NS), confs=np.array(confs), meta=meta)
+    if "G19_SEED0" in os.environ:
+        save(f"g19b_part_{seed0:03d}.npz", **arrs)
+    else:
+        save("g19b_search_default_streams.npz", **arrs)
+
+
+def g19bmerge():
+    import glob
+    parts = [np.load(f) for f in sorted(glob.glob(os.path.join(HERE, "g19b_part_*.npz")))]
+    assert parts and all(np.array_equal(p["meta"], parts[0]["meta"]) and np.array_equal(p["confs"], parts[0]["confs"]) for p in parts)
+    seeds = np.concatenate([p["seeds"] for p in parts])
+    assert np.array_equal(seeds, np.arange(len(seeds))), seeds
+    save("g19b_search_default_streams.npz", best_acc=np.concatenate([p["best_acc"] for p in parts]),
+         dev_acc=np.concatenate([p["dev_acc"] for p in parts]), seeds=seeds, confs=parts[0]["confs"], meta=parts[0]["meta"])
+
+
+G19A_CONFS = (0, 5, 11)      # indices into sampled_l4(16)
+
+
+def g19a():
+    """G18c in the search-default regime: confs G19A_CONFS of the configs[2] population at full size (R=16, no batchnorm,
+    drpt 0.5, B=20, N=10,000/5,600, bf16-rounded taps at snr 0.12, 3 epochs) through the unchanged train_sampled_models
+    from NT starts per conf that differ by a 1e-7 relative perturbation of the initial weight matrices
+    (O.perturb_params(init_params(conf, hp, 79), trial)); every start sees the SAME masks (seed 4141) and the SAME order
+    (default_rng(1913)).  Splittable: G19A_T0=a G19A_NT=n -> g19a_part_<a>.npz; `g19amerge`."""
+    NT = int(os.environ.get("G19A_NT", "64"))
+    t0 = int(os.environ.get("G19A_T0", "0"))
+    E = 3
+    ttr, tdv = _g19_tables()
+    rng = np.random.default_rng(1913)
+    order = np.stack([rng.permutation(10000) for _ in range(E)])
+    allc = sampled_l4(16)
+    confs = [allc[i] for i in G19A_CONFS]
+    args = mkargs(inner_representation_size=16, batchnorm=False, drpt=0.5, epochs=E, batchsize=20)
+    torch.set_num_threads(1)
+    hists, bests = [], []
+    for trial in range(t0, t0 + NT):
+        hrow, brow = [], []
+        for conf in confs:
+            cap = CaptureMasked(79, 4141, perturb_trial=trial)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                accs = ntu.train_sampled_models([conf], cap, {"train": OrderLoader(ttr, 20, order), "dev": ListLoader(tdv, 20)}, args, "cpu")
+            hrow.append(parse_hist(buf.getvalue()))
+            brow.append(float(accs[0]))
+        hists.append(hrow)
+        bests.append(brow)
+        print("g19a trial", trial, brow, flush=True)
+    arrs = dict(hist=np.array(hists), best_acc=np.array(bests), trials=np.arange(t0, t0 + NT), rel=np.array([1e-7]), confs=np.array(confs),
+                meta=np.array([10000, 5600, G19_SNR, 16, 20, E, 0, 0.5, 79, 4141, 1913]))
+    if "G19A_T0" in os.environ:
+        save(f"g19a_part_{t0:03d}.npz", **arrs)
+    else:
+        save("g19a_search_default_envelope.npz", **arrs)
+
+
+def g19amerge():
+    import glob
+    parts = [np.load(f) for f in sorted(glob.glob(os.path.join(HERE, "g19a_part_*.npz")))]
+    assert parts and all(np.array_equal(p["meta"], parts[0]["meta"]) for p in parts)
+    trials = np.concatenate([p["trials"] for p in parts])
+    assert np.array_equal(trials, np.arange(len(trials))), trials
+    save("g19a_search_default_envelope.npz", hist=np.concatenate([p["hist"] for p in parts]),
+         best_acc=np.concatenate([p["best_acc"] for p in parts]), trials=trials, rel=parts[0]["rel"], confs=parts[0]["confs"], meta=parts[0]["meta"])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g23", "g456", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g14m", "g15", "g16", "g17", "g18a", "g18b", "g18c"]
     for w in which:
