@@ -308,20 +308,31 @@ def main():
             backend_note = f"gloo control plane unavailable ({type(e).__name__}); RCCL is the default group"
             dist.init_process_group("nccl", device_id=device)
         if a.backend == "nccl" and gloo_ok:
+            # two agreements over gloo: first that EVERY rank created the RCCL group (a rank whose new_group raised must not leave the
+            # others blocked in the probe), then that the probe all_reduce came back right everywhere
+            def agree(ok_here):
+                f = torch.tensor([1 if ok_here else 0], dtype=torch.int32)
+                dist.all_reduce(f, op=dist.ReduceOp.MIN)
+                return int(f.item()) == 1
             ok, err = 1, ""
             try:
                 if force_fail and os.environ["MFAS_TEST_RCCL_FAIL"] != "real":     # ("real": let RCCL itself refuse the shared GPU)
                     raise RuntimeError("forced by MFAS_TEST_RCCL_FAIL")
                 group = dist.new_group(backend="nccl")
-                probe = torch.ones(1, device=device)
-                dist.all_reduce(probe, group=group)
-                torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    raise RuntimeError(f"RCCL probe all_reduce returned {probe.item()} for {world} ranks")
             except Exception as e:      # noqa: BLE001 - whatever RCCL raises, the fallback is the same
                 ok, err = 0, f"{type(e).__name__}: {str(e)[:200]}"
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if agree(ok == 1):
+                try:
+                    probe = torch.ones(1, device=device)
+                    dist.all_reduce(probe, group=group)
+                    torch.cuda.synchronize()
+                    if int(probe.item()) != world:
+                        raise RuntimeError(f"RCCL probe all_reduce returned {probe.item()} for {world} ranks")
+                except Exception as e:      # noqa: BLE001
+                    ok, err = 0, f"{type(e).__name__}: {str(e)[:200]}"
+                flag = torch.tensor([1 if agree(ok == 1) else 0], dtype=torch.int32)
+            else:
+                flag = torch.tensor([0], dtype=torch.int32)
             if int(flag.item()) == 1:
                 from mfas_amd import population as _pm
                 _pm.set_group(group)

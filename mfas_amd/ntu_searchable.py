@@ -232,9 +232,11 @@ class Searchable_Skeleton_Image_Net(nn.Module):
             raise ValueError("forward needs the pooled taps 'v0'.. / 's0'.. of the batch (there are no backbones in this engine)")
         some = next(iter(taps.values()))
         n = some.shape[0]
-        if torch.is_grad_enabled() and any(t.requires_grad for t in taps.values()):
+        if self.training and torch.is_grad_enabled() and any(t.requires_grad for t in taps.values()):
             raise NotImplementedError("the taps require grad, but this engine's backbones are frozen feature tables: it produces gradients "
                                       "for central_params() only (train_only_central_params, ntu_searchable.py:27); detach() the taps")
+        # (eval mode needs no gradient of the taps: the reference's eval forward accepts them, so they are detached silently)
+        taps = {k: v.detach() for k, v in taps.items()}
         table = FeatureTable(taps, torch.zeros(n, dtype=torch.int32, device=some.device))
         if self.training:
             # train mode (ntu_searchable.py:206-247 under model.train(True)): batch-statistics BatchNorm — running statistics and
@@ -471,6 +473,7 @@ def torch_init_bounds(conf, hp) -> np.ndarray:
     return out
 
 
+_TEST_FAIL_RANK = -1         # tests only: the rank whose first share of a sharded call raises (never read from the environment)
 _DEVICE_STREAMS_OK = {}      # device -> the device-side Mersenne-Twister init reproduces torch's CPU draws on this host (checked once)
 
 
@@ -481,7 +484,10 @@ def _init_population_device_streams(pop, args, confs, group, hp, seed_base, devi
     kernels fuse x * (hi - lo) + lo into one fma on AVX2 / AVX512 hosts; a build that does not would differ in last bits) — and
     abandoned for the host path when that check fails (MFAS_HOST_INIT=1 forces the host path)."""
     import os
-    key = (str(device), searchable_type.__name__)
+    # one check per device, class (qualified) and geometry incl. the candidate's depth: a later call with another Hyper, another L or
+    # an unrelated class of the same __name__ is checked again (one module build per key)
+    key = (str(device), getattr(searchable_type, "__module__", ""), getattr(searchable_type, "__qualname__", searchable_type.__name__),
+           hp.R, hp.C, bool(hp.bn), bool(hp.alphas), tuple(hp.s_sizes), tuple(hp.v_sizes), len(np.asarray(confs[group[0]]).reshape(-1, 3)))
     if os.environ.get("MFAS_HOST_INIT") or _DEVICE_STREAMS_OK.get(key) is False:
         return False
     seeds = [(seed_base + 2 + i) & 0xFFFFFFFFFFFFFFFF for i in group]
@@ -626,14 +632,14 @@ def _train_sampled_models(sampled_configurations, searchable_type, dataloaders, 
     sched = LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm, num_batches_per_epoch)
     etas = sched.eta_table(E * nb)
     shared_order = {}
-    fail_rank = int(os.environ.get("MFAS_TEST_FAIL_RANK", "-1"))      # test hook: this rank's FIRST share raises (population.train_sharded re-queues it)
+    fail_rank = _TEST_FAIL_RANK      # test hook (module attribute, set by tests only): this rank's FIRST share raises (population.train_sharded re-queues it)
     attempts = [0]
 
     def train_share(mine):
         """This rank's share (or a re-queued part of a failed rank's): {candidate index: best dev metric}."""
         attempts[0] += 1
         if world > 1 and rank == fail_rank and attempts[0] == 1:
-            raise RuntimeError("MFAS_TEST_FAIL_RANK: simulated failure of this rank's share")
+            raise RuntimeError("_TEST_FAIL_RANK: simulated failure of this rank's share")
         acc_by_idx = {}
         if mine and not per_cand and "o" not in shared_order:
             shared_order["o"] = make_order(N_tr, E, train_l.shuffle, seed_base + 1, device)

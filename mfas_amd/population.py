@@ -120,8 +120,13 @@ def train_sharded(wanted: Sequence[int], owner: Sequence[int], cap: int, K: int,
     err, got = None, {}
     try:
         got = train_share(mine)
-    except Exception as e:      # noqa: BLE001 — reported through the collective, re-raised below if nobody can take over
+    except (ValueError, TypeError, NotImplementedError, AssertionError):
+        raise                   # a programming / argument error is the same on every rank: nothing to re-queue, fail loudly here
+    except Exception as e:      # noqa: BLE001 — runtime / device errors: reported through the collective, re-queued below
         err = e
+        import traceback
+        import warnings
+        warnings.warn(f"mfas_amd: rank {rank} failed to train its share of {len(mine)} candidate(s):\n{traceback.format_exc()}")
     have = [i for i in mine if i in got]
     out, bad = gather_accuracies(have, [got[i] for i in have], K, device, cap=cap, failed=err is not None, strict=False)
     missing = [i for i in wanted if np.isnan(out[i])]
@@ -341,13 +346,18 @@ def _measure_step_us(hp, conf, K, device) -> float:
     table = FeatureTable(taps, label, multilabel=ml)
     etas = np.full(T2, 1e-3)
     pop = Population(hp, [conf] * K, device, drop_seeds=list(range(K)))
+    # the schedule the call will really run: with per-candidate sample orders the units take the gather path (a NULL order would
+    # make the probe read rows sequentially and the launch-per-phase points optimistic)
+    order = None
+    if getattr(hp, "order_per_candidate", False):
+        order = torch.stack([torch.stack([torch.randperm(N, generator=g, device=device) for _ in range(1)]) for _ in range(K)]).to(torch.int32)
     try:
         pop.init(list(range(1, K + 1)))
         best = {}
         for T in (T1, T2, T1, T2):
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
-            pop.train(table, None, 1, etas, max_steps=T)
+            pop.train(table, None, 1, etas, order=order, max_steps=T)
             best[T] = min(best.get(T, 1e30), time.perf_counter() - t0)
     finally:
         pop.close()

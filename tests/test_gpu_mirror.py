@@ -191,6 +191,8 @@ ld = {{"train": M.FeatureLoader(tr, 16, shuffle=True), "dev": M.FeatureLoader(dv
 rng = np.random.default_rng(0)
 confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in (1, 2, 3, 4, 4, 2, 1)]
 torch.manual_seed(5)
+import mfas_amd.ntu_searchable as _ns
+_ns._TEST_FAIL_RANK = int(os.environ.get("MFAS_TEST_FAIL_RANK", "-1"))      # the failure is injected by the TEST (module attribute), never by the product reading the environment
 accs = M.train_sampled_models(confs, M.Searchable_Skeleton_Image_Net, ld, args, dev)
 from mfas_amd import population as P
 hp = M.Hyper.from_args(args)
