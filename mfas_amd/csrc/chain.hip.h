@@ -354,8 +354,12 @@ __device__ __forceinline__ void softmax_rows_lean(const ChainArgs& a, float* lg_
 
 #ifdef MFAS_CHAIN_TIMING
 #define CT_STAMP(slot) do { if (threadIdx.x == 0 && bid == 0 && cs.gstep == 3) a.status[64 + (slot)] = (int32_t)(__builtin_readcyclecounter() - ct0); } while (0)
+// debug checksums (schedule bit-identity hunts): XOR of the bits of a tile wave's register image, candidate 0, global step 0
+#define CT_SUM4(slot, v4) do { if (bid == 0 && cs.gstep == 0 && is_tw) { \
+        atomicXor(&a.status[96 + (slot)], __float_as_int((v4)[0]) ^ __float_as_int((v4)[1]) ^ __float_as_int((v4)[2]) ^ __float_as_int((v4)[3])); } } while (0)
 #else
 #define CT_STAMP(slot) do { } while (0)
+#define CT_SUM4(slot, v4) do { } while (0)
 #endif
 
 template <int MB, bool PF, bool COH = false>
@@ -838,21 +842,31 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
 
 // ------------------------------------------------------------------------------------------------
 // chain_lean — the same train-step chain for ONE row block (R <= 16) and <= 4 class blocks (C <= 64): the reference's
-// search defaults (inner_representation_size 16, main_searchable_ntu.py:26-45).  A 16-wide cell is a string of ~15
-// dependent little steps, and in the general chain_body every one of them pays a workgroup barrier, fresh scalar loads of
-// the candidate record, address arithmetic for up to 32 row blocks and a global round trip for its weight tile.  Here:
-//   * everything a step needs from global memory (labels, vector block, EVERY product's weight tile, the sweep's partial
-//     sums) is requested at kernel entry — one memory latency for the whole chain;
-//   * the cells are ELEMENT-PARALLEL (round 2): wave w < 4*MB owns one element group of the 16 x 16 output block (batch-row
-//     quad w & 3 of row block w >> 2), one output element per lane; every wave recomputes the cell's tiny product (4 MFMAs)
-//     from out_{i-1} in LDS, finishes its element and keeps what the backward pass needs again (activation, x-hat, alpha
-//     difference, dropout keep-bits) in REGISTERS; one workgroup barrier per cell (three with BatchNorm, whose batch statistics
-//     cross the waves through 2 KB of LDS);
-//   * head / softmax, coalesced copies of out_i, dy_i and dlogits to the step buffers use all eight waves; everything that is
-//     not needed to publish dy — epoch statistics, bias / BatchNorm / alpha gradient sums and their Adam updates — is deferred
-//     to chain_lean_tail, which the resident persistent chain runs AFTER dy is out.
-// The arithmetic is that of chain_body except for the order in which bias / BatchNorm gradient sums are accumulated: the two
-// chain forms agree to rounding, not bit for bit; which one runs depends only on (R, C, B) — mfas_hip.hip, `lean_chain`.
+// search defaults (inner_representation_size 16, main_searchable_ntu.py:26-45).  A 16-wide cell is a string of dependent
+// little steps; what bounds a candidate's train step here is the LATENCY of that string (one workgroup, one candidate).
+//
+// Round 5 form: the chain of a 16-row batch tile lives in the REGISTERS OF ONE WAVE from the first cell to the last dy.
+// Every product is computed TRANSPOSED, out_i^T = W_i . out_{i-1}^T (A = the weight tile image, B = the activations): the
+// 16x16x4 MFMA's D block — lane (n = batch row, group lg) holds features 4*lg .. 4*lg+3 of that row — is then exactly the B
+// operand image of the next cell's four MFMAs (k = 4*lg + q for MFMA q), so a cell hands its output to the next one without a
+// shuffle, an LDS round trip or a barrier.  The same holds backwards (d_out^T = W^T . dy^T) and for the head (logits^T, four
+// class blocks in 16 registers of the row's four lanes; softmax / CE on those registers with two row-swap butterflies).
+// Wave tw < MB ("tile wave") owns batch rows 16*tw .. 16*tw + 15; the tile waves never meet unless BatchNorm needs the batch
+// statistics of both tiles (two LDS exchanges per cell forward, one backward).  Before: element-parallel cells over eight
+// waves — one LDS hand-off + workgroup barrier per cell and phase, ~1,000-2,000 shader cycles each (profiles/r05_chain_phases_
+// session_start.log: 18,700 cycles per step at R = 16, B = 20).
+//   * everything the chain needs from global memory (the sweep's partial sums, labels; launch-per-phase: vector block and the
+//     weight tiles of every product, staged in LDS) is requested at entry;
+//   * the other waves sum the partial slabs of cells 1..L-1 into LDS while the tile waves already compute cell 0 (resident
+//     schedule: its units write their slabs TRANSPOSED — MFMA operands swapped, persist.hip.h — so a tile wave's slab item is
+//     its own register image; launch-per-phase: the reduced sums are read from LDS with transposed indices);
+//   * out_i, dy_i, dlogits and the per-row loss terms are also dropped into LDS (plain writes, nobody waits for them) for what
+//     runs AFTER dy is out: chain_lean_tail (statistics, bias / BatchNorm / alpha gradient sums and their Adam updates) and the
+//     resident chain's own OUT / HEAD update (lean_res_update).
+// The arithmetic is that of chain_body except for the order in which row / column sums (BatchNorm statistics, bias gradients,
+// softmax denominators) are accumulated: the two chain forms agree to rounding, not bit for bit; which one runs depends only
+// on (R, C, B) — mfas_hip.hip, `lean_chain`.  All schedules of the lean chain (launch-per-phase, fused, resident) run THIS
+// code on the same operands and stay bit-identical to each other.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 pick4(const f32x4 (&t)[MFAS_MAX_CELLS], int i) {
     switch (i) { case 0: return t[0]; case 1: return t[1]; case 2: return t[2]; default: return t[3]; }
@@ -867,13 +881,16 @@ struct LeanRes {
     int bad;            // non-finite loss seen
 };
 #define LEAN_OWN_TILES 7   // slots 0..2: OUT_1..OUT_3, slots 3..6: head class blocks 0..3
-#define LEAN_SCR 1024      // floats: BN exchange [2][8][16] | bias-gradient partials [L][8][16] | alpha partials [L][8] | dgamma / dbeta [L][2][16]
+#define LEAN_SCR 1024      // floats: forward BN exchange [parity][sum | squares][tile][16] | +256: dgamma / dbeta [L][2][16] | +512: backward BN exchange | +768: [tile][cell][mean | rstd][16]
 
+#ifndef MFAS_RES_TRANSPOSED_SLABS
+#define MFAS_RES_TRANSPOSED_SLABS 1     // 0: debug build — the resident units keep the launch-per-phase operand order, the chain transposes in LDS
+#endif
 // LDS layout shared by chain_lean and the resident helpers
 template <int MB>
 struct LeanLds {
     static constexpr int Bp = MB * 16, Rp = 16, SX = Rp + 4, sav_plane = MFAS_MAX_CELLS * MB * 256;
-    float *xo_l, *dy_l, *lg_l, *rstd_l, *red_l, *yf_l, *vec_l, *scr, *own;
+    float *xo_l, *dy_l, *lg_l, *rstd_l, *red_l, *yf_l, *vec_l, *lgraw, *scr, *own;
     int* lab_l;
     int nvec, SC;
     __device__ __forceinline__ LeanLds(float* lds, const Geo& g) {
@@ -882,25 +899,108 @@ struct LeanLds {
         xo_l = lds;                                          // [L][Bp][SX] out_i of every cell
         dy_l = xo_l + MFAS_MAX_CELLS * Bp * SX;              // [L][Bp][SX] dy_i of every cell
         lg_l = dy_l + MFAS_MAX_CELLS * Bp * SX;              // [Bp][SC] logits -> dlogits
-        rstd_l = lg_l + Bp * SC;                             // [L][Rp]
+        rstd_l = lg_l + Bp * SC;                             // [L][Rp] (unused since round 5: gamma * rstd stays in registers)
         red_l = rstd_l + MFAS_MAX_CELLS * Rp;                // [2*Bp + 16]
         lab_l = reinterpret_cast<int*>(red_l + 2 * Bp + 16); // [Bp]
         yf_l = reinterpret_cast<float*>(lab_l + Bp);         // [1 or 2][L][MB][256] reduced feature sums
         vec_l = yf_l + (g.alphas ? 2 : 1) * sav_plane;       // [3][nvec] vector block + Adam state
-        // (activations / x-hat / alpha differences needed by the backward live in the owning lanes' registers)
-        scr = vec_l + ((3 * nvec + 3) & ~3);                 // cross-wave exchange scratch (LEAN_SCR floats)
-        own = scr + LEAN_SCR;                                                                 // resident: [W|M|V|T][7 tiles][256]
+        lgraw = vec_l + ((3 * nvec + 3) & ~3);               // [Bp][64] raw logits of the step (register softmax: the tail's statistics read them)
+        scr = lgraw + Bp * 64;                               // cross-wave exchange scratch (LEAN_SCR floats)
+        own = scr + LEAN_SCR;        // resident: [W|M|V|T][7 tiles][256], the master copy; otherwise [W|T][7 tiles][256] staged at entry
     }
     static __host__ __device__ constexpr int own_floats() { return 4 * LEAN_OWN_TILES * 256; }
+    static __host__ __device__ constexpr int stage_floats() { return 2 * LEAN_OWN_TILES * 256; }
+    // tile image of slot s (OUT_{s+1} / head block s-3) as the A operand of the forward products, and its transposed image
+    template <bool RES> __device__ __forceinline__ float* wtile(int s) const { return own + s * 256; }
+    template <bool RES> __device__ __forceinline__ float* ttile(int s) const { return own + ((RES ? 3 : 1) * LEAN_OWN_TILES + s) * 256; }
 };
 
-// MODE 0: launch-per-phase schedule; 1: persistent, everything exchanged through memory (write-through / sc1);
-// 2: persistent AND resident (LeanRes): vector block, OUT / HEAD weights and statistics live on chip, the chain's only
-// global traffic per step is the sweep's partial sums in and dy (+ alpha scales) out.
-template <int MB, int MODE = 0, int PB = 16>
-__device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds, LeanRes* rs = nullptr) {
+// own-tile plane offsets of slot s: OUT_{s+1} (s < 3), head class block s-3
+__device__ __forceinline__ int64_t lean_own_off(const CandDev& cd, int s) { return s < 3 ? cd.seg_off[s + 1][2] : cd.head_off + ((int64_t)(s - 3) << 8); }
+__device__ __forceinline__ int64_t lean_own_toff(const CandDev& cd, int s) { return s < 3 ? cd.outT_off[s + 1] : cd.headT_off + ((int64_t)(s - 3) << 8); }
+__device__ __forceinline__ bool lean_own_live(const CandDev& cd, const Geo& g, int s) { return s < 3 ? (s + 1 < cd.L) : (s - 3 < g.ncb); }
+
+// max over the 4 lane groups that share (lane & 15) (colsum's butterflies, common.hip.h)
+__device__ __forceinline__ float colmax(float x) {
+    int xi = __float_as_int(x);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    x = fmaxf(__int_as_float(r16[0]), __int_as_float(r16[1]));
+    xi = __float_as_int(x);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    return fmaxf(__int_as_float(r32[0]), __int_as_float(r32[1]));
+}
+__device__ __forceinline__ f32x4 row_sum16_4(f32x4 v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = row_sum<16>(v[q]);
+    return v;
+}
+// The lean chain's activations on the 4 features a lane holds of its batch row (nl is wave-uniform: one branch, four independent
+// strings).  Sigmoid: 1 / (1 + 2^(-y log2 e)) on v_exp_f32 and v_rcp_f32 — absolute error <= 1.5e-7 (an activation is an absolute
+// quantity: it is summed with O(1) terms by the next product), 4 instructions per element where expf() and the IEEE division take
+// ~35 in one dependent string; +-inf and NaN behave as in the library form (rcp(inf) = 0).  ReLU / LeakyReLU: act_fwd's.
+__device__ __forceinline__ f32x4 act_fwd4_lean(const f32x4 y, const int nl) {
+    f32x4 v;
+    if (nl == 1) {
+        const f32x4 t = y * -1.44269504088896341f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[q]));
+    } else if (nl == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = y[q] <= 0.0f ? 0.0f : y[q];
+    } else {
+        const f32x4 s = y * 0.01f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = y[q] > 0.0f ? y[q] : s[q];
+    }
+    return v;
+}
+__device__ __forceinline__ f32x4 act_bwd4_lean(const f32x4 a, const f32x4 da, const int nl) {
+    f32x4 d;
+    if (nl == 1) {
+        d = da * ((f32x4)(1.0f) - a) * a;
+    } else if (nl == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = a[q] <= 0.0f ? 0.0f : da[q];
+    } else {
+        const f32x4 s = da * 0.01f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = a[q] > 0.0f ? da[q] : s[q];
+    }
+    return d;
+}
+// dropout keep-bits of a tile-wave lane's 4 features in every cell of train step `gstep`: bit 4 * cell + q (oracle/np_oracle.py:
+// dropout_keep).  The resident chain computes step t + 1's bits after it has published step t's dy (persist.hip.h).
+template <int MB>
+__device__ __forceinline__ uint32_t lean_keep_bits(const CandDev& cd, const Geo& g, const int gstep) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (!g.use_drop) return 0xFFFFu;
+    uint32_t bits = 0u;
+    if (wave < MB) {
+        const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(gstep + 1));
+        const uint32_t idx0 = (uint32_t)((wave * 16 + (lane & 15)) * g.R + 4 * (lane >> 4));
+#pragma unroll
+        for (int i = 0; i < MFAS_MAX_CELLS; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (drop_keep(h0, i, idx0 + q, g.drop_thr)) bits |= 1u << (4 * i + q);
+    }
+    return bits;
+}
+// does this population's loss run on the tile waves' registers (softmax / CE, single task, no external gradient)?
+__device__ __forceinline__ bool lean_ce_in_regs(const ChainArgs& a) { return a.g.loss_mode == 0 && !a.g.multitask && !a.dlogits_in; }
+
+// MODE 0: launch-per-phase schedule; 2: persistent AND resident (LeanRes): vector block, OUT / HEAD weights and statistics live
+// on chip, the chain's only global traffic per step is the sweep's partial sums in and dy (+ alpha scales) out; `keep_pre` = the
+// step's dropout keep-bits (lean_keep_bits), computed a step ahead.
+// (MODE 1 — persistent, everything exchanged through memory — went with the streaming persistent form in round 3.)
+// PLAIN: the search default compiled on its own — no BatchNorm, no alphas, softmax CE, no external logits / gradients: the flags
+// are compile-time false, their uniform values need no scalar registers and their branches are gone.
+template <int MB, int MODE = 0, int PB = 16, bool PLAIN = false>
+__device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds, LeanRes* rs = nullptr,
+                                           const uint32_t keep_pre = 0u) {
     constexpr bool COH = MODE >= 1;
     constexpr bool RES = MODE == 2;
+    constexpr bool TS = RES && (MFAS_RES_TRANSPOSED_SLABS != 0);      // the partial slabs arrive transposed (resident units, persist.hip.h)
 #ifdef MFAS_CHAIN_TIMING
     const unsigned long long ct0 = __builtin_readcyclecounter();
 #endif
@@ -913,21 +1013,17 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     constexpr int Rp = 16, SX = Rp + 4;
     const int Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L, SC = Cp + 4;
     constexpr int sav_plane = MFAS_MAX_CELLS * MB * 256;
+    const bool f_bn = PLAIN ? false : (g.bn != 0);
+    const bool f_alphas = PLAIN ? false : (g.alphas != 0);
     const LeanLds<MB> ll(lds, g);
     const int nvec = ll.nvec;
     float* xo_l = ll.xo_l;
     float* dy_l = ll.dy_l;
     float* lg_l = ll.lg_l;
-    float* rstd_l = ll.rstd_l;
     float* red_l = ll.red_l;
     int* lab_l = ll.lab_l;
     float* yf_l = ll.yf_l;
     float* vec_l = ll.vec_l;
-    // vector-parameter updates: memory (MODE 0 / 1) or the resident LDS copy (MODE 2; flushed at the end of the launch)
-    auto put_vec = [&](int64_t o, float w, float m, float v) {
-        if constexpr (RES) { const int e = (int)(o - cd.vec_off); vec_l[e] = w; vec_l[nvec + e] = m; vec_l[2 * nvec + e] = v; }
-        else { a.plane[o] = w; a.plane[a.plane_stride + o] = m; a.plane[2 * a.plane_stride + o] = v; }
-    };
 
     float* W = a.plane;
     float* Mv = a.plane + a.plane_stride;
@@ -940,29 +1036,28 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
     const int nvalid = cs.nvalid;
     const float nf = (float)nvalid;
-    const AdamC ac = adam_consts(a.ac, cs.ss, cs.bc2s);
-    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(cs.gstep + 1));
     const int64_t sbo = cd.step_off;
+    // tile wave tw = wave < MB: batch row b_row = 16 * tw + l15, features 4 * lg + q in register q
+    const bool is_tw = wave < MB;
+    const int b_row = (is_tw ? wave : 0) * 16 + l15;
+    const bool rowok = b_row < nvalid;
+    const int r0 = 4 * lg;
 
     // ------------------------------------------------------------------ entry: every global read of the chain is
     // requested here, in the order the results are needed (the memory counter retires in order): the sweep's partial
-    // sums first, then the vector block, the weight tiles of all products and last the labels (a dependent pair of loads
-    // that nothing needs before the loss, fetched by wave 1 so that wave 0 never waits for them)
+    // sums first, then (launch-per-phase) the vector block and the weight tiles of all products, last the labels
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int per_cell = MB * 64;   // float4 partial-sum items per cell; L * per_cell <= 512: one item per thread
     // PB = partial-sum chunks requested per thread before any is consumed (16; 8 in the 128-VGPR co-scheduled builds of k_step)
     const bool has_item = tid < L * per_cell;
-    // (per_cell = MB * 64: the cell index is wave-uniform -> scalar loads of cd.nch_* / part_cell_off)
+    // (per_cell = MB * 64: the cell index is wave-uniform -> scalar loads of cd.nch_* / part_cell_off; wave w sums the slabs of
+    //  cell w / MB for batch tile w % MB — the tile waves hold cell 0's)
     const int pi = __builtin_amdgcn_readfirstlane(has_item ? tid / per_cell : 0), pit = tid - pi * per_cell;
     const int ns = cd.nch_s[pi], nch = has_item ? ns + cd.nch_v[pi] : 0;
     const int64_t part = sbo + g.sb_part + (((int64_t)cd.part_cell_off[pi] * MB) << 8) + pit * 4;
-    // every load below is UNCONDITIONAL (indices clamped to something valid): with a statically known number of loads in
-    // flight the compiler can wait for exactly the ones it consumes instead of draining the whole queue at first use
     f32x4 p8[PB];
     if constexpr (RES) {
-        // resident chain: only the slabs that exist (wave-uniform count -> scalar branches).  The unconditional form below re-requests
-        // slab 0 for every missing one — 16 requests per thread for the 2-4 slabs per cell of 256...1024-column units: 128 KB of
-        // requests through this one CU's memory pipeline per step for 30-60 KB of partial sums, on the critical path.
+        // resident chain: only the slabs that exist (wave-uniform count -> scalar branches)
         const int nch_u = __builtin_amdgcn_readfirstlane(nch);
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
@@ -970,127 +1065,128 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             if (u < nch_u) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)u * MB) << 8));
         }
     } else {
+        // every load UNCONDITIONAL (indices clamped to something valid): with a statically known number of loads in flight the
+        // compiler waits for exactly the ones it consumes instead of draining the whole queue at first use
 #pragma unroll
-    for (int u = 0; u < PB; ++u) {
-        const int uu = u < nch ? u : 0;
-        p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)uu * MB) << 8));
-    }
+        for (int u = 0; u < PB; ++u) {
+            const int uu = u < nch ? u : 0;
+            p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)uu * MB) << 8));
+        }
     }
     const int vi = tid < nvec ? tid : 0;   // nvec = 4 * 96 + Cp <= 448: one element of the vector block per thread
     float vw = 0.f, vm = 0.f, vv = 0.f;
-    if constexpr (!RES) { vw = W[cvec_off + vi]; vm = Mv[cvec_off + vi]; vv = Vv[cvec_off + vi]; }
-    // weight tiles of every product (all waves fetch them — 11 KiB, uniform control flow; wave 0 / waves < ncb use them)
-    f32x4 tP[MFAS_MAX_CELLS], tT[MFAS_MAX_CELLS], tHT[4], tH;   // prev-out tile of cell i, its transpose, head^T, head
-    tP[0] = z4; tT[0] = z4;
-    if constexpr (RES) {   // the chain owns these weights: LDS-resident images (slot i-1: OUT_i, slot 3+u: head block u), read where
-                           // they are used (an LDS read costs ~100 cycles; 13 tiles held from entry cost 52 VGPRs and spilled)
-#pragma unroll
-        for (int i = 1; i < MFAS_MAX_CELLS; ++i) { tP[i] = z4; tT[i] = z4; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) tHT[u] = z4;
-        tH = z4;
-    } else {
-#pragma unroll
-        for (int i = 1; i < MFAS_MAX_CELLS; ++i) {
-            // (cells beyond L: any valid address — the loads stay unconditional, their values are never used)
-            tP[i] = ldc4<COH>(W, (i < L ? cd.seg_off[i][2] : cvec_off) + lane * 4);
-            tT[i] = ldc4<COH>(a.wt, (i < L ? cd.outT_off[i] : cd.headT_off) + lane * 4);
+    f32x4 st0 = z4, st1 = z4;              // launch-per-phase: the 14 weight tile images, two 16-byte items per thread
+    if constexpr (!RES) {
+        vw = W[cvec_off + vi]; vm = Mv[cvec_off + vi]; vv = Vv[cvec_off + vi];
+        {
+            const int s = wave;            // item tid: slot wave (0..7) = W images 0..6, T image 0
+            const bool live = s < LEAN_OWN_TILES ? lean_own_live(cd, g, s) : lean_own_live(cd, g, 0);
+            const float* base = s < LEAN_OWN_TILES ? W : a.wt;
+            const int64_t off = s < LEAN_OWN_TILES ? lean_own_off(cd, s) : lean_own_toff(cd, 0);
+            st0 = ldc4<COH>(base, (live ? off : (s < LEAN_OWN_TILES ? cvec_off : cd.headT_off)) + lane * 4);
+            if (!live) st0 = z4;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            tHT[u] = ldc4<COH>(a.wt, cd.headT_off + ((int64_t)(u < ncb ? u : 0) << 8) + lane * 4);
-        tH = ldc4<COH>(W, cd.head_off + ((int64_t)(wave < ncb ? wave : 0) << 8) + lane * 4);
+        {
+            const int s = wave + 1;        // item 512 + tid: T images 1..6 (waves 0..5)
+            const bool in = s < LEAN_OWN_TILES;
+            const bool live = in && lean_own_live(cd, g, in ? s : 0);
+            st1 = ldc4<COH>(a.wt, (live ? lean_own_toff(cd, s) : cd.headT_off) + lane * 4);
+            if (!live) st1 = z4;
+        }
     }
-    const int r = l15;
-    const bool colok = r < R;
-    // phase 0: reduce the sweep's column-chunk partial sums (fixed order) into LDS; stage the vector block.
-    // Resident chain (round 5): only cell 0's sums are waited for here — the waves that hold the slabs of cells 1..L-1 (the cell
-    // index is wave-uniform) consume theirs at the end of cell 0's forward, so the 3/4 of the slab bytes that cell 0 does not need
-    // stream into this CU while cell 0 is computed instead of in front of it (the chain spent ~5,000 of ~14,000 cycles per step
-    // between "units have arrived" and "sums in LDS": profiles/r04_chain_phases.log, slot 0).
-// (a macro, not a lambda: with the slab registers captured by reference the closure keeps p8[] addressable and the whole array
-//  lands in scratch memory — 272 bytes per lane, measured: entry 5,400 -> 15,900 cycles)
-#define LEAN_CONSUME() do { \
-        f32x4 accS = z4, accV = z4; \
-_Pragma("unroll") \
-        for (int u = 0; u < PB; ++u) \
-            if (u < nch) { \
-                if (u < ns) accS += p8[u]; else accV += p8[u]; \
-            } \
-        for (int ch0 = PB; ch0 < nch; ch0 += PB) { \
-_Pragma("unroll") \
-            for (int u = 0; u < PB; ++u) \
-                if (ch0 + u < nch) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)(ch0 + u) * MB) << 8)); \
-_Pragma("unroll") \
-            for (int u = 0; u < PB; ++u) \
-                if (ch0 + u < nch) { \
-                    if (ch0 + u < ns) accS += p8[u]; else accV += p8[u]; \
-                } \
-        } \
-        if (g.alphas) { \
-            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS; \
-            *reinterpret_cast<f32x4*>(yf_l + sav_plane + tid * 4) = accV; \
-        } else { \
-            *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS + accV; \
-        } \
-    } while (0)
-    // dropout keep-bits of this lane's element in every cell (a few dozen integer instructions: issued under the slab loads)
-    const int ew = wave, emb = ew >> 2, eq = ew & 3;
-    const bool eact = ew < MB * 4;
-    const int eb = emb * 16 + 4 * lg + eq;                  // this lane's batch row
-    uint32_t ekeep = 0xFu;
-    if (g.use_drop) {
-        ekeep = 0u;
-#pragma unroll
-        for (int i = 0; i < MFAS_MAX_CELLS; ++i)
-            if (drop_keep(h0, i, (uint32_t)(eb * R + r), g.drop_thr)) ekeep |= 1u << i;
+    // labels of this tile wave's rows (a dependent pair of loads that nothing needs before the loss)
+    int lab = 0;
+    if (is_tw && rowok) {
+        const int32_t* ord = cand_order(a.order, g, cgidx);
+        const int64_t row = ord ? (int64_t)ord[cs.pos_t + b_row] : (int64_t)(cs.base_t + b_row);
+        lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
     }
-    if constexpr (RES) {
-        if (has_item && pi == 0) LEAN_CONSUME();
-    } else {
-        if (has_item) LEAN_CONSUME();
+    // dropout keep-bits of this lane's 4 features in every cell (bit 4 * i + q), with "feature exists" and "row is in the batch"
+    // folded in: one select per element zeroes dropped, padded and out-of-batch elements alike, forward and backward
+    uint32_t ekeep = RES ? keep_pre : lean_keep_bits<MB>(cd, g, cs.gstep);
+    {
+        uint32_t m4 = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m4 |= (r0 + q < R && rowok) ? (1u << q) : 0u;
+        ekeep &= m4 * 0x1111u;
+    }
+    const float dscale = g.use_drop ? g.drop_scale : 1.0f;
+    // phase 0: sum the sweep's column-chunk partial slabs of (cell pi, tile) in fixed order: S chunks, then V chunks
+    f32x4 accS = z4, accV = z4;
+    if (has_item) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+            if (u < nch) {
+                if (u < ns) accS += p8[u]; else accV += p8[u];
+            }
+        for (int ch0 = PB; ch0 < nch; ch0 += PB) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+                if (ch0 + u < nch) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)(ch0 + u) * MB) << 8));
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+                if (ch0 + u < nch) {
+                    if (ch0 + u < ns) accS += p8[u]; else accV += p8[u];
+                }
+        }
+        // resident: cell 0's sums stay in the tile waves' registers (transposed slabs: the item IS the lane's register image)
+        if (!(TS && pi == 0)) {
+            if (f_alphas) {
+                *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS;
+                *reinterpret_cast<f32x4*>(yf_l + sav_plane + tid * 4) = accV;
+            } else {
+                *reinterpret_cast<f32x4*>(yf_l + tid * 4) = accS + accV;
+            }
+        }
     }
     if constexpr (!RES) {
         if (tid < nvec) { vec_l[tid] = vw; vec_l[nvec + tid] = vm; vec_l[2 * nvec + tid] = vv; }
-    }
-    // labels: a dependent pair of loads that nothing needs before the loss; requested last, by wave 1, consumed after the
-    // forward pass
-    int lab = 0;
-    if (wave == 1 && lane < nvalid) {
-        const int32_t* ord = cand_order(a.order, g, cgidx);
-        const int64_t row = ord ? (int64_t)ord[cs.pos_t + lane] : (int64_t)(cs.base_t + lane);
-        lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
+        *reinterpret_cast<f32x4*>(ll.own + (wave << 8) + lane * 4) = st0;
+        if (wave + 1 < LEAN_OWN_TILES) *reinterpret_cast<f32x4*>(ll.own + ((LEAN_OWN_TILES + wave + 1) << 8) + lane * 4) = st1;
+        lds_barrier();
+    } else if constexpr (!TS) {
+        lds_barrier();
     }
     const float* vecW = vec_l;
-    const float* vecM = vec_l + nvec;
-    const float* vecV = vec_l + 2 * nvec;
-    lds_barrier();
     CT_STAMP(0);
 
-    // ------------------------------------------------------------------ forward: ELEMENT-PARALLEL over the waves.
-    // A 16-wide cell is ~150 dependent VALU / transcendental instructions per lane when one wave owns all Bp x 16 outputs (8 per
-    // lane at B = 20); here wave w < 4*MB owns ONE element row group — batch rows mb*16 + 4*lg + q with (mb, q) = (w >> 2, w & 3)
-    // — every wave recomputes the cell's tiny product (4 MFMAs) from the shared out_{i-1} in LDS and finishes one element per
-    // lane, then one workgroup barrier hands out_i to the next cell.  BatchNorm's batch statistics and the backward's column
-    // sums are exchanged through LDS (fixed order over the waves).  What each lane needs again in the backward (activation,
-    // x-hat, alpha difference) stays in its registers.
-    float* bnw = ll.scr;                                     // [2][8][16] cross-wave column sums
+    // reduced feature sums of (cell i, this tile) in the transposed register image: S and V parts
+    auto cell_sums = [&](const int i, f32x4& yS, f32x4& yV) {
+        const int o = (i * MB + wave) << 8;
+        if constexpr (TS) {
+            yS = *reinterpret_cast<const f32x4*>(yf_l + o + lane * 4);
+            if (f_alphas) yV = *reinterpret_cast<const f32x4*>(yf_l + sav_plane + o + lane * 4);
+        } else {
+            // the launch-per-phase sweeps write the D image of x . W^T (lane: feature l15, batch rows 4*lg + q): read it transposed
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int at = o + ((((l15 >> 2) << 4) + r0 + q) << 2) + (l15 & 3);
+                yS[q] = yf_l[at];
+                if (f_alphas) yV[q] = yf_l[sav_plane + at];
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------ forward, in the tile waves' registers
+    float* bnw = ll.scr;                                     // BN exchange: [parity][sum | sum of squares][tile][16]
     float* gv2 = ll.scr + 256;                               // [cell][dgamma | dbeta][16]
-    auto sel4 = [&](const f32x4& v4) -> float { return eq == 0 ? v4[0] : (eq == 1 ? v4[1] : (eq == 2 ? v4[2] : v4[3])); };
-    float av[MFAS_MAX_CELLS], xhs[MFAS_MAX_CELLS], dsv[MFAS_MAX_CELLS];
+    float* bst = ll.scr + 768 + (is_tw ? wave : 0) * 128;     // this tile wave's copy of every cell's batch mean | rstd: [cell][2][16]
+    f32x4 av[MFAS_MAX_CELLS];                                 // activations: all the backward needs again in registers (x-hat is recomputed
+                                                              // from the batch statistics, the alpha differences wait in the dead sums plane)
+    f32x4 o_prev = z4;
+    bool cm[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cm[q] = r0 + q < R;
 #pragma unroll
     for (int i = 0; i < MFAS_MAX_CELLS; ++i) {
-        av[i] = 0.f; xhs[i] = 0.f; dsv[i] = 0.f;
+        av[i] = z4;
         if (i < L) {      // (workgroup-uniform)
             CT_STAMP(1 + i);
             const int nl = (nlbits >> (2 * i)) & 3;
             const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
             const int vbl = i * g.vec_cell_stride;
-            const float bias = vecW[vbl + VEC_B * Rp + r];
-            float gam = 1.f, bet = 0.f;
-            if (g.bn) { gam = vecW[vbl + VEC_G * Rp + r]; bet = vecW[vbl + VEC_BE * Rp + r]; }
             float sgS = 1.0f, sgV = 1.0f;
-            if (g.alphas) {
+            if (f_alphas) {
                 const float sg = 1.0f / (1.0f + expf(-vecW[vbl + 5 * Rp]));
                 sgS = sg;
                 sgV = 1.0f - sg;
@@ -1099,215 +1195,301 @@ _Pragma("unroll") \
                     stc1<COH>(sb + g.sb_gsc + i * 2 + 1, sgV);
                 }
             }
-            float v = 0.f;
-            if (eact) {
-                const int o = ((i * MB + emb) << 8) + lane * 4;
-                f32x4 acc = *reinterpret_cast<const f32x4*>(yf_l + o);
-                if (g.alphas) {
-                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yf_l + sav_plane + o);
-                    dsv[i] = sel4(acc) - sel4(yv);
-                    acc = acc * sgS + yv * sgV;
+            if constexpr (TS) {
+                if (i == 1) lds_barrier();     // the other waves' sums of cells 1..L-1 are in LDS (they got there under cell 0)
+            }
+            f32x4 v = z4, s1 = z4;
+            if (is_tw) {
+                f32x4 yS = accS, yV = accV;
+                if (!TS || i > 0) { yS = z4; yV = z4; cell_sums(i, yS, yV); }
+                else if (!f_alphas) yS = accS + accV;
+                f32x4 acc = yS;
+                CT_SUM4(i, acc);
+                if (f_alphas) {
+                    // (yS - yV) for d(alpha_i): parked in this lane's slot of the (now read) sums plane until the backward
+                    *reinterpret_cast<f32x4*>(yf_l + ((i * MB + wave) << 8) + lane * 4) = yS - yV;
+                    acc = yS * sgS + yV * sgV;
                 }
                 if (i > 0) {
-                    f32x4 w;
-                    if constexpr (RES) w = *reinterpret_cast<const f32x4*>(ll.own + ((i - 1) << 8) + lane * 4);
-                    else w = pick4(tP, i);
-                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(xo_l + (i - 1) * Bp * SX + (emb * 16 + l15) * SX + 4 * lg);
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(ll.template wtile<RES>(i - 1) + lane * 4);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], w[q], acc);
+                    for (int q = 0; q < 4; ++q) acc = MFMA16(w[q], o_prev[q], acc);
                 }
-                v = act_fwd(sel4(acc) + bias, nl);
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(vecW + vbl + VEC_B * Rp + r0);
+                v = act_fwd4_lean(acc + bias, nl);
+                if (f_bn) s1 = row_sum16_4(rowok ? v : z4);
             }
-            float z = v;
-            if (g.bn) {   // batch statistics over the valid rows: two exchanges (mean, then the variance of the deviations)
-                float s1 = colsum((eact && eb < nvalid) ? v : 0.f);
-                if (lg == 0) bnw[ew * 16 + r] = s1;
-                lds_barrier();
-                float tot = 0.f;
+            f32x4 z = v;
+            if (f_bn) {   // batch statistics over the valid rows: mean, then the variance of the deviations
+                float* ex = bnw + (i & 1) * 128;
+                f32x4 tot = s1;
+                if constexpr (MB > 1) {
+                    if (is_tw && l15 == 0) *reinterpret_cast<f32x4*>(ex + wave * 16 + r0) = s1;
+                    lds_barrier();
+                    if (is_tw) tot = *reinterpret_cast<const f32x4*>(ex + r0) + *reinterpret_cast<const f32x4*>(ex + 16 + r0);
+                }
+                f32x4 mu = z4, s2 = z4;
+                if (is_tw) {
 #pragma unroll
-                for (int w = 0; w < MB * 4; ++w) tot += bnw[w * 16 + r];
-                const float mu = tot / nf;
-                const float dlt = v - mu;
-                float s2 = colsum((eact && eb < nvalid) ? dlt * dlt : 0.f);
-                if (lg == 0) bnw[128 + ew * 16 + r] = s2;
-                lds_barrier();
-                float tot2 = 0.f;
+                    for (int q = 0; q < 4; ++q) mu[q] = tot[q] / nf;
+                    const f32x4 dlt = v - mu;
+                    s2 = row_sum16_4(rowok ? dlt * dlt : z4);
+                }
+                f32x4 tot2 = s2;
+                if constexpr (MB > 1) {
+                    if (is_tw && l15 == 0) *reinterpret_cast<f32x4*>(ex + 64 + wave * 16 + r0) = s2;
+                    lds_barrier();
+                    if (is_tw) tot2 = *reinterpret_cast<const f32x4*>(ex + 64 + r0) + *reinterpret_cast<const f32x4*>(ex + 64 + 16 + r0);
+                }
+                if (is_tw) {
+                    const f32x4 gam = *reinterpret_cast<const f32x4*>(vecW + vbl + VEC_G * Rp + r0);
+                    const f32x4 bet = *reinterpret_cast<const f32x4*>(vecW + vbl + VEC_BE * Rp + r0);
+                    f32x4 var, rstd;
 #pragma unroll
-                for (int w = 0; w < MB * 4; ++w) tot2 += bnw[128 + w * 16 + r];
-                const float var = tot2 / nf;
-                const float rstd = 1.0f / sqrtf(var + g.bn_eps);
-                const float xh = (v - mu) * rstd;
-                xhs[i] = xh;
-                z = xh * gam + bet;
-                if (wave == 0 && lg == 0) {
-                    rstd_l[i * Rp + r] = rstd;
-                    if (colok) {   // running stats: momentum 0.1, unbiased variance
-                        float rm = vecW[vbl + VEC_RM * Rp + r], rv = vecW[vbl + VEC_RV * Rp + r];
-                        const float unb = var * (nf / (nf - 1.0f));
-                        rm += g.bn_mom * (mu - rm);
-                        rv += g.bn_mom * (unb - rv);
-                        if constexpr (RES) { vec_l[vbl + VEC_RM * Rp + r] = rm; vec_l[vbl + VEC_RV * Rp + r] = rv; }
-                        else { W[vb + VEC_RM * Rp + r] = rm; W[vb + VEC_RV * Rp + r] = rv; }
+                    for (int q = 0; q < 4; ++q) {
+                        var[q] = tot2[q] / nf;
+                        rstd[q] = 1.0f / sqrtf(var[q] + g.bn_eps);
+                    }
+                    const f32x4 xh = (v - mu) * rstd;
+                    z = xh * gam + bet;
+                    if (l15 == 0) {
+                        *reinterpret_cast<f32x4*>(bst + i * 32 + r0) = mu;
+                        *reinterpret_cast<f32x4*>(bst + i * 32 + 16 + r0) = rstd;
+                    }
+                    if (wave == 0 && l15 == 0) {   // running stats: momentum 0.1, unbiased variance
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (cm[q]) {
+                                float rm = vecW[vbl + VEC_RM * Rp + r0 + q], rv = vecW[vbl + VEC_RV * Rp + r0 + q];
+                                const float unb = var[q] * (nf / (nf - 1.0f));
+                                rm += g.bn_mom * (mu[q] - rm);
+                                rv += g.bn_mom * (unb - rv);
+                                if constexpr (RES) { vec_l[vbl + VEC_RM * Rp + r0 + q] = rm; vec_l[vbl + VEC_RV * Rp + r0 + q] = rv; }
+                                else { W[vb + VEC_RM * Rp + r0 + q] = rm; W[vb + VEC_RV * Rp + r0 + q] = rv; }
+                            }
                     }
                 }
             }
-            av[i] = v;
-            if (eact) {
-                float o = z;
-                if (g.use_drop) o = ((ekeep >> i) & 1u) ? o * g.drop_scale : 0.0f;
-                if (!(colok && eb < nvalid)) o = 0.0f;
-                xo_l[i * Bp * SX + eb * SX + r] = o;
+            if (is_tw) {
+                av[i] = v;
+                const f32x4 zs = z * dscale;
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (ekeep & (1u << (4 * i + q))) ? zs[q] : 0.0f;
+                o_prev = o;
+                CT_SUM4(4 + i, o);
+                // for the updates that run after dy is out (x operand of OUT_{i+1} / HEAD): LDS, and the step buffer when the sweep owns them
+                *reinterpret_cast<f32x4*>(xo_l + i * Bp * SX + b_row * SX + r0) = o;
+                if constexpr (!RES) stc4<COH>(a.stepbuf, sbo + g.sb_xo + (int64_t)(i * Bp + b_row) * Rp + r0, o);
             }
-            if constexpr (RES) {
-                if (i == 0 && has_item && pi > 0) LEAN_CONSUME();     // the other cells' sums (see phase 0)
-            }
-            if (i + 1 < L) lds_barrier();     // (the last cell's hand-off is the barrier below)
         }
     }
-    if (wave == 1 && lane < Bp) lab_l[lane] = lab;   // visible to the loss after the head's barrier
-    lds_barrier();
     CT_STAMP(5);
 
-    // ------------------------------------------------------------------ out_i -> step buffer (x operand of the sweep's
-    // OUT / HEAD segments), coalesced, by everyone; head on waves < ncb
-    {
-        if constexpr (!RES) {   // (the resident chain updates OUT / HEAD itself: no sweep reads out_i)
-            float* xo_g = sb + g.sb_xo;   // [L][Bp][Rp]
-            for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(xo_g + e, xo_l[(e >> 4) * SX + (e & 15)]);
-        }
-        const float* xl = xo_l + (L - 1) * Bp * SX;
-        if (wave < ncb) {
-            const int c = wave * 16 + l15;
-            const float bias = vecW[g.vec_head + c];
-            if constexpr (RES) tH = *reinterpret_cast<const f32x4*>(ll.own + ((3 + wave) << 8) + lane * 4);
+    // ------------------------------------------------------------------ head: logits^T, class 16 * cb + 4 * lg + q of this lane's row
+    f32x4 lgt[4];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
+    for (int cb = 0; cb < 4; ++cb) lgt[cb] = z4;
+    if (is_tw) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+            if (cb < ncb) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(ll.template wtile<RES>(3 + cb) + lane * 4);
                 f32x4 acc = z4;
-                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xl + (mb * 16 + l15) * SX + 4 * lg);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], tH[q], acc);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) lg_l[(mb * 16 + 4 * lg + q) * SC + c] = acc[q] + bias;
+                for (int q = 0; q < 4; ++q) acc = MFMA16(w[q], o_prev[q], acc);
+                lgt[cb] = acc + *reinterpret_cast<const f32x4*>(vecW + g.vec_head + cb * 16 + r0);
             }
-        }
     }
-    lds_barrier();
     CT_STAMP(6);
-    if constexpr (MODE == 0) {
+    CT_SUM4(8, lgt[0]); CT_SUM4(8, lgt[1]); CT_SUM4(8, lgt[2]); CT_SUM4(8, lgt[3]);
+    if constexpr (MODE == 0 && !PLAIN) {
         if (a.logits_out) {   // train-mode forward only
-            for (int e = tid; e < nvalid * C; e += CHAIN_THREADS) {
-                const int b = e / C, c = e - b * C;
-                a.logits_out[e] = lg_l[b * SC + c];
+            if (is_tw && rowok) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = cb * 16 + r0 + q;
+                        if (c < C) a.logits_out[(int64_t)b_row * C + c] = lgt[cb][q];
+                    }
             }
             return;
         }
     }
-    if (a.dlogits_in) {     // the caller's dL/dlogits instead of the loss gradient (rows / classes beyond the batch: 0)
-        for (int e = tid; e < Bp * Cp; e += CHAIN_THREADS) {
-            const int b = e / Cp, c = e - b * Cp;
-            lg_l[b * SC + c] = (b < nvalid && c < C) ? a.dlogits_in[(int64_t)b * C + c] : 0.f;
+    if (!PLAIN && a.dlogits_in) {     // the caller's dL/dlogits instead of the loss gradient (rows / classes beyond the batch: 0)
+        if (is_tw) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = cb * 16 + r0 + q;
+                    lgt[cb][q] = (rowok && c < C) ? a.dlogits_in[(int64_t)b_row * C + c] : 0.f;
+                }
         }
-    } else if (g.loss_mode == 1) {
-        if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
-    } else if (!g.multitask) {
-        if (tid < 8 * Bp) softmax_rows_lean<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
-    } else if (tid < LPR * Bp) {
-        softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
+    } else if (PLAIN || (g.loss_mode == 0 && !g.multitask)) {
+        // softmax / cross entropy on the registers (train_searchable/ntu.py:53-61): the row's 64 class slots sit in 16 registers of
+        // its four lanes; max and sum cross the lane groups with two row-swap butterflies.  Only what dy needs runs here:
+        //   e_c = 2^(x_c log2 e - m),  m = rounded(max_c x_c * log2 e)  (ONE rounded m for the whole row: the probabilities
+        //   e_c / sum e do not depend on its rounding; v_exp_f32: absolute error <= 1e-7 of the probability),
+        //   dlogits_c = e_c * (1/sum)(1/n) - [c = label] (1/n)   (reciprocals by v_rcp_f32 + one Newton step).
+        // The row's loss and top-1 hit — statistics — are computed by chain_lean_tail (after dy is out) from the raw logits parked
+        // in LDS and (m, sum e) in red_l.
+        if (is_tw) {
+            constexpr float L2E = 1.44269504088896341f;
+            f32x4 xv[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                *reinterpret_cast<f32x4*>(ll.lgraw + b_row * 64 + cb * 16 + r0) = lgt[cb];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[cb][q] = (cb * 16 + r0 + q < C) ? lgt[cb][q] : -3.0e38f;      // (only the last class block has padding)
+            }
+            float mxl = fmaxf(fmaxf(xv[0][0], xv[0][1]), fmaxf(xv[0][2], xv[0][3]));
+#pragma unroll
+            for (int cb = 1; cb < 4; ++cb) mxl = fmaxf(mxl, fmaxf(fmaxf(xv[cb][0], xv[cb][1]), fmaxf(xv[cb][2], xv[cb][3])));
+            const float mx = colmax(mxl);
+            const float mneg = -(mx * L2E);
+            f32x4 ev[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const f32x4 t = vfma4(xv[cb], (f32x4)(L2E), (f32x4)(mneg));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ev[cb][q] = __builtin_amdgcn_exp2f(t[q]);
+            }
+            const f32x4 s4 = (ev[0] + ev[1]) + (ev[2] + ev[3]);
+            const float se = colsum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+            if (lg == 0) {
+                red_l[b_row] = mneg;
+                red_l[Bp + b_row] = se;
+                lab_l[b_row] = lab;
+            }
+            const float rnf = rowok ? rcp_refined(nf) : 0.0f;
+            const f32x4 k4 = (f32x4)(rcp_refined(se) * rnf);
+            const int jown = (((lab >> 2) & 3) == lg) ? (((lab >> 4) << 2) | (lab & 3)) : -1;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x4 oh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) oh[q] = (4 * cb + q == jown) ? -rnf : 0.0f;
+                lgt[cb] = vfma4(ev[cb], k4, oh);
+            }
+        }
+    } else {
+        // multitask CE / weighted BCE: the LDS forms over all eight waves (logits to LDS, gradient back to the registers)
+        if (is_tw) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                if (cb < ncb) *reinterpret_cast<f32x4*>(lg_l + b_row * SC + cb * 16 + r0) = lgt[cb];
+            if (lg == 0) lab_l[b_row] = lab;
+        }
+        lds_barrier();
+        if (g.loss_mode == 1) {
+            if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
+        } else if (tid < LPR * Bp) {
+            softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
+        }
+        lds_barrier();
+        if (is_tw) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                if (cb < ncb) lgt[cb] = *reinterpret_cast<const f32x4*>(lg_l + b_row * SC + cb * 16 + r0);
+        }
     }
-    lds_barrier();
+    // dlogits for the tail (head-bias gradient) and the HEAD update
+    if (is_tw) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+            if (cb < ncb) {
+                *reinterpret_cast<f32x4*>(lg_l + b_row * SC + cb * 16 + r0) = lgt[cb];
+                if constexpr (!RES) stc4<COH>(a.stepbuf, sbo + g.sb_dlog + (int64_t)b_row * Cp + cb * 16 + r0, lgt[cb]);
+            }
+    }
     CT_STAMP(7);
-    // ------------------------------------------------------------------ backward: element-parallel like the forward; one
-    // barrier per cell (two with BatchNorm: the column sums of dz and dz * x-hat are needed before the activation gradient)
+    CT_SUM4(9, lgt[0]); CT_SUM4(9, lgt[1]); CT_SUM4(9, lgt[2]); CT_SUM4(9, lgt[3]);
+    // ------------------------------------------------------------------ backward, in the same registers
+    f32x4 dy_next = z4;
 #pragma unroll
     for (int i = MFAS_MAX_CELLS - 1; i >= 0; --i) {
         if (i < L) {
             CT_STAMP(8 + (L - 1 - i));
             const int nl = (nlbits >> (2 * i)) & 3;
-            const int vbl = i * g.vec_cell_stride;
             const bool from_head = (i == L - 1);
-            float gr = 0.f;
-            if (g.bn) gr = vecW[vbl + VEC_G * Rp + r] * rstd_l[i * Rp + r];
-            if (from_head) {
-                // d_out = dlogits . Wc (round 5): every wave used to run all four class blocks' products for its row block — 16 MFMAs per
-                // wave, 32 per SIMD at 32 cycles of matrix pipe each, the longest phase of the backward (profiles/r04_chain_phases.log:
-                // 2,236 cycles against ~1,000 for the other cells).  Now wave (row block emb, class block eq) runs ONE block's four
-                // products and parks the 16 x 16 partial in the (dead) reduced-sums plane; after the barrier every element owner adds
-                // the four partials of its row block, (0 + 2) + (1 + 3).
-                if (eact) {
-                    f32x4 pt = z4;
-                    if (eq < ncb) {
-                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(lg_l + (emb * 16 + l15) * SC + eq * 16 + 4 * lg);
-                        f32x4 wt4;
-                        if constexpr (RES) wt4 = *reinterpret_cast<const f32x4*>(ll.own + ((3 * LEAN_OWN_TILES + 3 + eq) << 8) + lane * 4);
-                        else wt4 = pick4(tHT, eq);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) pt = MFMA16(x4[q], wt4[q], pt);
-                    }
-                    *reinterpret_cast<f32x4*>(yf_l + (ew << 8) + lane * 4) = pt;
-                }
-                lds_barrier();
-            }
-            float d = 0.f;
-            if (eact) {
+            f32x4 d = z4, p0 = z4, p1 = z4, xh = z4;
+            if (is_tw) {
                 f32x4 acc = z4;
                 if (from_head) {
-                    const float* pp = yf_l + ((emb * 4) << 8) + lane * 4;
-                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 256);
-                    const f32x4 p2 = *reinterpret_cast<const f32x4*>(pp + 512), p3 = *reinterpret_cast<const f32x4*>(pp + 768);
-                    acc = (p0 + p2) + (p1 + p3);
+                    // d_out^T = Wc^T . dlogits^T: one 4-MFMA string per class block, summed (0 + 2) + (1 + 3)
+                    f32x4 pt[4];
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        pt[cb] = z4;
+                        if (cb < ncb) {
+                            const f32x4 wt4 = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(3 + cb) + lane * 4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) pt[cb] = MFMA16(wt4[q], lgt[cb][q], pt[cb]);
+                        }
+                    }
+                    acc = (pt[0] + pt[2]) + (pt[1] + pt[3]);
                 } else {
-                    f32x4 w;
-                    if constexpr (RES) w = *reinterpret_cast<const f32x4*>(ll.own + ((3 * LEAN_OWN_TILES + i) << 8) + lane * 4);
-                    else w = pick4(tT, i + 1);
-                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(dy_l + (i + 1) * Bp * SX + (emb * 16 + l15) * SX + 4 * lg);
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(i) + lane * 4);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], w[q], acc);
+                    for (int q = 0; q < 4; ++q) acc = MFMA16(w[q], dy_next[q], acc);
                 }
-                d = sel4(acc);
-                if (g.use_drop) d = ((ekeep >> i) & 1u) ? d * g.drop_scale : 0.0f;
-                if (!(eb < nvalid)) d = 0.f;
-            }
-            float dz = d;
-            if (g.bn) {
-                const float p0 = colsum(d), p1 = colsum(d * xhs[i]);
-                if (lg == 0) { bnw[ew * 16 + r] = p0; bnw[128 + ew * 16 + r] = p1; }
-                lds_barrier();
-                float dbet = 0.f, dgam = 0.f;
+                const f32x4 ds = acc * dscale;
 #pragma unroll
-                for (int w = 0; w < MB * 4; ++w) { dbet += bnw[w * 16 + r]; dgam += bnw[128 + w * 16 + r]; }
-                const float k1 = dbet / nf, k2 = dgam / nf;
-                const float da = gr * (d - k1 - xhs[i] * k2);
-                dz = (eact && eb < nvalid) ? da : 0.f;
-                if (wave == 0 && lg == 0) { gv2[(i * 2 + 0) * 16 + r] = dgam; gv2[(i * 2 + 1) * 16 + r] = dbet; }
+                for (int q = 0; q < 4; ++q) d[q] = (ekeep & (1u << (4 * i + q))) ? ds[q] : 0.0f;
+                if (f_bn) {
+                    xh = (av[i] - *reinterpret_cast<const f32x4*>(bst + i * 32 + r0)) * *reinterpret_cast<const f32x4*>(bst + i * 32 + 16 + r0);
+                    p0 = row_sum16_4(d);
+                    p1 = row_sum16_4(d * xh);
+                }
             }
-            float dy = eact ? act_bwd(av[i], dz, nl) : 0.f;
-            if (!colok) dy = 0.f;
-            if (eact) {
-                dy_l[i * Bp * SX + eb * SX + r] = dy;
+            f32x4 dz = d;
+            if (f_bn) {
+                float* ex = bnw + 512 + (i & 1) * 128;     // (not the forward's region: no barrier separates the last forward cell's reads from these writes)
+                f32x4 dbet = p0, dgam = p1;
+                if constexpr (MB > 1) {
+                    if (is_tw && l15 == 0) {
+                        *reinterpret_cast<f32x4*>(ex + wave * 16 + r0) = p0;
+                        *reinterpret_cast<f32x4*>(ex + 64 + wave * 16 + r0) = p1;
+                    }
+                    lds_barrier();
+                    if (is_tw) {
+                        dbet = *reinterpret_cast<const f32x4*>(ex + r0) + *reinterpret_cast<const f32x4*>(ex + 16 + r0);
+                        dgam = *reinterpret_cast<const f32x4*>(ex + 64 + r0) + *reinterpret_cast<const f32x4*>(ex + 64 + 16 + r0);
+                    }
+                }
+                if (is_tw) {
+                    const f32x4 gr = *reinterpret_cast<const f32x4*>(vecW + i * g.vec_cell_stride + VEC_G * Rp + r0) *
+                                     *reinterpret_cast<const f32x4*>(bst + i * 32 + 16 + r0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float k1 = dbet[q] / nf, k2 = dgam[q] / nf;
+                        const float da = gr[q] * (d[q] - k1 - xh[q] * k2);
+                        dz[q] = (rowok && cm[q]) ? da : 0.f;
+                    }
+                    if (wave == 0 && l15 == 0) {
+                        *reinterpret_cast<f32x4*>(gv2 + (i * 2 + 0) * 16 + r0) = dgam;
+                        *reinterpret_cast<f32x4*>(gv2 + (i * 2 + 1) * 16 + r0) = dbet;
+                    }
+                }
+            }
+            if (is_tw) {
+                const f32x4 dy = act_bwd4_lean(av[i], dz, nl);
+                dy_next = dy;
+                CT_SUM4(10 + i, dy);
+                CT_SUM4(14 + i, d);
+                // dy_i -> step buffer (dy operand of the sweep) as soon as it exists; LDS copy for the tail / the own updates
+                stc4<COH>(a.stepbuf, sbo + g.sb_dy + (int64_t)(i * Bp + b_row) * Rp + r0, dy);
+                *reinterpret_cast<f32x4*>(dy_l + i * Bp * SX + b_row * SX + r0) = dy;
                 // d(alpha_i) needs sum_{b,r} dy[b,r] * (yS_raw - yV_raw)[b,r]: the products go to the (now dead) V plane of the
                 // reduced feature sums, summed in fixed order by chain_lean_tail
-                if (g.alphas) yf_l[sav_plane + (i * Bp + eb) * 16 + r] = dy * dsv[i];
+                if (f_alphas) *reinterpret_cast<f32x4*>(yf_l + sav_plane + (i * Bp + b_row) * 16 + r0) = dy * *reinterpret_cast<const f32x4*>(yf_l + ((i * MB + wave) << 8) + lane * 4);
             }
-            lds_barrier();
         }
     }
     CT_STAMP(12);
-    {   // dy_i -> step buffer (dy operand of the sweep), coalesced
-        if constexpr (RES) {   // 16 B write-through stores: [L][Bp][16] = one f32x4 per thread and cell pair
-            for (int e4 = tid; e4 < L * Bp * 4; e4 += CHAIN_THREADS)
-                stc4<true>(a.stepbuf, sbo + g.sb_dy + (int64_t)e4 * 4, *reinterpret_cast<const f32x4*>(dy_l + (e4 >> 2) * SX + (e4 & 3) * 4));
-        } else {
-            float* dy_g = sb + g.sb_dy;   // [L][Bp][Rp]
-            for (int e = tid; e < L * Bp * Rp; e += CHAIN_THREADS) stc1<COH>(dy_g + e, dy_l[(e >> 4) * SX + (e & 15)]);
-        }
-    }
-    if constexpr (!RES) {   // dlogits -> step buffer (dy operand of the HEAD segment)
-        float* dlg = sb + g.sb_dlog;
-        for (int e = tid; e < Bp * Cp; e += CHAIN_THREADS) {
-            const int b = e / Cp, c = e - b * Cp;
-            stc1<COH>(dlg + e, lg_l[b * SC + c]);
-        }
-    }
+    if constexpr (!RES) lds_barrier();     // (the resident loop's publish barrier follows the call)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1343,6 +1525,34 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
         else { a.plane[o] = w; a.plane[a.plane_stride + o] = m; a.plane[2 * a.plane_stride + o] = v; }
     };
     if (a.logits_out) return;       // train-mode forward only: no statistics, no update
+    if (lean_ce_in_regs(a)) {
+        // the register softmax left (m, sum e) per row in red_l and the raw logits in LDS: row loss = ln(sum_c e^x_c) - x_label and
+        // the top-1 hit (first maximum = torch.max(dim=1)), 16 lanes per row
+        float* red_w = ll.red_l;
+        float ls = 0.f, hit = 0.f;
+        const int b = tid >> 4, sub = tid & 15;
+        if (tid < Bp * 16) {
+            const float* row = ll.lgraw + b * 64;
+            const int lab = ll.lab_l[b];
+            float bv = -3.0e38f;
+            int bi = 0x7FFFFFFF;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = sub + 16 * j;
+                if (c < C) {
+                    const float t = row[c];
+                    if (t > bv) { bv = t; bi = c; }
+                }
+            }
+            row_argmax<16>(bv, bi);
+            const bool ok = b < cs.nvalid;
+            ls = ok ? (__builtin_amdgcn_logf(red_l[Bp + b]) - red_l[b]) * 0.693147180559945309f - row[lab] : 0.f;
+            hit = (ok && bi == lab) ? 1.f : 0.f;
+        }
+        lds_barrier();
+        if (tid < Bp * 16 && sub == 0) { red_w[b] = ls; red_w[Bp + b] = hit; }
+        lds_barrier();
+    }
     if (tid == CHAIN_THREADS - 64 && (RES || a.stats)) {
         float ls = 0.f, ncor = 0.f;
         for (int b = 0; b < Bp; ++b) { ls += red_l[b]; ncor += red_l[Bp + b]; }
@@ -1399,10 +1609,6 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
 // ------------------------------------------------------------------------------------------------
 // Resident lean chain, launch prologue / per-step weight update / launch epilogue (persist.hip.h, MODE 2)
 // ------------------------------------------------------------------------------------------------
-// own-tile plane offsets of slot s: OUT_{s+1} (s < 3), head class block s-3
-__device__ __forceinline__ int64_t lean_own_off(const CandDev& cd, int s) { return s < 3 ? cd.seg_off[s + 1][2] : cd.head_off + ((int64_t)(s - 3) << 8); }
-__device__ __forceinline__ int64_t lean_own_toff(const CandDev& cd, int s) { return s < 3 ? cd.outT_off[s + 1] : cd.headT_off + ((int64_t)(s - 3) << 8); }
-__device__ __forceinline__ bool lean_own_live(const CandDev& cd, const Geo& g, int s) { return s < 3 ? (s + 1 < cd.L) : (s - 3 < g.ncb); }
 
 template <int MB>
 __device__ __forceinline__ void lean_res_load(const ChainArgs& a, const int bid, float* lds, LeanRes& rs) {

@@ -262,8 +262,8 @@ static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs
     // lean chain — k_president; a population without both runs launch-per-phase)
     const size_t lean_bytes = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
                                + (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.MB * 256 + (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp)
-                               + LEAN_SCR + 8) * 4;
-    lp.lean_ok = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean_bytes <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
+                               + LEAN_SCR + 8 + LeanLds<1>::stage_floats() + (size_t)g.Bp * 64) * 4;
+    lp.lean_ok = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean_bytes <= 78 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
     lp.plan_res = lp.want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT") && !getenv("MFAS_PERSIST_NO_RES_CHAIN") && lp.lean_ok;
     auto feat_units = [&](int cc_target, int* max_cc) {
         int64_t n = 0;
@@ -600,17 +600,17 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         // chain_lean's LDS: out_i / dy_i of all cells, logits, misc, reduced sums, vector block, saved activations
         const size_t plane = (size_t)MFAS_MAX_CELLS * g.MB * 256;
         const size_t lean = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
-                             + (g.alphas ? 2 : 1) * plane + vec / 4 + LEAN_SCR + 8) * 4;
+                             + (g.alphas ? 2 : 1) * plane + vec / 4 + LEAN_SCR + 8 + LeanLds<1>::stage_floats() + (size_t)g.Bp * 64) * 4;
         // (the chain form must not depend on the sweep's chunk size: since round 2 the lean chain sums bias gradients and BN
         // statistics in its own — element-parallel — order, so lean and general chains agree to rounding, not bit for bit)
-        p->lean_chain = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean <= 72 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
+        p->lean_chain = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean <= 78 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
         if (p->lean_chain) { p->lds_chain = lean; p->lds_step = std::max(p->lds_step, lean); }
         p->res_chain = res_ok && p->lean_chain;
         if (res_ok && !p->lean_chain) {   // (cannot happen while lean_ok_early mirrors the formula above)
             delete p;
             return MFAS_RETRY_NO_PERSIST;
         }
-        const size_t lds_rchain = p->res_chain ? p->lds_chain + 16 + 4 * (size_t)LeanLds<1>::own_floats() : 0;
+        const size_t lds_rchain = p->res_chain ? p->lds_chain + 16 + 4 * (size_t)(LeanLds<1>::own_floats() - LeanLds<1>::stage_floats()) : 0;
         p->lds_president = ((std::max(lds_rchain, lds_res) + 15) & ~(size_t)15) + 4 * PERSIST_LDS_WORDS;
     }
     p->nrbw = (g.nrb + 3) / 4;
@@ -640,6 +640,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     CREATE_CHK(hipMalloc(&p->d_cands, sizeof(CandDev) * K));
     CREATE_CHK(hipMalloc(&p->d_descs, sizeof(SegDesc) * p->descs.size()));
     CREATE_CHK(hipMalloc(&p->d_status, sizeof(int32_t) * (K + 256)));   // + debug timestamp slots (MFAS_CHAIN_TIMING builds)
+    CREATE_CHK(hipMemset(p->d_status, 0, sizeof(int32_t) * (K + 256)));
     CREATE_CHK(hipMalloc(&p->d_seeds, sizeof(uint32_t) * K));
     CREATE_CHK(hipMalloc(&p->d_corr, sizeof(long long)));
     {
@@ -820,10 +821,10 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             CREATE_CHK(hipMalloc(&p->d_trace, sizeof(unsigned long long) * 256));
             CREATE_CHK(hipMemset(p->d_trace, 0, sizeof(unsigned long long) * 256));
         }
-#define SET_RES(M) CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 1>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 2>), p->lds_president)); \
-                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR16, true, 1>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 1>), p->lds_president)); \
-                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2>), p->lds_president))
-        SET_RES(1); SET_RES(2);
+#define SET_RES(M, P) CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 1, P>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 2, P>), p->lds_president)); \
+                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR16, true, 1, P>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 1, P>), p->lds_president)); \
+                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2, P>), p->lds_president))
+        SET_RES(1, false); SET_RES(2, false); SET_RES(1, true); SET_RES(2, true);
 #undef SET_RES
     }
     // W/m/v beyond what the 256 MiB Infinity Cache can keep between steps are streamed nontemporally
@@ -1393,7 +1394,10 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         }
         {      // one instantiation per unit form
             const int lw = (int)(p->lds_president / 4) - PERSIST_LDS_WORDS;
-#define RES_LAUNCH(M, NTR, X, NU) hipLaunchKernelGGL((k_president<M, NTR, X, NU>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw)
+            // the search default — no BatchNorm, no alphas, single-task softmax CE — runs the chain compiled for exactly that (chain_lean PLAIN)
+            const bool plain = !g.bn && !g.alphas && !g.multitask && g.loss_mode == 0 && !getenv("MFAS_NO_PLAIN_CHAIN");
+#define RES_LAUNCH(M, NTR, X, NU) do { if (plain) hipLaunchKernelGGL((k_president<M, NTR, X, NU, true>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); \
+                                       else hipLaunchKernelGGL((k_president<M, NTR, X, NU, false>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); } while (0)
 #define RES_PICK(M) do { if (train->dtype == MFAS_DT_F32) { if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, false, 2); else RES_LAUNCH(M, PERSIST_NTR, false, 1); } \
                          else if (pa.res_wide) RES_LAUNCH(M, PERSIST_NTR16, true, 1); \
                          else if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, true, 2); else RES_LAUNCH(M, PERSIST_NTR, true, 1); } while (0)
@@ -1544,6 +1548,12 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             fprintf(stderr, "[chain timing, shader cycles since kernel entry, candidate 0 step 3]");
             for (int i = 0; i < 13; ++i) fprintf(stderr, " %d", ts[i]);
             fprintf(stderr, "\n");
+            int32_t cs[24];
+            if (hipMemcpy(cs, p->d_status + 96, sizeof(cs), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[chain checksums, candidate 0 global step 0: sums x4, out x4, logits, dlogits, dy x4, d x4]");
+                for (int i = 0; i < 18; ++i) fprintf(stderr, " %08x", (unsigned)cs[i]);
+                fprintf(stderr, "\n");
+            }
         }
     }
 #endif

@@ -132,6 +132,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 #define MFAS_RES_DMA 0
 #endif
 
+// forward partial of a resident unit: operands SWAPPED -> the slab is the partial's TRANSPOSE, chain_lean's register image (the
+// f32 MFMA is symmetric under the swap bit for bit: tools/mfma_swap_check.hip)
+#if MFAS_RES_TRANSPOSED_SLABS
+#define RES_FWD_MFMA(x, w, acc) MFMA16((w), (x), (acc))
+#else
+#define RES_FWD_MFMA(x, w, acc) MFMA16((x), (w), (acc))
+#endif
 struct ResUnit {              // wave-uniform constants of one resident unit
     int32_t valid, index, cand, cell, kind, cc, nkb, S, width, k0;
     const void* tp;
@@ -275,7 +282,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     for (int mb = 0; mb < MB; ++mb) {
                         const f32x4 x4 = x4of(lds + res_xbo(U[u], 0), U[u].S, mb * 16 + l15, kb * 16 + 4 * lg);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][s][q], yacc[mb]);
+                        for (int q = 0; q < 4; ++q) yacc[mb] = RES_FWD_MFMA(x4[q], w4[u][s][q], yacc[mb]);
                     }
                 }
             }
@@ -362,7 +369,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                             for (int mb = 0; mb < MB; ++mb) {
                                 const f32x4 x4 = x4of(xn, un.S, mb * 16 + l15, kb * 16 + 4 * lg);
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) yacc[mb] = MFMA16(x4[q], w4[u][s][q], yacc[mb]);
+                                for (int q = 0; q < 4; ++q) yacc[mb] = RES_FWD_MFMA(x4[q], w4[u][s][q], yacc[mb]);
                             }
                         }
                     }
@@ -439,7 +446,7 @@ __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_president<MB, NTR, X16, NU> — the RESIDENT schedule (the default for small populations at R <= 16): ONE launch per epoch,
+// k_president<MB, NTR, X16, NU, PLAIN> — the RESIDENT schedule (the default for small populations at R <= 16): ONE launch per epoch,
 // blocks [0, K) = the resident lean chain of candidate blockIdx.x, blocks [K, K + nres_wg) = workgroups of resident feature
 // units.  One instantiation per unit form (staging width, tiles per wave, units per workgroup): an instantiation carries exactly
 // the two bodies its grid runs.  (Round 3 also ran the two roles as two kernels on two streams, each with its own register budget — the unit
@@ -448,7 +455,7 @@ __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, c
 // hardware queues, which HIP does not promise: after a few hundred stream creations in one process the second launch queued
 // behind the first and every roll call failed.  One launch cannot be split by the runtime.)
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NTR, bool X16, int NU>
+template <int MB, int NTR, bool X16, int NU, bool PLAIN>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs a, const int lds_word) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
@@ -464,6 +471,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
     LeanRes& rs = *reinterpret_cast<LeanRes*>(ldsw + 16);   // the epoch's running statistics: LDS words 16..21 (as registers of one lane
                                                              // they were live across the whole step loop in every wave, and spilled)
     lean_res_load<MB>(a.ca, bid, lds, rs);
+    uint32_t keep = lean_keep_bits<MB>(a.ca.cands[bid], a.ca.g, a.gstep0);     // dropout keep-bits of the step about to run
     for (int t = 0; t < a.T; ++t) {
         const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
         const int tr_base = (t - 8) * 8;
@@ -478,12 +486,13 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
         cs.epoch = a.epoch;
         cs.ss = a.scal[2 * (int64_t)cs.gstep];
         cs.bc2s = a.scal[2 * (int64_t)cs.gstep + 1];
-        chain_lean<MB, 2>(a.ca, cs, bid, lds, &rs);
+        chain_lean<MB, 2, 16, PLAIN>(a.ca, cs, bid, lds, &rs, keep);
         PTRACE(2);
         wg_publish_barrier();
         if (tid == 0 && !(bid == 0 && t == a.lose_step))
             __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PTRACE(3);
+        keep = lean_keep_bits<MB>(a.ca.cands[bid], a.ca.g, cs.gstep + 1);      // (next step's: ~200 integer instructions off the critical path)
         chain_lean_tail<MB, 2>(a.ca, cs, bid, lds, &rs);   // statistics + vector-parameter Adam, after dy is out
         lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the feature units run
     }

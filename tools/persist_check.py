@@ -78,5 +78,9 @@ if not same and steps >= 0:
                 if not np.array_equal(a, b):
                     bad = np.flatnonzero(a != b)
                     print(f"  cand {k} plane {pl} {key}: {bad.size}/{n} differ, max abs {np.abs(a - b).max():g}, first idx {bad[:6].tolist()}")
+                    if "dump" in sys.argv:
+                        for j in bad[:3]:
+                            print("     idx", int(j), "schedule0 W m v:", [float.hex(float(p0[k][q][off + j])) for q in range(3)],
+                                  "schedule1 W m v:", [float.hex(float(p1[k][q][off + j])) for q in range(3)])
 print("BIT-IDENTICAL" if same else f"MISMATCH (max abs param diff {worst:g}; train loss {s0['train_loss_sum'][0]} vs {s1['train_loss_sum'][0]})", flush=True)
 sys.exit(0 if same else 1)
