@@ -986,6 +986,53 @@ __device__ __forceinline__ uint32_t lean_keep_bits(const CandDev& cd, const Geo&
     }
     return bits;
 }
+// label (loss_mode 1: table row) of a tile-wave lane's batch row in the batch at sample-order position pos_t; the resident chain
+// fetches step t + 1's after it has published step t's dy — a dependent pair of loads that must not sit in front of the chain
+template <int MB>
+__device__ __forceinline__ int lean_label(const ChainArgs& a, const CandDev& cd, const int64_t pos_t, const int base_t, const int nvalid) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b_row = (wave < MB ? wave : 0) * 16 + (lane & 15);
+    int lab = 0;
+    if (wave < MB && b_row < nvalid) {
+        const int32_t* ord = cand_order(a.order, a.g, cd.gidx);
+        const int64_t row = ord ? (int64_t)ord[pos_t + b_row] : (int64_t)(base_t + b_row);
+        lab = a.g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
+    }
+    return lab;
+}
+// What a chain workgroup's thread needs of its candidate's record, read ONCE per launch: inside the resident step loop the compiler
+// cannot hoist these loads itself (the loop stores to global memory), and as four dependent vector loads in front of the first
+// slab request they cost ~2,000 cycles per step (profiles/r05_chain_phases.log).
+struct LeanPre {
+    int32_t L, nlbits;          // cells, 2 bits of non-linearity per cell
+    int32_t pi, ns, nch;        // this wave's slab duty: cell, S chunks, S + V chunks (0: none)
+    int64_t part;               // step-buffer index of this thread's first slab item
+    int64_t step_off, vec_off;  // the candidate's step buffers / vector block
+    int32_t gidx;
+};
+template <int MB>
+__device__ __forceinline__ LeanPre lean_pre(const ChainArgs& a, const int bid) {
+    const CandDev& cd = a.cands[bid];
+    const int tid = threadIdx.x;
+    constexpr int per_cell = MB * 64;   // float4 partial-sum items per cell; L * per_cell <= 512: one item per thread
+    LeanPre lp;
+    // (wave-uniform by construction; said so explicitly, or every `i < L` / activation switch becomes an exec-masked region)
+    lp.L = __builtin_amdgcn_readfirstlane(cd.L);
+    int nlbits = 0;
+#pragma unroll
+    for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
+    lp.nlbits = __builtin_amdgcn_readfirstlane(nlbits);
+    const bool has_item = tid < lp.L * per_cell;
+    // (per_cell = MB * 64: the cell index is wave-uniform; wave w sums the slabs of cell w / MB for batch tile w % MB — the tile
+    //  waves hold cell 0's)
+    lp.pi = __builtin_amdgcn_readfirstlane(has_item ? tid / per_cell : 0);
+    const int pit = tid - lp.pi * per_cell;
+    lp.ns = __builtin_amdgcn_readfirstlane(cd.nch_s[lp.pi]);
+    lp.nch = __builtin_amdgcn_readfirstlane(has_item ? lp.ns + cd.nch_v[lp.pi] : 0);
+    lp.step_off = cd.step_off; lp.vec_off = cd.vec_off; lp.gidx = __builtin_amdgcn_readfirstlane(cd.gidx);
+    lp.part = lp.step_off + a.g.sb_part + (((int64_t)cd.part_cell_off[lp.pi] * MB) << 8) + pit * 4;
+    return lp;
+}
 // does this population's loss run on the tile waves' registers (softmax / CE, single task, no external gradient)?
 __device__ __forceinline__ bool lean_ce_in_regs(const ChainArgs& a) { return a.g.loss_mode == 0 && !a.g.multitask && !a.dlogits_in; }
 
@@ -996,8 +1043,8 @@ __device__ __forceinline__ bool lean_ce_in_regs(const ChainArgs& a) { return a.g
 // PLAIN: the search default compiled on its own — no BatchNorm, no alphas, softmax CE, no external logits / gradients: the flags
 // are compile-time false, their uniform values need no scalar registers and their branches are gone.
 template <int MB, int MODE = 0, int PB = 16, bool PLAIN = false>
-__device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds, LeanRes* rs = nullptr,
-                                           const uint32_t keep_pre = 0u) {
+__device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds, const LeanPre& lp,
+                                           const uint32_t keep_pre = 0u, const int lab_pre = 0) {
     constexpr bool COH = MODE >= 1;
     constexpr bool RES = MODE == 2;
     constexpr bool TS = RES && (MFAS_RES_TRANSPOSED_SLABS != 0);      // the partial slabs arrive transposed (resident units, persist.hip.h)
@@ -1011,7 +1058,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     constexpr int Bp = MB * 16;
     constexpr int LPR = (STEP_THREADS / Bp) < 16 ? (STEP_THREADS / Bp) : 16;
     constexpr int Rp = 16, SX = Rp + 4;
-    const int Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L, SC = Cp + 4;
+    const int Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = lp.L, SC = Cp + 4;
     constexpr int sav_plane = MFAS_MAX_CELLS * MB * 256;
     const bool f_bn = PLAIN ? false : (g.bn != 0);
     const bool f_alphas = PLAIN ? false : (g.alphas != 0);
@@ -1028,15 +1075,13 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     float* W = a.plane;
     float* Mv = a.plane + a.plane_stride;
     float* Vv = Mv + a.plane_stride;
-    float* sb = a.stepbuf + cd.step_off;
-    const int64_t cvec_off = cd.vec_off;
-    const int cgidx = cd.gidx;
-    int nlbits = 0;
-#pragma unroll
-    for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
+    float* sb = a.stepbuf + lp.step_off;
+    const int64_t cvec_off = lp.vec_off;
+    const int cgidx = lp.gidx;
+    const int nlbits = lp.nlbits;
     const int nvalid = cs.nvalid;
     const float nf = (float)nvalid;
-    const int64_t sbo = cd.step_off;
+    const int64_t sbo = lp.step_off;
     // tile wave tw = wave < MB: batch row b_row = 16 * tw + l15, features 4 * lg + q in register q
     const bool is_tw = wave < MB;
     const int b_row = (is_tw ? wave : 0) * 16 + l15;
@@ -1050,19 +1095,19 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     constexpr int per_cell = MB * 64;   // float4 partial-sum items per cell; L * per_cell <= 512: one item per thread
     // PB = partial-sum chunks requested per thread before any is consumed (16; 8 in the 128-VGPR co-scheduled builds of k_step)
     const bool has_item = tid < L * per_cell;
-    // (per_cell = MB * 64: the cell index is wave-uniform -> scalar loads of cd.nch_* / part_cell_off; wave w sums the slabs of
-    //  cell w / MB for batch tile w % MB — the tile waves hold cell 0's)
-    const int pi = __builtin_amdgcn_readfirstlane(has_item ? tid / per_cell : 0), pit = tid - pi * per_cell;
-    const int ns = cd.nch_s[pi], nch = has_item ? ns + cd.nch_v[pi] : 0;
-    const int64_t part = sbo + g.sb_part + (((int64_t)cd.part_cell_off[pi] * MB) << 8) + pit * 4;
+    const int pi = lp.pi, ns = lp.ns, nch = lp.nch;      // (wave-uniform: lean_pre)
+    const int64_t part = lp.part;
     f32x4 p8[PB];
     if constexpr (RES) {
-        // resident chain: only the slabs that exist (wave-uniform count -> scalar branches)
-        const int nch_u = __builtin_amdgcn_readfirstlane(nch);
+        // resident chain: only the slabs that exist.  The count is handed to the loads as a per-lane value: exec-masked loads in ONE
+        // straight-line block, all requested before the first is touched (as a scalar count every load sits in its own branch, and
+        // the compiler threads "slab 0 exists" through to its consumption: it waited for slab 0 before requesting slab 1)
+        int nch_v = nch;
+        asm volatile("" : "+v"(nch_v));
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
             p8[u] = z4;
-            if (u < nch_u) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)u * MB) << 8));
+            if (u < nch_v) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)u * MB) << 8));
         }
     } else {
         // every load UNCONDITIONAL (indices clamped to something valid): with a statically known number of loads in flight the
@@ -1094,12 +1139,20 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             if (!live) st1 = z4;
         }
     }
-    // labels of this tile wave's rows (a dependent pair of loads that nothing needs before the loss)
-    int lab = 0;
-    if (is_tw && rowok) {
-        const int32_t* ord = cand_order(a.order, g, cgidx);
-        const int64_t row = ord ? (int64_t)ord[cs.pos_t + b_row] : (int64_t)(cs.base_t + b_row);
-        lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
+    // labels of this tile wave's rows (launch-per-phase: a dependent pair of loads that nothing needs before the loss)
+    const int lab = RES ? lab_pre : lean_label<MB>(a, cd, cs.pos_t, cs.base_t, nvalid);
+    // resident chain: the LDS operands of the step — biases, weight tile images, their transposes — are read a phase AHEAD of
+    // their use, in three groups (a ds_read in front of each product cost ~120 cycles apiece, three per cell): the cells' here, under
+    // the slab loads' latency; the head's under cell 0; the backward's under the softmax
+    f32x4 pb4[MFAS_MAX_CELLS], pw4[MFAS_MAX_CELLS], pt4[MFAS_MAX_CELLS], phw[4], phb[4], pht[4];
+    if constexpr (RES) {
+        if (is_tw) {
+#pragma unroll
+            for (int i = 0; i < MFAS_MAX_CELLS; ++i) {
+                pb4[i] = *reinterpret_cast<const f32x4*>(vec_l + i * g.vec_cell_stride + VEC_B * Rp + r0);
+                pw4[i] = i > 0 ? *reinterpret_cast<const f32x4*>(ll.template wtile<RES>(i - 1) + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
     }
     // dropout keep-bits of this lane's 4 features in every cell (bit 4 * i + q), with "feature exists" and "row is in the batch"
     // folded in: one select per element zeroes dropped, padded and out-of-batch elements alike, forward and backward
@@ -1113,20 +1166,29 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     const float dscale = g.use_drop ? g.drop_scale : 1.0f;
     // phase 0: sum the sweep's column-chunk partial slabs of (cell pi, tile) in fixed order: S chunks, then V chunks
     f32x4 accS = z4, accV = z4;
+    const int nch_c = nch, ns_c = ns;
+    // (acc += slab as a volatile statement: as a plain fadd, `0 + slab 0` is speculated up into the block that requests slab 0 —
+    //  and the wave waits for slab 0 before it requests slab 1: one memory round trip more in front of every step)
+    auto slab_add = [](f32x4& acc, const f32x4& p) {
+        f32x2 lo = acc.lo, hi = acc.hi;
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(lo) : "v"(p.lo));
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(hi) : "v"(p.hi));
+        acc = (f32x4){lo.x, lo.y, hi.x, hi.y};
+    };
     if (has_item) {
 #pragma unroll
         for (int u = 0; u < PB; ++u)
-            if (u < nch) {
-                if (u < ns) accS += p8[u]; else accV += p8[u];
+            if (u < nch_c) {
+                if (u < ns_c) slab_add(accS, p8[u]); else slab_add(accV, p8[u]);
             }
-        for (int ch0 = PB; ch0 < nch; ch0 += PB) {
+        for (int ch0 = PB; ch0 < nch_c; ch0 += PB) {
 #pragma unroll
             for (int u = 0; u < PB; ++u)
-                if (ch0 + u < nch) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)(ch0 + u) * MB) << 8));
+                if (ch0 + u < nch_c) p8[u] = ldc4<COH>(a.stepbuf, part + (((int64_t)(ch0 + u) * MB) << 8));
 #pragma unroll
             for (int u = 0; u < PB; ++u)
-                if (ch0 + u < nch) {
-                    if (ch0 + u < ns) accS += p8[u]; else accV += p8[u];
+                if (ch0 + u < nch_c) {
+                    if (ch0 + u < ns_c) accS += p8[u]; else accV += p8[u];
                 }
         }
         // resident: cell 0's sums stay in the tile waves' registers (transposed slabs: the item IS the lane's register image)
@@ -1198,6 +1260,15 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             if constexpr (TS) {
                 if (i == 1) lds_barrier();     // the other waves' sums of cells 1..L-1 are in LDS (they got there under cell 0)
             }
+            if constexpr (RES) {
+                if (i == (L > 1 ? 1 : 0) && is_tw) {      // the head's operands, a phase ahead
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        phw[cb] = *reinterpret_cast<const f32x4*>(ll.template wtile<RES>(3 + cb) + lane * 4);
+                        phb[cb] = *reinterpret_cast<const f32x4*>(vec_l + g.vec_head + (cb < ncb ? cb : 0) * 16 + r0);
+                    }
+                }
+            }
             f32x4 v = z4, s1 = z4;
             if (is_tw) {
                 f32x4 yS = accS, yV = accV;
@@ -1211,11 +1282,13 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                     acc = yS * sgS + yV * sgV;
                 }
                 if (i > 0) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(ll.template wtile<RES>(i - 1) + lane * 4);
+                    f32x4 w;
+                    if constexpr (RES) w = pw4[i]; else w = *reinterpret_cast<const f32x4*>(ll.template wtile<RES>(i - 1) + lane * 4);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc = MFMA16(w[q], o_prev[q], acc);
                 }
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(vecW + vbl + VEC_B * Rp + r0);
+                f32x4 bias;
+                if constexpr (RES) bias = pb4[i]; else bias = *reinterpret_cast<const f32x4*>(vecW + vbl + VEC_B * Rp + r0);
                 v = act_fwd4_lean(acc + bias, nl);
                 if (f_bn) s1 = row_sum16_4(rowok ? v : z4);
             }
@@ -1294,15 +1367,26 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
             if (cb < ncb) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(ll.template wtile<RES>(3 + cb) + lane * 4);
+                f32x4 w, hb;
+                if constexpr (RES) { w = phw[cb]; hb = phb[cb]; }
+                else { w = *reinterpret_cast<const f32x4*>(ll.template wtile<RES>(3 + cb) + lane * 4); hb = *reinterpret_cast<const f32x4*>(vecW + g.vec_head + cb * 16 + r0); }
                 f32x4 acc = z4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc = MFMA16(w[q], o_prev[q], acc);
-                lgt[cb] = acc + *reinterpret_cast<const f32x4*>(vecW + g.vec_head + cb * 16 + r0);
+                lgt[cb] = acc + hb;
             }
     }
     CT_STAMP(6);
     CT_SUM4(8, lgt[0]); CT_SUM4(8, lgt[1]); CT_SUM4(8, lgt[2]); CT_SUM4(8, lgt[3]);
+    if constexpr (RES) {
+        if (is_tw) {      // the backward's operands, under the loss
+#pragma unroll
+            for (int i = 0; i < MFAS_MAX_CELLS; ++i)
+                pt4[i] = i < MFAS_MAX_CELLS - 1 ? *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(i) + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) pht[cb] = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(3 + cb) + lane * 4);
+        }
+    }
     if constexpr (MODE == 0 && !PLAIN) {
         if (a.logits_out) {   // train-mode forward only
             if (is_tw && rowok) {
@@ -1341,8 +1425,11 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 *reinterpret_cast<f32x4*>(ll.lgraw + b_row * 64 + cb * 16 + r0) = lgt[cb];
+                xv[cb] = lgt[cb];
+                if (cb >= ncb - 1) {      // (only the last class block has padding; the blocks behind it do not exist)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xv[cb][q] = (cb * 16 + r0 + q < C) ? lgt[cb][q] : -3.0e38f;      // (only the last class block has padding)
+                    for (int q = 0; q < 4; ++q) xv[cb][q] = (cb * 16 + r0 + q < C) ? lgt[cb][q] : -3.0e38f;
+                }
             }
             float mxl = fmaxf(fmaxf(xv[0][0], xv[0][1]), fmaxf(xv[0][2], xv[0][3]));
 #pragma unroll
@@ -1424,14 +1511,16 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                     for (int cb = 0; cb < 4; ++cb) {
                         pt[cb] = z4;
                         if (cb < ncb) {
-                            const f32x4 wt4 = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(3 + cb) + lane * 4);
+                            f32x4 wt4;
+                            if constexpr (RES) wt4 = pht[cb]; else wt4 = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(3 + cb) + lane * 4);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) pt[cb] = MFMA16(wt4[q], lgt[cb][q], pt[cb]);
                         }
                     }
                     acc = (pt[0] + pt[2]) + (pt[1] + pt[3]);
                 } else {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(i) + lane * 4);
+                    f32x4 w;
+                    if constexpr (RES) w = pt4[i]; else w = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(i) + lane * 4);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc = MFMA16(w[q], dy_next[q], acc);
                 }

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bid = (int)blockIdx.x;
     if (bid < a.nchain) {
-        if constexpr (LEAN) { chain_lean<MB, 0, (WPE >= 4 ? 8 : 16)>(a.ca, chain_step_of(a.ca), bid, lds); chain_lean_tail<MB, 0>(a.ca, chain_step_of(a.ca), bid, lds); }
+        if constexpr (LEAN) { chain_lean<MB, 0, (WPE >= 4 ? 8 : 16)>(a.ca, chain_step_of(a.ca), bid, lds, lean_pre<MB>(a.ca, bid)); chain_lean_tail<MB, 0>(a.ca, chain_step_of(a.ca), bid, lds); }
         else chain_body<MB, false>(a.ca, chain_step_of(a.ca), bid, lds);
     }
     else if (bid < a.nchain + a.ga.nblocks) gather_body(a.ga, a.ga.cands[bid - a.nchain], a.sa.g, a.sa.tab, a.sa.order, (int)threadIdx.x);
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 4) k_step_same(const StepArgs a)
 template <int MB, bool LEAN>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_chain(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if constexpr (LEAN) { chain_lean<MB>(a, chain_step_of(a), (int)blockIdx.x, lds); chain_lean_tail<MB, 0>(a, chain_step_of(a), (int)blockIdx.x, lds); }
+    if constexpr (LEAN) { chain_lean<MB>(a, chain_step_of(a), (int)blockIdx.x, lds, lean_pre<MB>(a, (int)blockIdx.x)); chain_lean_tail<MB, 0>(a, chain_step_of(a), (int)blockIdx.x, lds); }
     else chain_body<MB, true>(a, chain_step_of(a), (int)blockIdx.x, lds);
 }
 

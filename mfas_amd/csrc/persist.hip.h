@@ -471,7 +471,9 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
     LeanRes& rs = *reinterpret_cast<LeanRes*>(ldsw + 16);   // the epoch's running statistics: LDS words 16..21 (as registers of one lane
                                                              // they were live across the whole step loop in every wave, and spilled)
     lean_res_load<MB>(a.ca, bid, lds, rs);
-    uint32_t keep = lean_keep_bits<MB>(a.ca.cands[bid], a.ca.g, a.gstep0);     // dropout keep-bits of the step about to run
+    const LeanPre lpre = lean_pre<MB>(a.ca, bid);
+    uint32_t keep = lean_keep_bits<MB>(a.ca.cands[bid], a.ca.g, a.gstep0);     // dropout keep-bits and labels of the step about to run
+    int labp = lean_label<MB>(a.ca, a.ca.cands[bid], a.pos0, 0, (int)min((int64_t)a.B, a.N));
     for (int t = 0; t < a.T; ++t) {
         const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
         const int tr_base = (t - 8) * 8;
@@ -486,13 +488,14 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
         cs.epoch = a.epoch;
         cs.ss = a.scal[2 * (int64_t)cs.gstep];
         cs.bc2s = a.scal[2 * (int64_t)cs.gstep + 1];
-        chain_lean<MB, 2, 16, PLAIN>(a.ca, cs, bid, lds, &rs, keep);
+        chain_lean<MB, 2, 16, PLAIN>(a.ca, cs, bid, lds, lpre, keep, labp);
         PTRACE(2);
         wg_publish_barrier();
         if (tid == 0 && !(bid == 0 && t == a.lose_step))
             __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PTRACE(3);
         keep = lean_keep_bits<MB>(a.ca.cands[bid], a.ca.g, cs.gstep + 1);      // (next step's: ~200 integer instructions off the critical path)
+        if (t + 1 < a.T) labp = lean_label<MB>(a.ca, a.ca.cands[bid], cs.pos_t + a.B, cs.base_t + a.B, (int)min((int64_t)a.B, a.N - (int64_t)(t + 1) * a.B));
         chain_lean_tail<MB, 2>(a.ca, cs, bid, lds, &rs);   // statistics + vector-parameter Adam, after dy is out
         lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the feature units run
     }
