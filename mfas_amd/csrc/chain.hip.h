@@ -1095,14 +1095,16 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     constexpr int per_cell = MB * 64;   // float4 partial-sum items per cell; L * per_cell <= 512: one item per thread
     // PB = partial-sum chunks requested per thread before any is consumed (16; 8 in the 128-VGPR co-scheduled builds of k_step)
     const bool has_item = tid < L * per_cell;
-    const int pi = lp.pi, ns = lp.ns, nch = lp.nch;      // (wave-uniform: lean_pre)
+    const int pi = lp.pi, ns = lp.ns, nch = lp.nch, pit = tid - lp.pi * per_cell;      // (wave-uniform: lean_pre)
     const int64_t part = lp.part;
     f32x4 p8[PB];
     if constexpr (RES) {
         // resident chain: only the slabs that exist.  The count is handed to the loads as a per-lane value: exec-masked loads in ONE
         // straight-line block, all requested before the first is touched (as a scalar count every load sits in its own branch, and
         // the compiler threads "slab 0 exists" through to its consumption: it waited for slab 0 before requesting slab 1)
-        int nch_v = nch;
+        // (transposed slabs: a lane's item is ONE batch row — rows beyond the batch hold zeros nobody needs to move: with B = 20 the
+        //  second tile's slab items are 3/4 padding, 37 % of the slab bytes that all cross this one CU's memory pipeline)
+        int nch_v = (!TS || (pit >> 6) * 16 + l15 < nvalid) ? nch : 0;
         asm volatile("" : "+v"(nch_v));
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
@@ -1422,13 +1424,17 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
         if (is_tw) {
             constexpr float L2E = 1.44269504088896341f;
             f32x4 xv[4];
+            // classes this lane holds below C, counted from its first: per STEP an opaque value — as a loop invariant the compiler
+            // turns the 16 tests into 16 scalar-register masks held (spilled) across the whole step loop
+            int nq = C - r0;
+            asm volatile("" : "+v"(nq));
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 *reinterpret_cast<f32x4*>(ll.lgraw + b_row * 64 + cb * 16 + r0) = lgt[cb];
                 xv[cb] = lgt[cb];
                 if (cb >= ncb - 1) {      // (only the last class block has padding; the blocks behind it do not exist)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) xv[cb][q] = (cb * 16 + r0 + q < C) ? lgt[cb][q] : -3.0e38f;
+                    for (int q = 0; q < 4; ++q) xv[cb][q] = (cb * 16 + q < nq) ? lgt[cb][q] : -3.0e38f;
                 }
             }
             float mxl = fmaxf(fmaxf(xv[0][0], xv[0][1]), fmaxf(xv[0][2], xv[0][3]));

@@ -247,7 +247,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
             stage_table(dst, un.S, un.tp, sa.tab.dtype, un.width, un.k0, un.cc, cand_order(sa.order, sa.g, un.gidx), a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
     };
     // cross-wave reduction of a forward partial (fixed order 0..7, as sweep_body) -> partial slot (write-through) -> arrive
-    auto reduce_publish = [&](const ResUnit& un, const f32x4 (&yacc)[MB]) {
+    auto reduce_publish = [&](const ResUnit& un, const f32x4 (&yacc)[MB], const int nv_next) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
             *reinterpret_cast<f32x4*>(wred + ((wave * MB + mb) << 8) + lane * 4) = yacc[mb];
@@ -258,7 +258,8 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
 #pragma unroll
             for (int w = 1; w < STEP_NW; ++w)
                 sum += *reinterpret_cast<const f32x4*>(wred + ((w * MB + slot) << 8) + ln * 4);
-            stc4<true>(sa.stepbuf, un.part + (slot << 8) + ln * 4, sum);
+            // (transposed slabs: lane ln holds batch row slot * 16 + (ln & 15); the chain does not read rows beyond the batch)
+            if (!MFAS_RES_TRANSPOSED_SLABS || slot * 16 + (ln & 15) < nv_next) stc4<true>(sa.stepbuf, un.part + (slot << 8) + ln * 4, sum);
         }
         wg_publish_barrier();
         if (tid == 0) __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -286,7 +287,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     }
                 }
             }
-            reduce_publish(U[u], yacc);
+            reduce_publish(U[u], yacc, (int)min((int64_t)a.B, a.N));
             if (1 < a.T) stage(U[u], lds + res_xbo(U[u], 1), 1);
         }
     }
@@ -377,7 +378,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 PTRACE(2);
                 PTRACE_UNIT(128);   // compute done
                 if (fwd) {
-                    reduce_publish(un, yacc);
+                    reduce_publish(un, yacc, (int)min((int64_t)a.B, a.N - (int64_t)(t + 1) * a.B));
                 } else {
                     wg_publish_barrier();
                     if (tid == 0) __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
