@@ -1168,7 +1168,10 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     const float dscale = g.use_drop ? g.drop_scale : 1.0f;
     // phase 0: sum the sweep's column-chunk partial slabs of (cell pi, tile) in fixed order: S chunks, then V chunks
     f32x4 accS = z4, accV = z4;
-    const int nch_c = nch, ns_c = ns;
+    // (per STEP opaque copies of the slab counts: as loop invariants, every `u < nch` below becomes a scalar-register mask computed
+    //  before the resident step loop and held — spilled to vector lanes, two v_readlane each use — across it)
+    int nch_c = nch, ns_c = ns;
+    if constexpr (RES) asm volatile("" : "+s"(nch_c), "+s"(ns_c));
     // (acc += slab as a volatile statement: as a plain fadd, `0 + slab 0` is speculated up into the block that requests slab 0 —
     //  and the wave waits for slab 0 before it requests slab 1: one memory round trip more in front of every step)
     auto slab_add = [](f32x4& acc, const f32x4& p) {
@@ -1650,6 +1653,7 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
     }
     if (tid == CHAIN_THREADS - 64 && (RES || a.stats)) {
         float ls = 0.f, ncor = 0.f;
+#pragma unroll 1
         for (int b = 0; b < Bp; ++b) { ls += red_l[b]; ncor += red_l[Bp + b]; }
         if constexpr (RES) {   // accumulated in registers for the epoch, flushed by lean_res_store
             rs->loss += (double)ls;
@@ -1665,6 +1669,9 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
     const int hc = tid - (CHAIN_THREADS - 256);
     if (hc >= 0 && hc < C) {            // head bias: column sums of dlogits
         float gsum = 0.f;
+        // (rolled loops in the lean tail: unrolled, their 32 loop-invariant LDS addresses are hoisted out of the resident step loop
+        //  and live — spilled — across it)
+#pragma unroll 1
         for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + hc];
         const int64_t o = cvec_off + g.vec_head + hc;
         float w = vecW[g.vec_head + hc], m = vecM[g.vec_head + hc], v = vecV[g.vec_head + hc];
@@ -1676,6 +1683,7 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
         if (rr < R && (which == 0 || g.bn)) {
             float gsum = 0.f;
             if (which == 0) {
+#pragma unroll 1
                 for (int b = 0; b < Bp; ++b) gsum += dy_l[i * Bp * SX + b * SX + rr];
             } else {
                 gsum = gv2[(i * 2 + (which - 1)) * 16 + rr];
