@@ -413,3 +413,37 @@ def test_engine_search_default_vs_reference_pointwise():
             worst = max(worst, max(abs(row[k] - stats[0, ci][k]) for k in range(12) if "acc" in SNAMES[k]))
         pop.close()
     print(f"G19a: worst |accuracy - reference| over 3 confs x 8 starts x 6 statistics = {worst:.5f}")
+
+
+@pytest.mark.gpu
+def test_full_search_schedule_configs3_is_seeded_and_deterministic():
+    """BASELINE configs[3] END TO END at full size (main_searchable_ntu.py --num_samples 50 --search_iterations 5 --max_fusions 4,
+    R=16, B=20, drpt 0.5, no batchnorm, E=10, N = 10,000 / 5,600: models/searchable.py:48-137 — 20 train_sampled_models calls, 982
+    candidates) through the engine with the seeded controller (surrogate on the CPU), twice: the call structure is the reference's,
+    the first call (the 32 single-layer configurations, drawn before any accuracy exists) has its fixed digest, and the whole decision
+    stream — every configuration list the controller asked for, which depends on every accuracy the engine returned — is the same
+    in both runs bit for bit.  (The digest of the stream itself moves whenever the engine's rounding does; bench.py prints it as
+    config.search_c3.decision_digest.)"""
+    import torch
+    import main_searchable_ntu as MS
+    import mfas_amd as M
+    from mfas_amd.search import NTUSearcher
+    from mfas_amd.search.searcher import timed_search
+    dev = torch.device("cuda:0")
+    train = M.FeatureTable.synthetic(10000, 1, dev, torch.bfloat16, snr=0.12)
+    devl = M.FeatureTable.synthetic(5600, 2, dev, torch.bfloat16, snr=0.12)
+    sa = MS.parse_args(["--num_samples", "50", "--search_iterations", "5", "--max_fusions", "4", "--epochs", "10", "--no-verbose"])
+    reps = []
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(max(1, sa.controller_threads))      # (the 81k-parameter surrogate trains fastest on a few threads: bench.py does the same)
+    try:
+        for _ in range(2):
+            _, rep = timed_search(NTUSearcher(sa, dev, {"train": train, "dev": devl}), seed=0)
+            reps.append(rep)
+    finally:
+        torch.set_num_threads(nthr)
+    a, b = reps
+    assert a["candidates"] == 982 and a["calls"] == 20 and a["call_sizes"] == [32] + [50] * 19
+    assert a["first_call_digest"] == "001d9faf4bfd802c"
+    assert a["decision_digest"] == b["decision_digest"] and a["best_dev_acc"] == b["best_dev_acc"]
+    assert 0.05 < a["best_dev_acc"] < 1.0 and a["cand_per_s"] > 50
