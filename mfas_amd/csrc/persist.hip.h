@@ -64,9 +64,25 @@ __device__ __forceinline__ bool wg_wait_ge(const uint32_t* p, uint32_t target, u
     if (threadIdx.x == 0) {
         int ok = 1;
         uint32_t spins = 0;
-        while (ld_u32_relaxed(p) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 0x3FFu) == 0 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
+        // pipelined poll: four reads in flight, a short sleep apart — a read's round trip to the coherence point (~0.4 us) is then
+        // not the polling interval, only its latency
+        uint32_t v0 = ld_u32_relaxed(p);
+        __builtin_amdgcn_s_sleep(2);
+        uint32_t v1 = ld_u32_relaxed(p);
+        __builtin_amdgcn_s_sleep(2);
+        uint32_t v2 = ld_u32_relaxed(p);
+        for (;;) {      // the OLDEST read is tested (the two younger ones stay in flight), then re-issued behind them: a ring of three
+                        // registers, unrolled (rotating the registers instead makes the compiler wait for the youngest read)
+            if (v0 >= target) break;
+            __builtin_amdgcn_s_sleep(2);
+            v0 = ld_u32_relaxed(p);
+            if (v1 >= target) break;
+            __builtin_amdgcn_s_sleep(2);
+            v1 = ld_u32_relaxed(p);
+            if (v2 >= target) break;
+            __builtin_amdgcn_s_sleep(2);
+            v2 = ld_u32_relaxed(p);
+            if (((spins += 3) & 0x3FFu) < 3 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
                 __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -303,18 +319,51 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         if (tid == 0) {
             int pick = -2;   // -2: every unit has finished its last step
             uint32_t spins = 0;
+            if constexpr (NU == 1) {
+                // one unit: pipelined poll of its candidate's flag (wg_wait_ge's ring of three reads in flight)
+                const int tj = nxt[0];
+                if (tj < a.T) {
+                    const uint32_t target = (uint32_t)(tj + 1);
+                    const uint32_t* fl = U[0].flag;
+                    uint32_t v0 = ld_u32_relaxed(fl);
+                    __builtin_amdgcn_s_sleep(2);
+                    uint32_t v1 = ld_u32_relaxed(fl);
+                    __builtin_amdgcn_s_sleep(2);
+                    uint32_t v2 = ld_u32_relaxed(fl);
+                    pick = 0;
+                    for (;;) {
+                        if (v0 >= target) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        v0 = ld_u32_relaxed(fl);
+                        if (v1 >= target) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        v1 = ld_u32_relaxed(fl);
+                        if (v2 >= target) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        v2 = ld_u32_relaxed(fl);
+                        if (((spins += 3) & 0x3FFu) < 3 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
+                            __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            pick = -3;
+                            break;
+                        }
+                    }
+                }
+            } else
             for (;;) {
                 bool pending = false;
+                uint32_t fv[NU];      // every unit's flag requested before the first is tested: the reads overlap
+#pragma unroll
+                for (int u = 0; u < NU; ++u) fv[u] = ld_u32_relaxed(U[u].flag);
 #pragma unroll
                 for (int q = 1; q <= NU; ++q) {
                     const int j = (last + q) % NU;
                     const int tj = nxt[j];
                     if (tj < a.T && pick < 0) {
                         pending = true;
-                        uint32_t* fl = U[0].flag;
+                        uint32_t fj = fv[0];
 #pragma unroll
-                        for (int u = 1; u < NU; ++u) if (j == u) fl = U[u].flag;
-                        if (ld_u32_relaxed(fl) >= (uint32_t)(tj + 1)) pick = j;
+                        for (int u = 1; u < NU; ++u) if (j == u) fj = fv[u];
+                        if (fj >= (uint32_t)(tj + 1)) pick = j;
                     }
                 }
                 if (pick >= 0 || !pending) break;
