@@ -53,6 +53,7 @@ struct PersistArgs {
 #define PTRACE(slot) do { if (a.trace && tr_on) a.trace[tr_base + (slot)] = wall_clock64(); } while (0)
 #define PTRACE_UNIT(base) do { if (a.trace && un.cand == 0 && t == 12 && tid == 0 && un.index < 64) a.trace[(base) + un.index] = wall_clock64(); } while (0)
 #define PERSIST_SPIN_LIMIT (1u << 22)   // a few seconds of s_sleep polls: only a lost workgroup or a bug gets here
+#define PERSIST_RING_LIMIT (1u << 25)   // the same few seconds for the pipelined polls (a read every ~0.1 us instead of one per round trip)
 #define PERSIST_ROLL_LIMIT 6000u        // roll call at launch start: ~5 ms of polls for every workgroup of the grid to be resident
 #define PERSIST_ROLL(sync, K) ((sync) + (size_t)(K) * PERSIST_SYNC_STRIDE + 32)   // workgroups that have started (own cache line)
 #define PERSIST_MAX_RELAUNCHES 40       // host: relaunches of an epoch whose roll call failed before the resident schedule is given up
@@ -82,7 +83,7 @@ __device__ __forceinline__ bool wg_wait_ge(const uint32_t* p, uint32_t target, u
             if (v2 >= target) break;
             __builtin_amdgcn_s_sleep(2);
             v2 = ld_u32_relaxed(p);
-            if (((spins += 3) & 0x3FFu) < 3 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
+            if (((spins += 3) & 0x3FFu) < 3 && (spins > PERSIST_RING_LIMIT || ld_u32_relaxed(abortw) != 0)) {
                 __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -341,7 +342,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                         if (v2 >= target) break;
                         __builtin_amdgcn_s_sleep(2);
                         v2 = ld_u32_relaxed(fl);
-                        if (((spins += 3) & 0x3FFu) < 3 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
+                        if (((spins += 3) & 0x3FFu) < 3 && (spins > PERSIST_RING_LIMIT || ld_u32_relaxed(abortw) != 0)) {
                             __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             pick = -3;
                             break;

@@ -14,6 +14,7 @@ Rule (float64, like the reference's numpy scalars): with c the number of steps s
 import numpy as np
 
 _RESTART_SLACK = 1e-10
+_TABLES = {}      # (scheduler state, n) -> (table, state after it): eta_table's memo
 
 
 def _set_lr(optimizer, lr):
@@ -31,16 +32,28 @@ class LRCosineAnnealingScheduler:
         self.eta = eta_max
 
     def eta_table(self, n):
-        """The next ``n`` learning rates; the object ends up where ``n`` calls of ``step()`` would leave it."""
-        table = np.empty(int(n), np.float64)
+        """The next ``n`` learning rates; the object ends up where ``n`` calls of ``step()`` would leave it.  Whole-run tables are
+        memoised on the scheduler's state (the search asks for the same 5,000-step table in every one of its calls: 3.4 ms of a
+        64 ms call of 16 candidates in this loop)."""
+        n = int(n)
+        key = (self.eta_max, self.eta_min, self.Ti, self.Tm, self.nbpe, self.iteration_counter, n)
+        hit = _TABLES.get(key) if n > 64 else None
+        if hit is not None:
+            table, (self.Ti, self.Tcur, self.iteration_counter, self.eta) = hit
+            return table.copy()
+        table = np.empty(n, np.float64)
         half_span = 0.5 * (self.eta_max - self.eta_min)
-        for k in range(int(n)):
+        for k in range(n):
             self.Tcur = self.iteration_counter / self.nbpe
             self.iteration_counter += 1.0
             self.eta = self.eta_min + half_span * (1 + np.cos(np.pi * self.Tcur / self.Ti))
             table[k] = self.eta
             if self.eta <= self.eta_min + _RESTART_SLACK:
                 self.Ti, self.Tcur, self.iteration_counter = self.Ti * self.Tm, 0, 0
+        if n > 64:
+            if len(_TABLES) >= 32:
+                _TABLES.clear()
+            _TABLES[key] = (table.copy(), (self.Ti, self.Tcur, self.iteration_counter, self.eta))
         return table
 
     def step(self):
