@@ -8,7 +8,7 @@ timeout 900 python bench.py > $out/bench_pop128.log 2> $out/bench_pop128.err; ec
 { timeout 400 python tools/popsweep.py 16 20 0 10 1,4,6,8,12,16,24,28
   timeout 400 python tools/popsweep.py 16 20 0 10 6,16,28 mixed
   timeout 600 python tools/popsweep.py 128 16 1 10 1,3,6,8,16; } 2>&1 | grep -v amdgpu > $out/popsweep.log
-bash tools/r04_chain_phases.sh > $out/chain_phases.log 2>&1
+bash tools/archive/r04_chain_phases.sh > $out/chain_phases.log 2>&1
 timeout 1500 python -m pytest tests/test_fullsize.py -q -x -m gpu -k "search_default" 2>&1 | tail -5 > $out/search_default_tests.log
 find $out -name "*kernel_stats.csv" | head -3
 cat $out/popsweep.log; cat $out/chain_phases.log; cat $out/search_default_tests.log; head -c 1500 $out/bench_pop128.log
