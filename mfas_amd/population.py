@@ -162,7 +162,7 @@ def train_sharded(wanted: Sequence[int], owner: Sequence[int], cap: int, K: int,
 # (profiles/r02_popsweep*.log, r03_popsweep_split_kernels.log).  Strong scaling of a small population is LATENCY-bound: with the
 # resident persistent schedule (R <= 16) a step costs the same for 1...8 candidates, so giving a rank fewer candidates than that
 # buys nothing — the model is what lets the sharder see it.
-RESIDENT_STEP_US = ((8, 14.3), (16, 15.3), (28, 17.5))      # R <= 16: (largest share, us per step) of the resident schedule
+RESIDENT_STEP_US = ((8, 10.7), (16, 11.3), (28, 15.5))      # R <= 16: (largest share, us per step) of the resident schedule (round 5: profiles/r05_popsweep.log)
 STREAM_BYTES_PER_US = 5.5e6                                   # what the sweep streams at (24 B per parameter and step)
 
 

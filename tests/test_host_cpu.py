@@ -204,7 +204,7 @@ def test_sharder_uses_only_the_ranks_that_pay():
     c128 = P.candidate_cost(CONFS["c4"], 128, O.S_SIZES, O.V_SIZES)
     assert P.predicted_step_us([c16] * 1, 16) == P.predicted_step_us([c16] * 8, 16) < P.predicted_step_us([c16] * 9, 16)
     assert P.choose_ranks([c16] * 6, 8, 16) == 1                    # 6 candidates: one GPU is as fast as eight
-    assert P.choose_ranks([c16] * 16, 2, 16) == 2                   # BASELINE configs[2]: 15.3 -> 14.3 us per step, worth 7 %
+    assert P.choose_ranks([c16] * 16, 2, 16) == 2                   # BASELINE configs[2]: 11.3 -> 10.7 us per step, worth 5 %
     assert P.choose_ranks([c16] * 50, 8, 16) == 7                   # configs[3]: shares of <= 8 already with 7 ranks
     assert P.choose_ranks([c128] * 1024, 8, 128) == 8               # the weak-scaling headline (128 per rank) uses every rank
     assert P.choose_ranks([c128] * 6, 8, 128) == 1
