@@ -278,9 +278,23 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
             // (transposed slabs: lane ln holds batch row slot * 16 + (ln & 15); the chain does not read rows beyond the batch)
             if (!MFAS_RES_TRANSPOSED_SLABS || slot * 16 + (ln & 15) < nv_next) stc4<true>(sa.stepbuf, un.part + (slot << 8) + ln * 4, sum);
         }
-        wg_publish_barrier();
-        if (tid == 0) __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Only the MB waves that stored the slab wait for the stores' acknowledgements; the LAST of them to see its own arrive counts
+        // the unit's arrival (an LDS ticket).  The other waves go on — the poller (wave 7) already looks for the workgroup's next
+        // unit while waves 0 .. MB-1 drain: no workgroup barrier behind the publish any more.
+        if (tid < MB * 64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                int old = 0;
+                if constexpr (MB > 1) old = __hip_atomic_fetch_add(ldsw + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old == MB - 1) {
+                    if constexpr (MB > 1) __hip_atomic_store(ldsw + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     };
+    constexpr int POLL_TID = STEP_THREADS - 64;      // the unit loop's poller: lane 0 of the last wave (waves 0 .. MB-1 drain the slab stores)
+    if (tid == 0) ldsw[4] = 0;
 
     // ---- prologue per unit: forward partial sums of batch 0 (no update), then batch 1 staged
 #pragma unroll
@@ -308,7 +322,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
             if (1 < a.T) stage(U[u], lds + res_xbo(U[u], 1), 1);
         }
     }
-    if (tid == 0) {
+    if (tid == POLL_TID) {
 #pragma unroll
         for (int u = 0; u < NU; ++u) nxt[u] = U[u].valid ? 0 : a.T;
     }
@@ -317,7 +331,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
     // ---- the epoch's train steps: serve whichever of my units' candidates has published the step the unit waits for
     int last = NU - 1;
     for (;;) {
-        if (tid == 0) {
+        if (tid == POLL_TID) {
             int pick = -2;   // -2: every unit has finished its last step
             uint32_t spins = 0;
             if constexpr (NU == 1) {
@@ -435,7 +449,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 }
                 PTRACE(3);
                 PTRACE_UNIT(192);   // arrived
-                if (tid == 0) nxt[u] = t + 1;
+                if (tid == POLL_TID) nxt[u] = t + 1;
                 cur[u] ^= 1;
                 // batch t+2 into the buffer batch t just vacated: it lands while this unit's chain runs step t+1
                 if (t + 2 < a.T) stage(un, lds + res_xbo(un, cur[u] ^ 1), t + 2);
