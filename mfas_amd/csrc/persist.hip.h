@@ -543,8 +543,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
         const bool tr_on = bid == 0 && tid == 0 && t >= 8 && t < 16;
         const int tr_base = (t - 8) * 8;
         PTRACE(0);
-        if (!wg_wait_ge(PERSIST_CNT(a.sync, bid), need * (uint32_t)(t + 1), abortw, ldsw)) return;
-        PTRACE(1);
+        // (the step's scalars — two loads from the Adam table among them — are requested BEFORE the wait for the units, not behind it)
         ChainStep cs;
         cs.pos_t = a.pos0 + (int64_t)t * a.B;
         cs.base_t = t * a.B;
@@ -553,6 +552,8 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
         cs.epoch = a.epoch;
         cs.ss = a.scal[2 * (int64_t)cs.gstep];
         cs.bc2s = a.scal[2 * (int64_t)cs.gstep + 1];
+        if (!wg_wait_ge(PERSIST_CNT(a.sync, bid), need * (uint32_t)(t + 1), abortw, ldsw)) return;
+        PTRACE(1);
         chain_lean<MB, 2, 16, PLAIN>(a.ca, cs, bid, lds, lpre, keep, labp);
         PTRACE(2);
         wg_publish_barrier();
