@@ -1306,10 +1306,12 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                     lds_barrier();
                     if (is_tw) tot = *reinterpret_cast<const f32x4*>(ex + r0) + *reinterpret_cast<const f32x4*>(ex + 16 + r0);
                 }
+                // (divisions and square root through common.hip.h's correctly rounding packed sequences: the values of operator/ and
+                //  sqrtf() for a fraction of the instructions)
+                const f32x4 nf4 = (f32x4)(nf), rnf4 = (f32x4)(rcp_refined(nf));
                 f32x4 mu = z4, s2 = z4;
                 if (is_tw) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) mu[q] = tot[q] / nf;
+                    mu = div_by4(tot, nf4, rnf4);
                     const f32x4 dlt = v - mu;
                     s2 = row_sum16_4(rowok ? dlt * dlt : z4);
                 }
@@ -1322,12 +1324,9 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                 if (is_tw) {
                     const f32x4 gam = *reinterpret_cast<const f32x4*>(vecW + vbl + VEC_G * Rp + r0);
                     const f32x4 bet = *reinterpret_cast<const f32x4*>(vecW + vbl + VEC_BE * Rp + r0);
-                    f32x4 var, rstd;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        var[q] = tot2[q] / nf;
-                        rstd[q] = 1.0f / sqrtf(var[q] + g.bn_eps);
-                    }
+                    const f32x4 var = div_by4(tot2, nf4, rnf4);
+                    const f32x4 sd = sqrt_rn4(var + g.bn_eps);
+                    const f32x4 rstd = div_by4((f32x4)(1.0f), sd, rcp_refined4(sd));
                     const f32x4 xh = (v - mu) * rstd;
                     z = xh * gam + bet;
                     if (l15 == 0) {
@@ -1560,12 +1559,11 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                 if (is_tw) {
                     const f32x4 gr = *reinterpret_cast<const f32x4*>(vecW + i * g.vec_cell_stride + VEC_G * Rp + r0) *
                                      *reinterpret_cast<const f32x4*>(bst + i * 32 + 16 + r0);
+                    const f32x4 nf4 = (f32x4)(nf), rnf4 = (f32x4)(rcp_refined(nf));
+                    const f32x4 k1 = div_by4(dbet, nf4, rnf4), k2 = div_by4(dgam, nf4, rnf4);
+                    const f32x4 da = gr * (d - k1 - xh * k2);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float k1 = dbet[q] / nf, k2 = dgam[q] / nf;
-                        const float da = gr[q] * (d[q] - k1 - xh[q] * k2);
-                        dz[q] = (rowok && cm[q]) ? da : 0.f;
-                    }
+                    for (int q = 0; q < 4; ++q) dz[q] = (rowok && cm[q]) ? da[q] : 0.f;
                     if (wave == 0 && l15 == 0) {
                         *reinterpret_cast<f32x4*>(gv2 + (i * 2 + 0) * 16 + r0) = dgam;
                         *reinterpret_cast<f32x4*>(gv2 + (i * 2 + 1) * 16 + r0) = dbet;
