@@ -166,6 +166,7 @@ struct mfas_population {
     int fell_back = 0;              // the resident schedule was given up for launch-per-phase inside a train() call (roll call never complete)
     uint32_t* d_sync = nullptr;     // [K] flags | [K] counters | abort word (zeroed before every launch)
     int32_t* d_need = nullptr;      // [K] sweep units per candidate
+    int32_t* d_role = nullptr;      // [K + nres_wg] role of every workgroup of the resident launch (XCD-aware placement)
     float* d_scal = nullptr;        // device copy of the step scalars
     size_t scal_cap = 0;
     unsigned long long* d_trace = nullptr;
@@ -803,10 +804,11 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     CREATE_CHK(set_lds((k_chain<1, true>), p->lds_chain));
     CREATE_CHK(set_lds((k_chain<2, true>), p->lds_chain));
     if (p->persist) {
+        std::vector<int> res_cand;      // candidate of every resident unit, in unit order
         {   // unit list of the resident schedule: the feature units (the resident lean chain updates OUT / HEAD itself)
             std::vector<SegDesc> res;
             for (const SegDesc& d : p->descs)
-                if (d.kind <= KIND_V) res.push_back(d);
+                if (d.kind <= KIND_V) { res.push_back(d); res_cand.push_back(d.cand); }
             p->n_pdescs = (int)res.size();
             CREATE_CHK(hipMalloc(&p->d_pdescs, sizeof(SegDesc) * res.size()));
             CREATE_CHK(hipMemcpy(p->d_pdescs, res.data(), sizeof(SegDesc) * res.size(), hipMemcpyHostToDevice));
@@ -816,6 +818,53 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             if (d.kind <= KIND_V) need[d.cand]++;
         CREATE_CHK(hipMalloc(&p->d_need, sizeof(int32_t) * K));
         CREATE_CHK(hipMemcpy(p->d_need, need.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice));
+        if (!getenv("MFAS_NO_XCD_PLACEMENT")) {
+            // XCD-aware placement (round 5): consecutive workgroups of a launch are dealt round-robin to the 8 XCDs (block b -> XCD b % 8,
+            // MI355X_MICROARCH.md), each with its own L2.  A candidate's chain and the workgroups that hold its units exchange 60 KB of
+            // slabs and 8 KB of dy per step: deal the roles so that they share an XCD wherever its 32 slots allow (greedy, candidate by
+            // candidate; two-unit workgroups are grouped by their FIRST unit's candidate, and the chain of a candidate that only ever
+            // comes second goes where most of its units are).  Placement only: the exchanges do not depend on it.
+            const int nwg = p->nres_wg, G = K + nwg, NX = 8;
+            std::vector<std::vector<int>> slots(NX);
+            for (int b = G - 1; b >= 0; --b) slots[b % NX].push_back(b);       // (pop_back hands out the lowest block of an XCD first)
+            std::vector<int32_t> role(G, -1);
+            std::vector<int> chain_xcd(K, -1);
+            std::vector<char> wg_done(nwg, 0);
+            auto take = [&](int x, int item) { role[slots[x].back()] = item; slots[x].pop_back(); };
+            auto roomiest = [&]() { int bx = 0; for (int x = 1; x < NX; ++x) if (slots[x].size() > slots[bx].size()) bx = x; return bx; };
+            std::vector<int> prim(nwg), sec(nwg, -1);
+            for (int w = 0; w < nwg; ++w) {
+                prim[w] = res_cand[w];
+                if (p->res_nu == 2 && w + nwg < (int)res_cand.size()) sec[w] = res_cand[w + nwg];
+            }
+            for (int c = 0; c < K; ++c) {                   // candidates that come first in some workgroup: chain + those workgroups
+                bool any = false;
+                for (int w = 0; w < nwg; ++w) any = any || prim[w] == c;
+                if (!any) continue;
+                const int x = roomiest();
+                if (!slots[x].empty()) { take(x, c); chain_xcd[c] = x; }
+                for (int w = 0; w < nwg; ++w)
+                    if (prim[w] == c && !wg_done[w] && !slots[x].empty()) { take(x, K + w); wg_done[w] = 1; }
+            }
+            std::vector<int> wg_xcd(nwg, -1);
+            for (int b = 0; b < G; ++b) if (role[b] >= K) wg_xcd[role[b] - K] = b % NX;
+            for (int c = 0; c < K; ++c) {                   // chains not placed yet: where most of the candidate's units are
+                if (chain_xcd[c] >= 0) continue;
+                std::vector<int> votes(NX, 0);
+                for (int w = 0; w < nwg; ++w) if ((prim[w] == c || sec[w] == c) && wg_xcd[w] >= 0) votes[wg_xcd[w]]++;
+                int bx = -1;
+                for (int x = 0; x < NX; ++x) if (!slots[x].empty() && (bx < 0 || votes[x] > votes[bx])) bx = x;
+                if (bx >= 0) { take(bx, c); chain_xcd[c] = bx; }
+            }
+            for (int w = 0; w < nwg; ++w)                   // whatever did not fit its XCD
+                if (!wg_done[w]) { const int x = roomiest(); take(x, K + w); wg_done[w] = 1; }
+            bool ok = true;
+            for (int b = 0; b < G; ++b) ok = ok && role[b] >= 0;
+            if (ok) {
+                CREATE_CHK(hipMalloc(&p->d_role, sizeof(int32_t) * G));
+                CREATE_CHK(hipMemcpy(p->d_role, role.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice));
+            }
+        }
         CREATE_CHK(hipMalloc(&p->d_sync, sizeof(uint32_t) * ((size_t)K * PERSIST_SYNC_STRIDE + 64)));
         if (getenv("MFAS_PERSIST_TRACE")) {
             CREATE_CHK(hipMalloc(&p->d_trace, sizeof(unsigned long long) * 256));
@@ -881,7 +930,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     hipFree(p->d_red_cnt);
     hipFree(p->d_gather);
     hipFree(p->d_cellflag);
-    hipFree(p->d_sync); hipFree(p->d_need); hipFree(p->d_scal); hipFree(p->d_trace); hipFree(p->d_pdescs);
+    hipFree(p->d_sync); hipFree(p->d_need); hipFree(p->d_role); hipFree(p->d_scal); hipFree(p->d_trace); hipFree(p->d_pdescs);
     delete p;
 }
 
@@ -1380,7 +1429,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         pa.lose_step = getenv("MFAS_PERSIST_TEST_LOSE_STEP") ? atoi(getenv("MFAS_PERSIST_TEST_LOSE_STEP")) : -1;
         pa.N = N; pa.pos0 = (int64_t)ep * N;
         pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);
-        pa.scal = p->d_scal; pa.sync = p->d_sync; pa.need = p->d_need; pa.trace = p->d_trace;
+        pa.scal = p->d_scal; pa.sync = p->d_sync; pa.need = p->d_need; pa.role = p->d_role; pa.trace = p->d_trace;
         const unsigned grid = (unsigned)(K + pa.nres_wg);
         if ((int)grid > p->n_cus) return hipErrorInvalidConfiguration;
         const bool prof = p->profiling;

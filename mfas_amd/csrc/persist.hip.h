@@ -42,6 +42,7 @@ struct PersistArgs {
                                // unit arrivals (own 128-byte line: hundreds of pollers and the arrival atomics of different candidates
                                // must not share a cache line / L2 channel); sync[64K] = abort word
     const int32_t* need;       // [K] sweep units of candidate c (= arrivals per step)
+    const int32_t* role;       // [grid] XCD-aware placement (round 5): block b runs role[b] — < K: that candidate's chain, else unit workgroup role[b] - K (nullptr: b)
     unsigned long long* trace; // optional: 100 MHz timestamps of candidate 0's chain and of sweep unit 0 (steps 8..15)
 };
 
@@ -524,7 +525,9 @@ template <int MB, int NTR, bool X16, int NU, bool PLAIN>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs a, const int lds_word) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
-    const int bid = (int)blockIdx.x, tid = threadIdx.x;
+    // blockIdx.x round-robins over the 8 XCDs: the host deals the roles so that a candidate's chain and its unit workgroups share an XCD
+    // (and its L2) where they fit — placement only, every exchange stays placement-independent (sc1 / write-through)
+    const int bid = a.role ? a.role[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
     const int K = a.nchain;
     if (!persist_roll_call(a.sync, K, gridDim.x, ldsw)) return;
     if (bid >= K) {
