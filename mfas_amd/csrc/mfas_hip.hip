@@ -1427,6 +1427,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         pa.res_nu = p->res_nu; pa.nres_wg = p->nres_wg; pa.res_buf_words = p->res_buf_words;
         pa.T = (int)T; pa.epoch = ep;
         pa.lose_step = getenv("MFAS_PERSIST_TEST_LOSE_STEP") ? atoi(getenv("MFAS_PERSIST_TEST_LOSE_STEP")) : -1;
+        pa.res_defer = getenv("MFAS_RES_NO_DEFER") ? 0 : 1;     // (A/B switch of the deferred unit hand-off, persist.hip.h)
         pa.N = N; pa.pos0 = (int64_t)ep * N;
         pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);
         pa.scal = p->d_scal; pa.sync = p->d_sync; pa.need = p->d_need; pa.role = p->d_role; pa.trace = p->d_trace;

@@ -32,7 +32,8 @@ struct PersistArgs {
                                       // LDS words of one staged batch
     int32_t nres, res_chain;   // units [0, nres) are RESIDENT feature units: one workgroup each (blocks K .. K + nres);
                                // res_chain: the (lean) chain owns OUT / HEAD and keeps them + its vector block on chip
-    int32_t lose_step, _pad0;  // test hook (MFAS_PERSIST_TEST_LOSE_STEP): candidate 0's chain never publishes this step (-1: off) -- the
+    int32_t lose_step, res_defer;  // res_defer (round 5, two-unit workgroups, 16-bit staging): a unit's arrival and the staging of its batch after next are
+                               // finished while the workgroup already serves its OTHER unit (sweep_resident); lose_step: test hook (MFAS_PERSIST_TEST_LOSE_STEP): candidate 0's chain never publishes this step (-1: off) -- the
                                // bounded waits must then end the launch with an error instead of hanging
     int32_t T, epoch;          // train steps of this launch, epoch index (statistics slot)
     int64_t N, pos0;           // N_train, epoch * N_train (position in the sample-order table)
@@ -264,8 +265,22 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         else
             stage_table(dst, un.S, un.tp, sa.tab.dtype, un.width, un.k0, un.cc, cand_order(sa.order, sa.g, un.gidx), a.pos0 + (int64_t)t * a.B, t * a.B, nv, Bp, tid, STEP_THREADS);
     };
+    // the slab-storing waves (0 .. MB-1) wait for their stores' acknowledgements; the LAST of them counts the unit's arrival (LDS ticket)
+    auto arrive = [&](uint32_t* cnt) {
+        if (tid < MB * 64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                int old = 0;
+                if constexpr (MB > 1) old = __hip_atomic_fetch_add(ldsw + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old == MB - 1) {
+                    if constexpr (MB > 1) __hip_atomic_store(ldsw + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    };
     // cross-wave reduction of a forward partial (fixed order 0..7, as sweep_body) -> partial slot (write-through) -> arrive
-    auto reduce_publish = [&](const ResUnit& un, const f32x4 (&yacc)[MB], const int nv_next) {
+    auto reduce_publish = [&](const ResUnit& un, const f32x4 (&yacc)[MB], const int nv_next, const bool defer_arrival) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
             *reinterpret_cast<f32x4*>(wred + ((wave * MB + mb) << 8) + lane * 4) = yacc[mb];
@@ -282,17 +297,60 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         // Only the MB waves that stored the slab wait for the stores' acknowledgements; the LAST of them to see its own arrive counts
         // the unit's arrival (an LDS ticket).  The other waves go on — the poller (wave 7) already looks for the workgroup's next
         // unit while waves 0 .. MB-1 drain: no workgroup barrier behind the publish any more.
-        if (tid < MB * 64) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                int old = 0;
-                if constexpr (MB > 1) old = __hip_atomic_fetch_add(ldsw + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (old == MB - 1) {
-                    if constexpr (MB > 1) __hip_atomic_store(ldsw + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!defer_arrival) arrive(un.cnt);
+    };
+    // ---- deferred hand-off (a.res_defer; two units per workgroup, 16-bit staging).  After a unit's step the workgroup used to sit through
+    // two latencies before it could turn to its other unit: the slab stores' acknowledgements (~1 us, then the arrival) and the round
+    // trip of the table rows of the batch after next (order entry -> row -> registers -> LDS, ~2 us).  Both are only WAITS, so with a
+    // second unit to serve they are left pending: the rows travel by LDS-DMA (one `global_load_lds_dwordx4` per row and wave — a row
+    // of <= 512 columns is the 64 lanes' 16-byte pieces — into the SAME row-major image the cooperative staging writes; no registers,
+    // no store pass; the order entries were fetched by scalar loads under the unit's MFMAs), and once the OTHER unit's dy has been
+    // requested, ONE `s_waitcnt vmcnt(0)` per wave covers stores, copies and dy; there the pending unit's arrival is counted.  When
+    // the first look at the flags finds no unit ready the pending work is finished at once (pick -4): an arrival is never held back
+    // by a wait for a flag.  Every wave passes that wait, and a workgroup barrier follows, before anyone reads the copied rows.
+    // Rows beyond the batch size are never copied: they are the zeros the prologue's cooperative staging left in both buffers.
+    // Arithmetic, reduction order and the staged image are unchanged: results are bit-identical with and without it.
+    constexpr bool CAN_DEFER = NU == 2 && X16 && !DMA;
+    constexpr int NROWQ = Bp / STEP_NW;        // rows per wave: wave w copies rows w, w + 8, ...
+    const bool defer_on = CAN_DEFER && a.res_defer != 0;
+    int rowq[NROWQ];                           // (wave-uniform) table rows of this wave's pieces: -1 = zeros (short last batch), -2 = nothing to copy
+    int pend = -1;                             // unit whose arrival is pending
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto rows_order = [&](const ResUnit& un, const int t) {
+        const int nv = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
+        const int32_t* ord = cand_order(sa.order, sa.g, un.gidx);
+        const int64_t pos = a.pos0 + (int64_t)t * a.B;
+#pragma unroll
+        for (int j = 0; j < NROWQ; ++j) {
+            const int b = wave_u + STEP_NW * j;
+            rowq[j] = b < a.B ? -1 : -2;
+            if (b < nv) rowq[j] = ord ? ord[pos + b] : t * a.B + b;
+        }
+    };
+    auto rows_dma = [&](const ResUnit& un, const int dst_word) {
+        const int vpr = un.cc >> 3;            // 16-byte pieces per row
+        const uint32_t dst0 = lds_base + ((uint32_t)dst_word << 2);
+#pragma unroll
+        for (int j = 0; j < NROWQ; ++j) {
+            if (rowq[j] != -2) {
+                const int b = wave_u + STEP_NW * j;
+                const uint16_t* grow = reinterpret_cast<const uint16_t*>(un.tp) + (int64_t)rowq[j] * un.width + un.k0;
+                for (int p0 = 0; p0 < vpr; p0 += 64) {
+                    if (p0 + lane < vpr) {
+                        const void* src = rowq[j] >= 0 ? static_cast<const void*>(grow + ((p0 + lane) << 3)) : zeros;
+                        glds16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((b * un.S + (p0 << 3)) << 1)));
+                    }
                 }
             }
         }
+    };
+    // every wave: its copies (and, on the slab-storing waves, the stores) have landed; then the pending unit's arrival
+    auto finish_pending = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (pend == u) arrive(U[u].cnt);
+        pend = -1;
     };
     constexpr int POLL_TID = STEP_THREADS - 64;      // the unit loop's poller: lane 0 of the last wave (waves 0 .. MB-1 drain the slab stores)
     if (tid == 0) ldsw[4] = 0;
@@ -319,7 +377,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     }
                 }
             }
-            reduce_publish(U[u], yacc, (int)min((int64_t)a.B, a.N));
+            reduce_publish(U[u], yacc, (int)min((int64_t)a.B, a.N), false);
             if (1 < a.T) stage(U[u], lds + res_xbo(U[u], 1), 1);
         }
     }
@@ -383,6 +441,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     }
                 }
                 if (pick >= 0 || !pending) break;
+                if (pend >= 0) { pick = -4; break; }     // nothing to serve yet: finish the pending arrival / rows first
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 0x3FFu) == 0 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
                     __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -395,6 +454,11 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         __syncthreads();
         const int pick = ldsw[0];
         if (pick == -3) return;
+        if (pick == -4) {
+            __syncthreads();   // everyone has read the pick before the poller overwrites it
+            finish_pending();
+            continue;
+        }
         if (pick < 0) break;
         const int t = nxt[pick];
         __syncthreads();   // everyone has read the pick / step before lane 0 can overwrite them
@@ -418,6 +482,10 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 const float a_ss = a.scal[2 * (int64_t)(a.gstep0 + t)], a_bc2s = a.scal[2 * (int64_t)(a.gstep0 + t) + 1];
                 // this wave's own LDS-DMA copies (batch t+1, requested after the unit's previous step) have landed: nothing else reads them
                 if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the other unit's pending arrival and rows: their round trips have run alongside the poll and this unit's dy request
+                if (pend >= 0) finish_pending();
+                const bool rows_next = defer_on && fwd && t + 2 < a.T;
+                if constexpr (CAN_DEFER) { if (rows_next) rows_order(un, t + 2); }     // (order entries of the batch after next: scalar loads, back before the MFMAs end)
                 f32x4 yacc[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -443,7 +511,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 PTRACE(2);
                 PTRACE_UNIT(128);   // compute done
                 if (fwd) {
-                    reduce_publish(un, yacc, (int)min((int64_t)a.B, a.N - (int64_t)(t + 1) * a.B));
+                    reduce_publish(un, yacc, (int)min((int64_t)a.B, a.N - (int64_t)(t + 1) * a.B), defer_on);
                 } else {
                     wg_publish_barrier();
                     if (tid == 0) __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -453,10 +521,14 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 if (tid == POLL_TID) nxt[u] = t + 1;
                 cur[u] ^= 1;
                 // batch t+2 into the buffer batch t just vacated: it lands while this unit's chain runs step t+1
-                if (t + 2 < a.T) stage(un, lds + res_xbo(un, cur[u] ^ 1), t + 2);
+                if (defer_on && fwd) {
+                    pend = u;
+                    if constexpr (CAN_DEFER) { if (rows_next) rows_dma(un, res_xbo(un, cur[u] ^ 1)); }
+                } else if (t + 2 < a.T) stage(un, lds + res_xbo(un, cur[u] ^ 1), t + 2);
             }
         }
     }
+    if (pend >= 0) finish_pending();
     // ---- state back to memory (dev evaluation, parameter export and the next epoch's launch read it there)
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
