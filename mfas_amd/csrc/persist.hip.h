@@ -36,6 +36,9 @@ struct PersistArgs {
                                // finished while the workgroup already serves its OTHER unit (sweep_resident); lose_step: test hook (MFAS_PERSIST_TEST_LOSE_STEP): candidate 0's chain never publishes this step (-1: off) -- the
                                // bounded waits must then end the launch with an error instead of hanging
     int32_t T, epoch;          // train steps of this launch, epoch index (statistics slot)
+    int64_t out_delta;         // floats from the plane the launch READS its state from (sa.plane = ca.plane) to the plane it writes the state back to at
+                               // its end: 0 = in place; != 0 = the population's second plane set (the dev pass of the previous epoch may then still
+                               // be reading the first while this launch runs: mfas_hip.hip, eval overlap)
     int64_t N, pos0;           // N_train, epoch * N_train (position in the sample-order table)
     int32_t B, gstep0;         // batch size, epoch * batches-per-epoch (Adam / dropout step counter base)
     const float* scal;         // device [steps][2]: {lr_t/(1-beta1^t), sqrt(1-beta2^t)}
@@ -538,9 +541,9 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 const int kb = wave + STEP_NW * s;
                 if (kb < U[u].nkb) {
                     const int64_t off = (int64_t)kb * 256 + lane * 4;
-                    *reinterpret_cast<f32x4*>(U[u].Wp + off) = w4[u][s];
-                    *reinterpret_cast<f32x4*>(U[u].Mp + off) = m4[u][s];
-                    *reinterpret_cast<f32x4*>(U[u].Vp + off) = v4[u][s];
+                    *reinterpret_cast<f32x4*>(U[u].Wp + a.out_delta + off) = w4[u][s];
+                    *reinterpret_cast<f32x4*>(U[u].Mp + a.out_delta + off) = m4[u][s];
+                    *reinterpret_cast<f32x4*>(U[u].Vp + a.out_delta + off) = v4[u][s];
                 }
             }
         }
@@ -640,5 +643,5 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
         chain_lean_tail<MB, 2>(a.ca, cs, bid, lds, &rs);   // statistics + vector-parameter Adam, after dy is out
         lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the feature units run
     }
-    lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs);
+    lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs, a.out_delta);
 }

@@ -900,6 +900,60 @@ def test_persistent_schedule_fuzz_bit_identical(dev, seed):
     print("schedule:", sched["default"])
 
 
+@pytest.mark.parametrize("K,mixed,N", [(24, True, 4010), (22, False, 4000), (7, True, 4010)])
+def test_deferred_handoff_and_eval_overlap_bit_identical(dev, K, mixed, N):
+    """Round 5 (late): two-unit resident workgroups finish a unit's arrival and the LDS-DMA copy of its batch after next under the
+    OTHER unit's dy request (persist.hip.h, deferred hand-off), and a resident launch that leaves CUs idle runs the previous epoch's
+    dev pass beside it from a second plane set (mfas_hip.hip, eval overlap).  Both only move WHEN things happen: statistics (train
+    and dev), parameters and both Adam moments must equal the run with both switched off, bit for bit — 24 / 22 candidates take the
+    deferred path (two units per workgroup, ~1,000 columns), N = 4,010 ends every epoch on a 10-row batch (rows past the batch are
+    copied from the zero line), 7 candidates leave ~40 CUs idle (overlap without deferral), E = 3 walks both plane sets."""
+    import os
+    from mfas_amd import FeatureTable, Hyper, Population
+    hp = Hyper(R=16, C=60, B=20, bn=False, drpt=0.5, tap_bits=16)
+    rng = np.random.default_rng(11)
+    confs = [np.array(CONFS["c4"])] * K
+    if mixed:
+        confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in rng.integers(2, 5, K)]
+    tr = FeatureTable.synthetic(N, 1, dev, torch.bfloat16, snr=0.5)
+    dv = FeatureTable.synthetic(1200, 2, dev, torch.bfloat16, snr=0.5)
+    E = 3
+    nb = -(-N // 20)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / 20, E * nb)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    order = torch.stack([torch.randperm(N, generator=g, device=dev) for _ in range(E)]).to(torch.int32)
+    out, sched = {}, {}
+    for mode in ("off", "on"):
+        if mode == "off":
+            os.environ["MFAS_RES_NO_DEFER"] = "1"
+            os.environ["MFAS_NO_EVAL_OVERLAP"] = "1"
+        try:
+            pop = Population(hp, confs, dev, drop_seeds=list(range(50, 50 + K)))
+            sched[mode] = pop.schedule()
+            pop.init(list(range(1, K + 1)))
+            stats, status = pop.train(tr, dv, E, etas, order=order)
+            assert not status.any()
+            out[mode] = (stats, [[pop.get_params(k, pl).cpu().numpy() for pl in range(3)] for k in range(K)])
+            # a second call on the same population starts from whichever plane set the first one ended on
+            stats2, status2 = pop.train(tr, dv, 2, etas[:2 * nb], order=order[:2])
+            out[mode] += (stats2, [pop.get_params(k, 0).cpu().numpy() for k in range(K)])
+            pop.close()
+        finally:
+            os.environ.pop("MFAS_RES_NO_DEFER", None)
+            os.environ.pop("MFAS_NO_EVAL_OVERLAP", None)
+    assert sched["on"]["persistent"] and sched["on"] == sched["off"]
+    if K >= 20:
+        assert sched["on"]["units_per_workgroup"] == 2
+    assert out["off"][0].tobytes() == out["on"][0].tobytes()
+    assert out["off"][2].tobytes() == out["on"][2].tobytes()
+    for k in range(K):
+        for pl in range(3):
+            assert np.array_equal(out["off"][1][k][pl], out["on"][1][k][pl]), (k, pl)
+        assert np.array_equal(out["off"][3][k], out["on"][3][k]), k
+    assert (out["on"][0]["dev_corrects"][:, -1] > 0.05 * 1200).all()      # and it trains (chance = 1.7 %)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_same_group_launch_fuzz_bit_identical(dev, seed):
     """Random small populations with the general chain (R = 32 / 64 / 128): the same-group fused launch — chain and sweep of the
