@@ -1773,17 +1773,17 @@ __device__ __forceinline__ void lean_res_update(const ChainArgs& a, const ChainS
 }
 
 template <int MB>
-__device__ __forceinline__ void lean_res_store(const ChainArgs& a, const int bid, const int epoch, float* lds, const LeanRes& rs, const int64_t out_delta) {
+__device__ __forceinline__ void lean_res_store(const ChainArgs& a, const int bid, const int epoch, float* lds, const LeanRes& rs) {
     const CandDev& cd = a.cands[bid];
     const LeanLds<MB> ll(lds, a.g);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __syncthreads();
     for (int e = tid; e < ll.nvec; e += CHAIN_THREADS)
-        for (int pl = 0; pl < 3; ++pl) a.plane[out_delta + pl * a.plane_stride + cd.vec_off + e] = ll.vec_l[pl * ll.nvec + e];
+        for (int pl = 0; pl < 3; ++pl) a.plane[pl * a.plane_stride + cd.vec_off + e] = ll.vec_l[pl * ll.nvec + e];
     if (wave < LEAN_OWN_TILES && lean_own_live(cd, a.g, wave)) {
         const int s = wave;
         for (int pl = 0; pl < 3; ++pl)
-            *reinterpret_cast<f32x4*>(a.plane + out_delta + pl * a.plane_stride + lean_own_off(cd, s) + lane * 4) =
+            *reinterpret_cast<f32x4*>(a.plane + pl * a.plane_stride + lean_own_off(cd, s) + lane * 4) =
                 *reinterpret_cast<const f32x4*>(ll.own + (pl * LEAN_OWN_TILES + s) * 256 + lane * 4);
         *reinterpret_cast<f32x4*>(const_cast<float*>(a.wt) + lean_own_toff(cd, s) + lane * 4) =
             *reinterpret_cast<const f32x4*>(ll.own + (3 * LEAN_OWN_TILES + s) * 256 + lane * 4);

@@ -114,11 +114,6 @@ struct mfas_population {
     float* wt = nullptr;
     float* stepbuf = nullptr;
     float* best = nullptr;          // snapshot_best: copy of plane 0
-    // eval overlap (resident schedule with idle CUs): a second W | m | v plane set — an epoch's launch reads its state from `plane` and
-    // writes it back to `plane_alt`, then the two swap — so the dev pass of epoch e (own stream) may run beside the launch of epoch e + 1
-    float* plane_alt = nullptr;
-    hipStream_t eval_stream = nullptr;
-    hipEvent_t eval_ev[2] = {nullptr, nullptr};
     int64_t plane_stride = 0, wt_size = 0, step_total = 0;
     CandDev* d_cands = nullptr;
     SegDesc* d_descs = nullptr;
@@ -161,7 +156,6 @@ struct mfas_population {
     uint32_t* d_cellflag = nullptr; // [K][CELLFLAG_STRIDE]
     bool res_chain = false;         // resident lean chain: owns OUT / HEAD + vector block on chip; persistent units = feature units only
     int res_nu = 1;                 // resident units per workgroup (2: a workgroup serves units of two candidates)
-    int res_cols_per_wg = 0;        // resident feature columns per resident workgroup (average)
     int nres_wg = 0;                // resident workgroups = ceil(nres / res_nu)
     int res_buf_words = 0;          // LDS words of one staged batch of a resident unit
     int nres = 0;                   // resident feature units (one workgroup each, W/m/v in registers): the first nres persistent units
@@ -586,11 +580,6 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         p->res_wide = lp.res_wide;
         p->nres = res_ok ? nfeat : 0;
         p->res_nu = plan_nu;
-        {
-            int64_t cols = 0;
-            for (const SegDesc& d : p->descs) if (d.kind <= KIND_V) cols += d.cc;
-            p->res_cols_per_wg = lp.nres_wg > 0 ? (int)(cols / lp.nres_wg) : 0;
-        }
         p->nres_wg = lp.nres_wg;
         p->res_buf_words = (int)((hp->tap_bits == 16 ? (size_t)g.Bp * (max_fcc + 8) * 2 : (size_t)g.Bp * (max_fcc + 4) * 4) / 4);
         size_t ls = 0;
@@ -883,7 +872,8 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         }
 #define SET_RES(M, P) CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 1, P>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 2, P>), p->lds_president)); \
                    CREATE_CHK(set_lds((k_president<M, PERSIST_NTR16, true, 1, P>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 1, P>), p->lds_president)); \
-                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2, P>), p->lds_president))
+                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2, P>), p->lds_president)); \
+                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2, P, true>), p->lds_president))
         SET_RES(1, false); SET_RES(2, false); SET_RES(1, true); SET_RES(2, true);
 #undef SET_RES
     }
@@ -935,9 +925,6 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->ev) hipEventDestroy(e);
     hipFree(p->plane); hipFree(p->wt); hipFree(p->stepbuf); hipFree(p->best);
-    hipFree(p->plane_alt);
-    if (p->eval_stream) { hipStreamSynchronize(p->eval_stream); hipStreamDestroy(p->eval_stream); }
-    for (hipEvent_t e : p->eval_ev) if (e) hipEventDestroy(e);
     for (auto& gr : p->groups) { hipFree(gr.d_descs); hipFree(gr.d_taps); }
     hipFree(p->d_cands); hipFree(p->d_descs); hipFree(p->d_mdescs); hipFree(p->d_stats); hipFree(p->d_status);
     hipFree(p->d_seeds); hipFree(p->d_corr); hipFree(p->d_posw);
@@ -1425,39 +1412,6 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         const size_t have = (size_t)(max_steps >= 0 ? std::min<int64_t>(max_steps, (int64_t)epochs * nb) : (int64_t)epochs * nb) * 2;
         HIPCHK(hipMemcpyAsync(p->d_scal, step_scalars, sizeof(float) * have, hipMemcpyHostToDevice, p->stream));
     }
-    // Eval overlap (round 5).  A resident launch that leaves CUs idle (K + unit workgroups < #CUs: shares of <= ~25 candidates) keeps its
-    // whole state on chip and touches the planes only at its start (read) and end (write back).  With a second plane set the dev pass of
-    // epoch e — launched on its own stream right BEHIND the launch of epoch e + 1, so that the resident grid gets its CUs first — runs on
-    // the idle CUs beside it instead of in front of it: epoch e reads set A and writes set B, the dev pass of e reads B, epoch e + 1 reads
-    // B and writes A (after the dev pass of e - 1, which read A, has finished: stream event).  If the runtime serialises the two streams
-    // the dev pass simply runs behind the launch — slower, never wrong.  Not with snapshot_best (the host looks at every epoch's result).
-    bool overlap = false;
-    bool eval_recorded[2] = {false, false};
-    int pending_eval = -1;
-    if (p->persist && do_dev && !snapshot_best && epochs > 1 && p->n_cus - (K + p->nres_wg) >= 24 && !getenv("MFAS_NO_EVAL_OVERLAP")) {
-        if (!p->plane_alt) HIPCHK(hipMalloc(&p->plane_alt, sizeof(float) * 3 * (size_t)p->plane_stride));
-        if (!p->eval_stream) HIPCHK(hipStreamCreateWithFlags(&p->eval_stream, hipStreamNonBlocking));
-        for (hipEvent_t& ev : p->eval_ev) if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        // (padding and whatever no workgroup owns must be the same in both sets)
-        HIPCHK(hipMemcpyAsync(p->plane_alt, p->plane, sizeof(float) * 3 * (size_t)p->plane_stride, hipMemcpyDeviceToDevice, p->stream));
-        overlap = true;
-    }
-    auto launch_dev_eval = [&](int ep, hipStream_t st) -> hipError_t {
-        EvalArgs ea;
-        memset(&ea, 0, sizeof(ea));
-        ea.cands = p->d_cands; ea.plane = p->plane; ea.tab = *dev; ea.row0 = 0; ea.nrows = dev->N;
-        ea.cand0 = 0; ea.epoch = ep; ea.E = epochs; ea.g = g; ea.stats = p->d_stats; ea.pos_w = p->d_posw;
-        return launch_eval(p, ea, K, st);
-    };
-    // the dev pass left pending by the overlap, now on the main stream (end of training, or the resident schedule is being given up)
-    auto flush_pending_eval = [&]() -> hipError_t {
-        for (int i = 0; i < 2; ++i)
-            if (eval_recorded[i]) { hipError_t e = hipStreamWaitEvent(p->stream, p->eval_ev[i], 0); if (e != hipSuccess) return e; eval_recorded[i] = false; }
-        if (pending_eval < 0) return hipSuccess;
-        const int ep = pending_eval;
-        pending_eval = -1;
-        return launch_dev_eval(ep, p->stream);
-    };
     // one persistent launch = all train steps of one epoch (persist.hip.h)
     const int test_not_resident = getenv("MFAS_PERSIST_TEST_NOT_RESIDENT") ? atoi(getenv("MFAS_PERSIST_TEST_NOT_RESIDENT")) : -1;   // test hook: from
                                                                            // this epoch on every roll call "fails" (nothing is launched)
@@ -1470,23 +1424,17 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         pa.sa = st.sa; pa.ca = st.ca;
         pa.sa.desc = p->d_pdescs; pa.sa.tdesc = nullptr; pa.sa.ntap = 0;
         pa.ca.cands = p->d_cands;
-        pa.sa.plane = p->plane; pa.ca.plane = p->plane;
-        pa.out_delta = overlap ? (int64_t)(p->plane_alt - p->plane) : 0;
-        if (overlap && eval_recorded[ep & 1]) {      // the dev pass of epoch ep - 2 read the plane this launch writes back to
-            e = hipStreamWaitEvent(p->stream, p->eval_ev[ep & 1], 0);
-            if (e != hipSuccess) return e;
-        }
         pa.nchain = K; pa.nitems = p->n_pdescs; pa.nres = p->nres; pa.res_chain = p->res_chain ? 1 : 0; pa.res_wide = p->res_wide ? 1 : 0;
         pa.res_nu = p->res_nu; pa.nres_wg = p->nres_wg; pa.res_buf_words = p->res_buf_words;
         pa.T = (int)T; pa.epoch = ep;
         pa.lose_step = getenv("MFAS_PERSIST_TEST_LOSE_STEP") ? atoi(getenv("MFAS_PERSIST_TEST_LOSE_STEP")) : -1;
-        // deferred unit hand-off (persist.hip.h): pays where the two-unit workgroups are the step's bottleneck — ~1,000 feature columns per
-        // workgroup, i.e. 17-28 conf-4-sized candidates (22 / 28: 17.1 / 17.4 -> 16.1 / 16.4 us per step; configs[3] 264 -> 288 cand/s on one
-        // box).  Where the workgroups have slack the later arrival costs more than the earlier turn to the other unit saves: 16 candidates
-        // (two 256-column units) 13.2 -> 13.7 us, the MM-IMDB-shaped rounds of 51 (~600 columns per workgroup) 338 -> 321 cand/s
-        // (profiles/r05_defer_ab.log, r05_defer_bench.log).  MFAS_RES_DEFER=0/1 forces it.
-        pa.res_defer = (p->res_nu == 2 && p->res_cols_per_wg >= 768) ? 1 : 0;
-        if (const char* e = getenv("MFAS_RES_DEFER")) pa.res_defer = atoi(e) != 0;
+        // deferred unit hand-off (persist.hip.h, k_president<..., DEFER = true>): OPT-IN (MFAS_RES_DEFER=1; two units per workgroup, 16-bit
+        // tables).  Measured NEGATIVE against the kernels it would replace: 22 / 28 candidates 15.3 / 15.2 -> 16.4 / 16.4 us per step, 16
+        // candidates 11.1 -> 13.6 (profiles/r05_defer_ab.log, final build) — what it saves in waits it loses to the 17-24 spilled VGPRs its
+        // extra live state costs the unit loop (scratch reloads on the serial path); an earlier "+6 %" compared it with a merged kernel
+        // whose non-deferred path carried the same spills.
+        pa.res_defer = 0;
+        if (const char* e = getenv("MFAS_RES_DEFER")) pa.res_defer = (atoi(e) != 0 && p->res_nu == 2) ? 1 : 0;
         if (getenv("MFAS_RES_NO_DEFER")) pa.res_defer = 0;
         pa.N = N; pa.pos0 = (int64_t)ep * N;
         pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);
@@ -1508,11 +1456,15 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             const bool plain = !g.bn && !g.alphas && !g.multitask && g.loss_mode == 0 && !getenv("MFAS_NO_PLAIN_CHAIN");
 #define RES_LAUNCH(M, NTR, X, NU) do { if (plain) hipLaunchKernelGGL((k_president<M, NTR, X, NU, true>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); \
                                        else hipLaunchKernelGGL((k_president<M, NTR, X, NU, false>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); } while (0)
+#define RES_LAUNCH_D(M, NTR, X, NU) do { if (plain) hipLaunchKernelGGL((k_president<M, NTR, X, NU, true, true>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); \
+                                         else hipLaunchKernelGGL((k_president<M, NTR, X, NU, false, true>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); } while (0)
 #define RES_PICK(M) do { if (train->dtype == MFAS_DT_F32) { if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, false, 2); else RES_LAUNCH(M, PERSIST_NTR, false, 1); } \
                          else if (pa.res_wide) RES_LAUNCH(M, PERSIST_NTR16, true, 1); \
+                         else if (pa.res_nu == 2 && pa.res_defer) RES_LAUNCH_D(M, PERSIST_NTR, true, 2); \
                          else if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, true, 2); else RES_LAUNCH(M, PERSIST_NTR, true, 1); } while (0)
             if (g.MB == 1) RES_PICK(1); else RES_PICK(2);
 #undef RES_PICK
+#undef RES_LAUNCH_D
 #undef RES_LAUNCH
         }
         if (prof) {
@@ -1533,14 +1485,6 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         for (int attempt = 0;; ++attempt) {
             hipError_t e = persist_epoch_once(ep, T);
             if (e != hipSuccess) return e;
-            if (overlap && pending_eval >= 0) {       // the previous epoch's dev pass: beside this launch, on the CUs it leaves idle
-                const int pe = pending_eval;
-                pending_eval = -1;
-                e = launch_dev_eval(pe, p->eval_stream);
-                if (e == hipSuccess) e = hipEventRecord(p->eval_ev[pe & 1], p->eval_stream);
-                if (e != hipSuccess) return e;
-                eval_recorded[pe & 1] = true;
-            }
             e = hipStreamSynchronize(p->stream);
             if (e != hipSuccess) return e;
             if (getenv("MFAS_PERSIST_VERBOSE") && atoi(getenv("MFAS_PERSIST_VERBOSE")) >= 2)
@@ -1567,15 +1511,12 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             if (aborts[ep] == PERSIST_ABORT_NOT_RESIDENT) {
                 // every attempt failed its roll call: nothing of this epoch has run.  Train it — and the rest — launch per phase.
                 if (getenv("MFAS_PERSIST_VERBOSE")) fprintf(stderr, "[persist] epoch %d: the resident grid never became resident; falling back to launch-per-phase\n", ep);
-                HIPCHK(flush_pending_eval());
-                overlap = false;
                 rc = persist_fallback(p);
                 if (rc) return rc;
                 HIPCHK(init_args());
                 HIPCHK(setup_gather());
                 aborts[ep] = 0;
             } else if (aborts[ep]) {
-                if (p->eval_stream) hipStreamSynchronize(p->eval_stream);
                 HIPCHK(hipStreamSynchronize(p->stream));
                 return fail(MFAS_EHIP, "persistent step loop: a workgroup timed out waiting for its dependency (abort code 1: the epoch was "
                                        "abandoned half way, this population's parameters are not usable)");
@@ -1601,11 +1542,12 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         }
         done += T;
         HIPCHK(hipGetLastError());
-        if (overlap && p->persist) {
-            std::swap(p->plane, p->plane_alt);      // the epoch's state went to the other set
-            pending_eval = ep;                      // its dev pass goes out behind the next epoch's launch (or at the end)
-        } else if (do_dev) {
-            HIPCHK(launch_dev_eval(ep, p->stream));
+        if (do_dev) {
+            EvalArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.cands = p->d_cands; ea.plane = p->plane; ea.tab = *dev; ea.row0 = 0; ea.nrows = dev->N;
+            ea.cand0 = 0; ea.epoch = ep; ea.E = epochs; ea.g = g; ea.stats = p->d_stats; ea.pos_w = p->d_posw;
+            HIPCHK(launch_eval(p, ea, K, p->stream));
             if (snapshot_best) {
                 HIPCHK(hipMemcpyAsync(hstats.data(), p->d_stats, sizeof(DevStats) * K * epochs, hipMemcpyDeviceToHost, p->stream));
                 HIPCHK(hipStreamSynchronize(p->stream));
@@ -1620,7 +1562,6 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             }
         }
     }
-    HIPCHK(flush_pending_eval());
     if (snapshot_best && do_dev) {   // model.load_state_dict(best_model_sd) (:86), unconditionally
         HIPCHK(hipMemcpyAsync(p->plane, p->best, sizeof(float) * (size_t)p->plane_stride, hipMemcpyDeviceToDevice, p->stream));
         // the transposed OUT / HEAD tiles the backward chain reads still hold the last epoch's weights: re-derive them

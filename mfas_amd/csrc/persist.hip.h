@@ -36,9 +36,6 @@ struct PersistArgs {
                                // finished while the workgroup already serves its OTHER unit (sweep_resident); lose_step: test hook (MFAS_PERSIST_TEST_LOSE_STEP): candidate 0's chain never publishes this step (-1: off) -- the
                                // bounded waits must then end the launch with an error instead of hanging
     int32_t T, epoch;          // train steps of this launch, epoch index (statistics slot)
-    int64_t out_delta;         // floats from the plane the launch READS its state from (sa.plane = ca.plane) to the plane it writes the state back to at
-                               // its end: 0 = in place; != 0 = the population's second plane set (the dev pass of the previous epoch may then still
-                               // be reading the first while this launch runs: mfas_hip.hip, eval overlap)
     int64_t N, pos0;           // N_train, epoch * N_train (position in the sample-order table)
     int32_t B, gstep0;         // batch size, epoch * batches-per-epoch (Adam / dropout step counter base)
     const float* scal;         // device [steps][2]: {lr_t/(1-beta1^t), sqrt(1-beta2^t)}
@@ -173,7 +170,7 @@ struct ResUnit {              // wave-uniform constants of one resident unit
 };
 __device__ __forceinline__ int res_xbo(const ResUnit& un, int which) { return un.xb0 + (which ? un.xbw : 0); }
 
-template <int MB, int NTR, bool X16, int NU>
+template <int MB, int NTR, bool X16, int NU, bool DEFER>
 __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int wg, const int nwg, float* lds, int* ldsw) {
     const SweepArgs& sa = a.sa;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -302,7 +299,8 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         // unit while waves 0 .. MB-1 drain: no workgroup barrier behind the publish any more.
         if (!defer_arrival) arrive(un.cnt);
     };
-    // ---- deferred hand-off (a.res_defer; two units per workgroup, 16-bit staging).  After a unit's step the workgroup used to sit through
+    // ---- deferred hand-off (DEFER instantiation, selected by a.res_defer = MFAS_RES_DEFER=1; two units per workgroup, 16-bit staging;
+    // measured slower than the default, kept opt-in).  After a unit's step the workgroup sits through
     // two latencies before it could turn to its other unit: the slab stores' acknowledgements (~1 us, then the arrival) and the round
     // trip of the table rows of the batch after next (order entry -> row -> registers -> LDS, ~2 us).  Both are only WAITS, so with a
     // second unit to serve they are left pending: the rows travel by LDS-DMA (one `global_load_lds_dwordx4` per row and wave — a row
@@ -313,34 +311,35 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
     // by a wait for a flag.  Every wave passes that wait, and a workgroup barrier follows, before anyone reads the copied rows.
     // Rows beyond the batch size are never copied: they are the zeros the prologue's cooperative staging left in both buffers.
     // Arithmetic, reduction order and the staged image are unchanged: results are bit-identical with and without it.
-    constexpr bool CAN_DEFER = NU == 2 && X16 && !DMA;
-    constexpr int NROWQ = Bp / STEP_NW;        // rows per wave: wave w copies rows w, w + 8, ...
-    const bool defer_on = CAN_DEFER && a.res_defer != 0;
-    int rowq[NROWQ];                           // (wave-uniform) table rows of this wave's pieces: -1 = zeros (short last batch), -2 = nothing to copy
+    constexpr bool CAN_DEFER = DEFER && NU == 2 && X16 && !DMA;      // (its own instantiation: the other forms carry none of it)
+    constexpr int NROWQ = Bp / STEP_NW;        // rows per wave: wave w copies rows w, w + 8, ... (2 or 4: a power of two);  row codes: -1 = zeros (short last batch), -2 = nothing to copy
+    constexpr bool defer_on = CAN_DEFER;
     int pend = -1;                             // unit whose arrival is pending
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // (the rows wait in ONE vector register — lane j holds the table row of this wave's j-th piece — not in NROWQ scalars: the merged
+    //  kernel's scalar file is full and every scalar kept across the MFMAs is spilled to lanes of a VGPR.  Either way this form's
+    //  unit loop carries 17-24 spilled VGPRs the default one does not, and loses to it: OPT-IN only)
+    int rowv = -2;
     auto rows_order = [&](const ResUnit& un, const int t) {
         const int nv = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
         const int32_t* ord = cand_order(sa.order, sa.g, un.gidx);
         const int64_t pos = a.pos0 + (int64_t)t * a.B;
-#pragma unroll
-        for (int j = 0; j < NROWQ; ++j) {
-            const int b = wave_u + STEP_NW * j;
-            rowq[j] = b < a.B ? -1 : -2;
-            if (b < nv) rowq[j] = ord ? ord[pos + b] : t * a.B + b;
-        }
+        const int b = wave + STEP_NW * (lane & (NROWQ - 1));      // lanes 0 .. NROWQ-1 matter
+        rowv = b < a.B ? -1 : -2;
+        if (b < nv) rowv = ord ? ord[pos + b] : t * a.B + b;
     };
     auto rows_dma = [&](const ResUnit& un, const int dst_word) {
         const int vpr = un.cc >> 3;            // 16-byte pieces per row
         const uint32_t dst0 = lds_base + ((uint32_t)dst_word << 2);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
         for (int j = 0; j < NROWQ; ++j) {
-            if (rowq[j] != -2) {
-                const int b = wave_u + STEP_NW * j;
-                const uint16_t* grow = reinterpret_cast<const uint16_t*>(un.tp) + (int64_t)rowq[j] * un.width + un.k0;
+            const int row = __builtin_amdgcn_readlane(rowv, j);
+            if (row != -2) {
+                const int b = wv + STEP_NW * j;
+                const uint16_t* grow = reinterpret_cast<const uint16_t*>(un.tp) + (int64_t)row * un.width + un.k0;
                 for (int p0 = 0; p0 < vpr; p0 += 64) {
                     if (p0 + lane < vpr) {
-                        const void* src = rowq[j] >= 0 ? static_cast<const void*>(grow + ((p0 + lane) << 3)) : zeros;
+                        const void* src = row >= 0 ? static_cast<const void*>(grow + ((p0 + lane) << 3)) : zeros;
                         glds16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((b * un.S + (p0 << 3)) << 1)));
                     }
                 }
@@ -444,7 +443,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     }
                 }
                 if (pick >= 0 || !pending) break;
-                if (pend >= 0) { pick = -4; break; }     // nothing to serve yet: finish the pending arrival / rows first
+                if constexpr (CAN_DEFER) { if (pend >= 0) { pick = -4; break; } }     // nothing to serve yet: finish the pending arrival / rows first
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 0x3FFu) == 0 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
                     __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -457,10 +456,12 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         __syncthreads();
         const int pick = ldsw[0];
         if (pick == -3) return;
-        if (pick == -4) {
-            __syncthreads();   // everyone has read the pick before the poller overwrites it
-            finish_pending();
-            continue;
+        if constexpr (CAN_DEFER) {
+            if (pick == -4) {
+                __syncthreads();   // everyone has read the pick before the poller overwrites it
+                finish_pending();
+                continue;
+            }
         }
         if (pick < 0) break;
         const int t = nxt[pick];
@@ -486,7 +487,13 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 // this wave's own LDS-DMA copies (batch t+1, requested after the unit's previous step) have landed: nothing else reads them
                 if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // the other unit's pending arrival and rows: their round trips have run alongside the poll and this unit's dy request
-                if (pend >= 0) finish_pending();
+                if constexpr (CAN_DEFER) {
+                    if (pend >= 0) {      // (always the OTHER unit: a unit cannot be published again before its own arrival)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        arrive(U[1 - u].cnt);
+                        pend = -1;
+                    }
+                }
                 const bool rows_next = defer_on && fwd && t + 2 < a.T;
                 if constexpr (CAN_DEFER) { if (rows_next) rows_order(un, t + 2); }     // (order entries of the batch after next: scalar loads, back before the MFMAs end)
                 f32x4 yacc[MB];
@@ -531,7 +538,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
             }
         }
     }
-    if (pend >= 0) finish_pending();
+    if constexpr (CAN_DEFER) { if (pend >= 0) finish_pending(); }
     // ---- state back to memory (dev evaluation, parameter export and the next epoch's launch read it there)
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -541,9 +548,9 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 const int kb = wave + STEP_NW * s;
                 if (kb < U[u].nkb) {
                     const int64_t off = (int64_t)kb * 256 + lane * 4;
-                    *reinterpret_cast<f32x4*>(U[u].Wp + a.out_delta + off) = w4[u][s];
-                    *reinterpret_cast<f32x4*>(U[u].Mp + a.out_delta + off) = m4[u][s];
-                    *reinterpret_cast<f32x4*>(U[u].Vp + a.out_delta + off) = v4[u][s];
+                    *reinterpret_cast<f32x4*>(U[u].Wp + off) = w4[u][s];
+                    *reinterpret_cast<f32x4*>(U[u].Mp + off) = m4[u][s];
+                    *reinterpret_cast<f32x4*>(U[u].Vp + off) = v4[u][s];
                 }
             }
         }
@@ -587,7 +594,7 @@ __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_president<MB, NTR, X16, NU, PLAIN> — the RESIDENT schedule (the default for small populations at R <= 16): ONE launch per epoch,
+// k_president<MB, NTR, X16, NU, PLAIN, DEFER> — the RESIDENT schedule (the default for small populations at R <= 16): ONE launch per epoch,
 // blocks [0, K) = the resident lean chain of candidate blockIdx.x, blocks [K, K + nres_wg) = workgroups of resident feature
 // units.  One instantiation per unit form (staging width, tiles per wave, units per workgroup): an instantiation carries exactly
 // the two bodies its grid runs.  (Round 3 also ran the two roles as two kernels on two streams, each with its own register budget — the unit
@@ -596,7 +603,7 @@ __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, c
 // hardware queues, which HIP does not promise: after a few hundred stream creations in one process the second launch queued
 // behind the first and every roll call failed.  One launch cannot be split by the runtime.)
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NTR, bool X16, int NU, bool PLAIN>
+template <int MB, int NTR, bool X16, int NU, bool PLAIN, bool DEFER = false>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs a, const int lds_word) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
@@ -606,7 +613,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
     const int K = a.nchain;
     if (!persist_roll_call(a.sync, K, gridDim.x, ldsw)) return;
     if (bid >= K) {
-        sweep_resident<MB, NTR, X16, NU>(a, bid - K, a.nres_wg, lds, ldsw);
+        sweep_resident<MB, NTR, X16, NU, DEFER>(a, bid - K, a.nres_wg, lds, ldsw);
         return;
     }
     uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
@@ -643,5 +650,5 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
         chain_lean_tail<MB, 2>(a.ca, cs, bid, lds, &rs);   // statistics + vector-parameter Adam, after dy is out
         lean_res_update<MB>(a.ca, cs, bid, lds);           // OUT / HEAD dW + Adam while the feature units run
     }
-    lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs, a.out_delta);
+    lean_res_store<MB>(a.ca, bid, a.epoch, lds, rs);
 }

@@ -900,14 +900,14 @@ def test_persistent_schedule_fuzz_bit_identical(dev, seed):
     print("schedule:", sched["default"])
 
 
-@pytest.mark.parametrize("K,mixed,N", [(24, True, 4010), (22, False, 4000), (7, True, 4010)])
-def test_deferred_handoff_and_eval_overlap_bit_identical(dev, K, mixed, N):
-    """Round 5 (late): two-unit resident workgroups finish a unit's arrival and the LDS-DMA copy of its batch after next under the
-    OTHER unit's dy request (persist.hip.h, deferred hand-off), and a resident launch that leaves CUs idle runs the previous epoch's
-    dev pass beside it from a second plane set (mfas_hip.hip, eval overlap).  Both only move WHEN things happen: statistics (train
-    and dev), parameters and both Adam moments must equal the run with both switched off, bit for bit — 24 / 22 candidates take the
-    deferred path (two units per workgroup, ~1,000 columns), N = 4,010 ends every epoch on a 10-row batch (rows past the batch are
-    copied from the zero line), 7 candidates leave ~40 CUs idle (overlap without deferral), E = 3 walks both plane sets."""
+@pytest.mark.parametrize("K,mixed,N", [(24, True, 4010), (22, False, 4000), (28, True, 4010)])
+def test_deferred_handoff_bit_identical(dev, K, mixed, N):
+    """Round 5 (late), opt-in form of the resident unit loop (MFAS_RES_DEFER=1, k_president<..., DEFER = true>): two-unit workgroups
+    finish a unit's arrival and the LDS-DMA copy of its batch after next under the OTHER unit's dy request (persist.hip.h).  Measured
+    slower than the default and therefore off, but kept buildable and correct: it only moves WHEN things happen, so statistics (train
+    and dev), parameters and both Adam moments must equal the default run bit for bit — 22 / 24 / 28 candidates (two units per
+    workgroup), N = 4,010 ends every epoch on a 10-row batch (rows past the batch are copied from the zero line), E = 3, and a second
+    train() call goes through the prologue's staging again."""
     import os
     from mfas_amd import FeatureTable, Hyper, Population
     hp = Hyper(R=16, C=60, B=20, bn=False, drpt=0.5, tap_bits=16)
@@ -925,9 +925,8 @@ def test_deferred_handoff_and_eval_overlap_bit_identical(dev, K, mixed, N):
     order = torch.stack([torch.randperm(N, generator=g, device=dev) for _ in range(E)]).to(torch.int32)
     out, sched = {}, {}
     for mode in ("off", "on"):
-        if mode == "off":
-            os.environ["MFAS_RES_NO_DEFER"] = "1"
-            os.environ["MFAS_NO_EVAL_OVERLAP"] = "1"
+        if mode == "on":
+            os.environ["MFAS_RES_DEFER"] = "1"
         try:
             pop = Population(hp, confs, dev, drop_seeds=list(range(50, 50 + K)))
             sched[mode] = pop.schedule()
@@ -940,18 +939,17 @@ def test_deferred_handoff_and_eval_overlap_bit_identical(dev, K, mixed, N):
             out[mode] += (stats2, [pop.get_params(k, 0).cpu().numpy() for k in range(K)])
             pop.close()
         finally:
-            os.environ.pop("MFAS_RES_NO_DEFER", None)
-            os.environ.pop("MFAS_NO_EVAL_OVERLAP", None)
+            os.environ.pop("MFAS_RES_DEFER", None)
     assert sched["on"]["persistent"] and sched["on"] == sched["off"]
-    if K >= 20:
-        assert sched["on"]["units_per_workgroup"] == 2
+    assert sched["on"]["units_per_workgroup"] == 2
     assert out["off"][0].tobytes() == out["on"][0].tobytes()
     assert out["off"][2].tobytes() == out["on"][2].tobytes()
     for k in range(K):
         for pl in range(3):
             assert np.array_equal(out["off"][1][k][pl], out["on"][1][k][pl]), (k, pl)
         assert np.array_equal(out["off"][3][k], out["on"][3][k]), k
-    assert (out["on"][0]["dev_corrects"][:, -1] > 0.05 * 1200).all()      # and it trains (chance = 1.7 %)
+    assert (out["on"][0]["train_loss_sum"][:, -1] < out["on"][0]["train_loss_sum"][:, 0]).all()      # and it trains
+    assert (out["on"][0]["dev_corrects"] > 0).all()                                                    # every epoch's dev pass ran
 
 
 @pytest.mark.parametrize("seed", range(8))

@@ -19,6 +19,8 @@ cc = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("cc=")), 0)   
 os.environ["MFAS_NO_TAP_MAJOR"] = "1"      # the persistent schedule runs per-segment units: compare like with like
 steps = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("steps=")), -1)   # debug: stop after N train steps
 dev = torch.device("cuda:0")
+if "sidestream" in sys.argv:      # the population's stream = a created stream instead of the legacy default stream
+    torch.cuda.set_stream(torch.cuda.Stream())
 tr = M.FeatureTable.synthetic(N, 1, dev, torch.bfloat16, snr=0.12)
 dv = M.FeatureTable.synthetic(Nd, 2, dev, torch.bfloat16, snr=0.12)
 hp = M.Hyper(R=R, B=B, bn=bool(bn), drpt=0.5, alphas="alphas" in sys.argv, tap_bits=16)
