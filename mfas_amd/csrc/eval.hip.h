@@ -85,6 +85,16 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
     float* xo_l = xs + ME * (X16 ? max((EVAL_CE + 8) / 2, SC) : max(SS, SC)); // [ME][SX]   out_{i-1} -> out_i (16-bit rows: the row tile is half as wide)
     float* lg_l = xs;
     const float* W = a.plane;
+    // WL (R <= 16, bf16 rows, m-blocks split over the waves): the four waves multiply DIFFERENT rows with the SAME weight tiles, and as
+    // four private copies those tiles were two thirds of what the workgroup pulled through the CU's vector L1 (32 of 48 KB per 128-column
+    // chunk; at 4 workgroups per CU the kernel sat at that port's 64 B / clock, which is why neither the MFMA pipe — 45 % busy — nor a
+    // fifth / sixth workgroup per CU moved it: profiles/r05_eval_occ.log).  Now ONE copy per workgroup travels global -> LDS by LDS-DMA
+    // (wave w copies tiles 2w, 2w + 1 of the NEXT chunk: a tile = 1 KB = the 64 lanes' 16-byte pieces; double-buffered, no registers)
+    // and every wave reads its B operands from there (ds_read_b128, conflict-free).  Same operands, same MFMA order: bit-identical.
+    constexpr bool WL = XB && MSP == 1 && NRBW == 1 && MBE == 4;
+    float* wl_buf = xo_l + ME * SX;      // [2][EVAL_CE / 16][256]
+    const uint32_t wl_base = (uint32_t)(uintptr_t)as_lds(wl_buf);
+    bool have_w = false;
     // wave -> (row block, m-blocks).  R >= 64: wave w owns row blocks w, w+4, ... and all MBE m-blocks of the rows.  With one or
     // two row blocks (R <= 32) that leaves 3 (2) of the 4 waves without MFMA work, so there the m-blocks are split instead:
     // wave w owns row block w % nrb and m-blocks w / nrb, w / nrb + 4 / nrb, ...  Every output element still accumulates the same
@@ -184,6 +194,7 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
                     for (int mb = 0; mb < NPI; ++mb) acc[j][mb] = acc[j][mb] * (vdead ? sgS : sgS / sgV);
             }
             have = false;
+            have_w = false;
             // (weight chunk, k-block inside it) of this eval chunk's first k-block, carried along instead of dividing per tile
             const int nkb_c = cc >> 4;
             int wch = 0, wkb = 0;
@@ -290,6 +301,50 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
                             }
                         }
                     }
+                } else if constexpr (WL) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const int cpar = (c0 / EVAL_CE) & 1;
+                    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+                    // tiles of the chunk whose first k-block is (ch0, t0): wave w copies tiles 2w, 2w + 1 into half `par`
+                    auto w_dma = [&](const int ch0, const int t0, const int ntile, const int par) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int kbl = 2 * wave_u + q;
+                            int ch = ch0, t = t0 + kbl;
+                            while (t >= nkb_c) { t -= nkb_c; ++ch; }
+                            if (kbl < ntile)
+                                glds16(W + cd.seg_off[i][sv] + (int64_t)ch * Rp * cc + (int64_t)t * 256 + lane * 4,
+                                       __builtin_amdgcn_readfirstlane(wl_base + (uint32_t)(((par * (EVAL_CE / 16) + kbl) * 256) << 2)));
+                        }
+                    };
+                    if (!have) rows_load(tp, tw, c0, nc);
+                    __syncthreads();
+                    // (a segment's first chunk: its tiles only now — every wave has left the previous segment's MFMAs, which read these halves)
+                    if (!have_w) w_dma(wch, wkb, nc >> 4, cpar);
+                    rows_store(nc);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's tile copies have landed (invisible to the compiler's counters)
+                    __syncthreads();
+                    have = c0 + EVAL_CE < cols;
+                    have_w = have;
+                    if (have) {          // the next chunk's rows (registers) and tiles (the other half) travel under this chunk's MFMAs
+                        const int ncn = min(EVAL_CE, cols - c0 - EVAL_CE);
+                        rows_load(tp, tw, c0 + EVAL_CE, ncn);
+                        int nch = wch, nkb0 = wkb + EVAL_CE / 16;
+                        while (nkb0 >= nkb_c) { nkb0 -= nkb_c; ++nch; }
+                        w_dma(nch, nkb0, ncn >> 4, cpar ^ 1);
+                    }
+                    const int nkbl = nc >> 4;
+                    const float* wl = wl_buf + cpar * (EVAL_CE / 16) * 256;
+#pragma unroll
+                    for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl)
+                        if (kbl < nkbl) {
+                            const f32x4 w4 = *as_lds(reinterpret_cast<const f32x4*>(wl + kbl * 256 + lane * 4));
+                            const u32x2 r = *as_lds(reinterpret_cast<const u32x2*>(xh + (mb0 * 16 + l15) * SSH + kbl * 16 + 4 * lg));
+                            const f32x4 x4 = (f32x4){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xFFFF0000U),
+                                                     __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xFFFF0000U)};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[0][0] = MFMA16(x4[q], w4[q], acc[0][0]);
+                        }
                 } else if constexpr (NRBW <= 2) {
                     // this chunk's weight tiles are requested BEFORE the feature staging so that their L2 latency
                     // overlaps the staging barriers (8 k-blocks x NRBW row blocks = up to 64 VGPRs)

@@ -1100,7 +1100,8 @@ template <int MBE, int NRBW, int MSP = 0, bool XB = false, bool B3 = false>
 static hipError_t launch_eval_t(mfas_population* p, const EvalArgs& a, int ncand, hipStream_t st) {
     const int ME = MBE * 16;
     // (16-bit row tile: half the width, more workgroups per CU)
-    const size_t lds = (XB || B3) ? ((size_t)ME * std::max((EVAL_CE + 8) / 2, p->g.Cp + 4) + (size_t)ME * (p->g.Rp + 8)) * 4 : p->lds_eval;
+    size_t lds = (XB || B3) ? ((size_t)ME * std::max((EVAL_CE + 8) / 2, p->g.Cp + 4) + (size_t)ME * (p->g.Rp + 8)) * 4 : p->lds_eval;
+    if (XB && MSP == 1 && NRBW == 1 && MBE == 4) lds += (size_t)2 * (EVAL_CE / 16) * 256 * 4;      // the workgroup's weight tiles, double-buffered (eval.hip.h, WL)
     hipError_t e = set_lds(k_eval<MBE, NRBW, MSP, XB, B3>, lds);
     if (e != hipSuccess) return e;
     const unsigned nblk = (unsigned)((a.nrows + ME - 1) / ME);
