@@ -94,7 +94,6 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
     constexpr bool WL = XB && MSP == 1 && NRBW == 1 && MBE == 4;
     float* wl_buf = xo_l + ME * SX;      // [2][EVAL_CE / 16][256]
     const uint32_t wl_base = (uint32_t)(uintptr_t)as_lds(wl_buf);
-    bool have_w = false;
     // wave -> (row block, m-blocks).  R >= 64: wave w owns row blocks w, w+4, ... and all MBE m-blocks of the rows.  With one or
     // two row blocks (R <= 32) that leaves 3 (2) of the 4 waves without MFMA work, so there the m-blocks are split instead:
     // wave w owns row block w % nrb and m-blocks w / nrb, w / nrb + 4 / nrb, ...  Every output element still accumulates the same
@@ -194,7 +193,6 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
                     for (int mb = 0; mb < NPI; ++mb) acc[j][mb] = acc[j][mb] * (vdead ? sgS : sgS / sgV);
             }
             have = false;
-            have_w = false;
             // (weight chunk, k-block inside it) of this eval chunk's first k-block, carried along instead of dividing per tile
             const int nkb_c = cc >> 4;
             int wch = 0, wkb = 0;
@@ -235,6 +233,89 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
                         }
                 }
             }
+            if constexpr (WL) {
+                // ---- WL segment walk: the table rows of THREE chunks in flight (three register sets, used round robin: a set is refilled
+                // with chunk c + 3 as soon as chunk c has gone to LDS), the weight tiles of the next chunk by LDS-DMA into the other half.
+                // With one chunk in flight (the general walk below) every chunk waited ~2 us for its rows: the pass was latency-bound at
+                // 4.5 us per chunk whatever the occupancy (profiles/r05_eval_occ.log).
+                // The row requests are UNCONDITIONAL (rows past the table clamp to its last row and are zeroed when stored): a wave then
+                // issues exactly MBE of them per chunk, which is what lets `s_waitcnt vmcnt(MBE)` wait for the tile copies — invisible to
+                // the compiler — without waiting for the youngest row set behind them.
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+                const int nchunks = (cols + EVAL_CE - 1) / EVAL_CE;
+                auto wl_rows_load = [&](uint4 (&r)[MBE], const int c) {
+                    const int cbase = c * EVAL_CE, ncc = min(EVAL_CE, cols - cbase), vpr = ncc >> 3;
+#pragma unroll
+                    for (int u = 0; u < MBE; ++u) {
+                        const int e = tid + u * 256;
+                        int b, cc8;
+                        if (vpr == 16) { b = e >> 4; cc8 = (e & 15) << 3; }
+                        else { b = e / vpr; cc8 = (e - b * vpr) << 3; }
+                        const int bc = min(b, nvalid - 1);
+                        r[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(tp) + (brow + bc) * tw + cbase + cc8);
+                    }
+                };
+                auto wl_rows_store = [&](const uint4 (&r)[MBE], const int c) {
+                    const int ncc = min(EVAL_CE, cols - c * EVAL_CE), vpr = ncc >> 3;
+#pragma unroll
+                    for (int u = 0; u < MBE; ++u) {
+                        const int e = tid + u * 256;
+                        int b, cc8;
+                        if (vpr == 16) { b = e >> 4; cc8 = (e & 15) << 3; }
+                        else { b = e / vpr; cc8 = (e - b * vpr) << 3; }
+                        if (b < ME) {
+                            const bool live = b < nvalid;
+                            *as_lds(reinterpret_cast<u32x4*>(xh + b * SSH + cc8)) = live ? (u32x4){r[u].x, r[u].y, r[u].z, r[u].w} : (u32x4){0u, 0u, 0u, 0u};
+                        }
+                    }
+                };
+                // tiles of chunk c: wave w copies tiles 2w, 2w + 1 into half c & 1
+                auto wl_tiles = [&](const int c) {
+                    const int ntile = min(EVAL_CE, cols - c * EVAL_CE) >> 4;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int kbl = 2 * wave_u + q;
+                        const int kb = c * (EVAL_CE / 16) + kbl;            // k-block inside the segment
+                        const int ch = kb / nkb_c, t = kb - ch * nkb_c;
+                        if (kbl < ntile)
+                            glds16(wseg + (int64_t)ch * Rp * cc + (int64_t)t * 256 + lane * 4,
+                                   __builtin_amdgcn_readfirstlane(wl_base + (uint32_t)((((c & 1) * (EVAL_CE / 16) + kbl) * 256) << 2)));
+                    }
+                };
+                auto wl_chunk = [&](uint4 (&r)[MBE], const int c) {
+                    __syncthreads();              // every wave has left the MFMAs of chunk c - 1 (and, at c = 0, of the previous segment)
+                    if (c == 0) wl_tiles(0);      // (a segment's first chunk: its tiles only now — the halves were still being read)
+                    wl_rows_store(r, c);
+                    // this wave's copies of chunk c's tiles have landed; only the youngest row set (chunk c + 2, requested behind them) may
+                    // still be in flight — and at c = 0 the tiles are the youngest
+                    if (c > 0 && c + 2 < nchunks) __builtin_amdgcn_s_waitcnt(0x0F70 | MBE); else __builtin_amdgcn_s_waitcnt(0x0F70);
+                    __syncthreads();
+                    if (c + 1 < nchunks) wl_tiles(c + 1);
+                    if (c + 3 < nchunks) wl_rows_load(r, c + 3);
+                    const int nkbl = min(EVAL_CE, cols - c * EVAL_CE) >> 4;
+                    const float* wl = wl_buf + (c & 1) * (EVAL_CE / 16) * 256;
+#pragma unroll
+                    for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl)
+                        if (kbl < nkbl) {
+                            const f32x4 w4 = *as_lds(reinterpret_cast<const f32x4*>(wl + kbl * 256 + lane * 4));
+                            const u32x2 rr = *as_lds(reinterpret_cast<const u32x2*>(xh + (mb0 * 16 + l15) * SSH + kbl * 16 + 4 * lg));
+                            const f32x4 x4 = (f32x4){__uint_as_float(rr[0] << 16), __uint_as_float(rr[0] & 0xFFFF0000U),
+                                                     __uint_as_float(rr[1] << 16), __uint_as_float(rr[1] & 0xFFFF0000U)};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[0][0] = MFMA16(x4[q], w4[q], acc[0][0]);
+                        }
+                };
+                uint4 rA[MBE], rB[MBE], rC[MBE];
+                if (0 < nchunks) wl_rows_load(rA, 0);
+                if (1 < nchunks) wl_rows_load(rB, 1);
+                if (2 < nchunks) wl_rows_load(rC, 2);
+                for (int c = 0; c < nchunks; c += 3) {
+                    wl_chunk(rA, c);
+                    if (c + 1 < nchunks) wl_chunk(rB, c + 1);
+                    if (c + 2 < nchunks) wl_chunk(rC, c + 2);
+                }
+            } else
             for (int c0 = 0; c0 < cols; c0 += EVAL_CE, wkb += EVAL_CE / 16) {
                 while (wkb >= nkb_c) { wkb -= nkb_c; ++wch; }
                 const int nc = min(EVAL_CE, cols - c0);
@@ -301,50 +382,6 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
                             }
                         }
                     }
-                } else if constexpr (WL) {
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    const int cpar = (c0 / EVAL_CE) & 1;
-                    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-                    // tiles of the chunk whose first k-block is (ch0, t0): wave w copies tiles 2w, 2w + 1 into half `par`
-                    auto w_dma = [&](const int ch0, const int t0, const int ntile, const int par) {
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int kbl = 2 * wave_u + q;
-                            int ch = ch0, t = t0 + kbl;
-                            while (t >= nkb_c) { t -= nkb_c; ++ch; }
-                            if (kbl < ntile)
-                                glds16(W + cd.seg_off[i][sv] + (int64_t)ch * Rp * cc + (int64_t)t * 256 + lane * 4,
-                                       __builtin_amdgcn_readfirstlane(wl_base + (uint32_t)(((par * (EVAL_CE / 16) + kbl) * 256) << 2)));
-                        }
-                    };
-                    if (!have) rows_load(tp, tw, c0, nc);
-                    __syncthreads();
-                    // (a segment's first chunk: its tiles only now — every wave has left the previous segment's MFMAs, which read these halves)
-                    if (!have_w) w_dma(wch, wkb, nc >> 4, cpar);
-                    rows_store(nc);
-                    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's tile copies have landed (invisible to the compiler's counters)
-                    __syncthreads();
-                    have = c0 + EVAL_CE < cols;
-                    have_w = have;
-                    if (have) {          // the next chunk's rows (registers) and tiles (the other half) travel under this chunk's MFMAs
-                        const int ncn = min(EVAL_CE, cols - c0 - EVAL_CE);
-                        rows_load(tp, tw, c0 + EVAL_CE, ncn);
-                        int nch = wch, nkb0 = wkb + EVAL_CE / 16;
-                        while (nkb0 >= nkb_c) { nkb0 -= nkb_c; ++nch; }
-                        w_dma(nch, nkb0, ncn >> 4, cpar ^ 1);
-                    }
-                    const int nkbl = nc >> 4;
-                    const float* wl = wl_buf + cpar * (EVAL_CE / 16) * 256;
-#pragma unroll
-                    for (int kbl = 0; kbl < EVAL_CE / 16; ++kbl)
-                        if (kbl < nkbl) {
-                            const f32x4 w4 = *as_lds(reinterpret_cast<const f32x4*>(wl + kbl * 256 + lane * 4));
-                            const u32x2 r = *as_lds(reinterpret_cast<const u32x2*>(xh + (mb0 * 16 + l15) * SSH + kbl * 16 + 4 * lg));
-                            const f32x4 x4 = (f32x4){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xFFFF0000U),
-                                                     __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xFFFF0000U)};
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[0][0] = MFMA16(x4[q], w4[q], acc[0][0]);
-                        }
                 } else if constexpr (NRBW <= 2) {
                     // this chunk's weight tiles are requested BEFORE the feature staging so that their L2 latency
                     // overlaps the staging barriers (8 k-blocks x NRBW row blocks = up to 64 VGPRs)
