@@ -175,7 +175,8 @@ int mfas_population_set_profiling(mfas_population* pop, int32_t on);
 /* (new) The step schedule this population was laid out for, so that a measurement can name the kernel it
  * timed: info[0] = 1 persistent step loop (k_president: resident units + resident chain, one launch per epoch) / 0 launch per phase (k_step / k_chain);
  * info[1] = feature units resident in registers; info[2] = their workgroups; info[3] = units per resident workgroup;
- * info[4] = 1 when the resident lean chain owns OUT/HEAD; info[5] = 1 lean chain (R <= 16); info[6] = candidate groups of the
+ * info[4] = 1 when the resident lean chain owns OUT/HEAD; info[5] = bit 0: lean chain (R <= 16), bits 8..15: compute units one
+ * candidate's general chain runs on in the same-group launch (round 6, chain_split; 1 otherwise); info[6] = candidate groups of the
  * launch-per-phase schedule (2 = fused A/B launches, 1 = chain and sweep back to back, -1 = one launch per step holding the chain
  * AND the sweep of the same candidates, released cell by cell through per-cell flags); info[7] = candidates. */
 int mfas_population_schedule(const mfas_population* pop, int32_t info[8]);
@@ -206,6 +207,13 @@ int mfas_global_pool(const void* x, int32_t dtype, int64_t rows, int64_t inner, 
  * (/root/reference/models/search/ntu_searchable.py:23-102) with these.  Always return MFAS_OK. */
 int mfas_range_push(const char* name);
 int mfas_range_pop(void);
+
+/* (new, round 6) The library's environment switches (A/B and debugging aids; INTEGRATION.md lists them) as parsed from the CURRENT
+ * environment: "name=value name=value ..." in declaration order, NUL-terminated, truncated to `cap`.  The library parses them in ONE
+ * place, when a population is created or planned (the reference has no counterpart: its knobs are the argparse flags of
+ * /root/reference/main_searchable_ntu.py:16-63, mirrored by mfas_hyper); a population keeps the set it was created under.  An empty
+ * environment yields the defaults the test suites run ("hooks=0": the product library parses no test hook). */
+int mfas_tuning_describe(char* buf, int32_t cap);
 
 /* snapshot_best bookkeeping: a dev metric must EXCEED `threshold` to replace the kept parameters (best_acc = 0,
  * train_searchable/ntu.py:18; best_f1 = init_f1, train_searchable/mmimdb.py:18).  Default 0.  If no epoch exceeds it the

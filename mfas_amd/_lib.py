@@ -73,6 +73,7 @@ def lib():
     L.mfas_global_pool.argtypes = [P, C.c_int32, C.c_int64, C.c_int64, P, C.c_int32, P]
     L.mfas_range_push.argtypes = [C.c_char_p]
     L.mfas_population_init_torch_streams.argtypes = [P, P, P, C.c_double, C.c_double]
+    L.mfas_tuning_describe.argtypes = [C.c_char_p, C.c_int32]
     _lib = L
     return L
 
@@ -82,7 +83,14 @@ EXPORTS = ["mfas_last_error", "mfas_version", "mfas_population_create", "mfas_po
            "mfas_population_init", "mfas_population_train", "mfas_population_forward",
            "mfas_population_sweep_profile", "mfas_population_set_profiling", "mfas_population_set_pos_weight", "mfas_global_pool", "mfas_stream_probe", "mfas_source_digest",
            "mfas_population_set_best_threshold", "mfas_population_forward_train", "mfas_population_schedule",
-           "mfas_population_plan", "mfas_population_backward", "mfas_range_push", "mfas_range_pop", "mfas_population_init_torch_streams"]
+           "mfas_population_plan", "mfas_population_backward", "mfas_range_push", "mfas_range_pop", "mfas_population_init_torch_streams", "mfas_tuning_describe"]
+
+
+def tuning() -> dict:
+    """The engine's environment switches as the library parses them right now (mfas_tuning_describe): {name: value string}."""
+    buf = C.create_string_buffer(2048)
+    check(lib().mfas_tuning_describe(buf, 2048))
+    return dict(kv.split("=", 1) for kv in buf.value.decode().split())
 
 
 import contextlib

@@ -31,6 +31,10 @@ struct ChainArgs {
                                  // after the head and stop — batch-statistics BN (running stats updated), dropout stream of `gstep`
     const float* dlogits_in;     // BACKWARD OF AN EXTERNAL LOSS (mfas_population_backward): dL/dlogits (nvalid x C) given by the caller
                                  // takes the place of the softmax / BCE gradient; no statistics are accumulated
+    // chain_split (one candidate's chain on nsplit CUs): exchange area [candidate][parity][slot][row block][256], parity of this launch,
+    // candidates of this launch (chain block b = part * ceil8(ncand) + candidate: the parts of a candidate share b % 8 = their XCD)
+    float* xch;
+    int32_t xpar, nsplit, ncand, _pads;
 };
 
 // what changes from one train step to the next (k_step / k_chain take it from the launch arguments, the persistent loop
@@ -1794,4 +1798,462 @@ __device__ __forceinline__ void lean_res_store(const ChainArgs& a, const int bid
         st.train_corr += rs.corr;
         if (rs.bad) atomicMax(&a.status[cd.gidx], 1);   // (never downgrades a timeout mark 2 set by a sweep unit of the same launch)
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// chain_split<NS> — the general chain of ONE candidate on NS compute units (round 6; R = 113 .. 128: eight row blocks, B <= 16: one
+// batch tile, C <= 64, no alphas).  /root/reference/models/search/ntu_searchable.py:228-242 is serial in the cells, and at R = 128 a
+// cell is 256 f32 MFMAs + ~300 VALU instructions per row-block wave: on ONE CU (chain_body) the eight row-block waves share four
+// SIMDs and sit in the same phase between barriers — 6-9 k shader cycles per cell, 84 k per step (profiles/r05_chain_wide_r128.log).
+// A cell is column-separable: Linear, activation, BatchNorm batch statistics (per column over the batch rows one wave holds),
+// dropout and their backward need nothing from other columns, so workgroup `part` of the candidate owns row blocks
+// part * 8 / NS .. (one wave per row block, each on its own SIMD), and only the 16 x 128 block a cell hands to the next product
+// (out_i forward, dy_i backward) crosses CUs — seven exchanges per step:
+//   * exchange area xch[parity][slot][row block][lane][4] (global, per candidate) in the MFMA D image: a producer's lane stores its
+//     four values as ONE write-through 16-byte piece; every consumer thread polls ITS piece with sc1 loads until it no longer holds
+//     the sentinel (all-ones words: not a value the arithmetic produces), then drops it into the LDS operand buffer.  No flags, no
+//     store drains: a hand-off is one store -> load round trip.  Parities alternate per chain launch; a launch resets the pieces it
+//     owns in the OTHER parity (the kernel boundary orders the reset before the next launch's data);
+//   * the head (16 x 128 x 64) and the softmax are REPLICATED on every part (waves 4 .. 4 + ncb - 1, tiles held in registers since
+//     entry): no exchange for logits / dlogits; statistics, dlogits, the head bias belong to part 0;
+//   * the weight tiles of the next product are staged global -> registers -> LDS by all eight waves while the main waves compute
+//     (the 128-register build of the same-group launch has no room for chain_body's register prefetch);
+//   * per-cell "dy is out" flags become arrival COUNTERS (every part adds 1 behind its exchange poll — whose returned load implies
+//     the wave's earlier stores were acknowledged — so no extra drain; target = NS * (step + 1)).
+// The arithmetic per row block is chain_body's (same products in the same even / odd MFMA chains, same reductions): every schedule
+// stays bit-identical (tests/test_gpu_parity.py::test_same_group_launch_fuzz_bit_identical, ::test_full_size_properties,
+// ::test_chain_split_bit_identical).
+// ------------------------------------------------------------------------------------------------
+#define XCH_SLOTS 7
+#define XCH_SENT 0xFFFFFFFFu
+#define XCH_SPIN_LIMIT (1u << 21)
+#define XCH_CAND_FLOATS (2 * XCH_SLOTS * 8 * 256)
+
+__device__ __forceinline__ f32x4 xch_wait(const float* base, const int64_t idx, int32_t* status, const int gidx) {
+    uint32_t spins = 0;
+    for (;;) {
+        const f32x4 v = ldc4<true>(base, idx);
+        const u32x4 u = __builtin_bit_cast(u32x4, v);
+        if (u[0] != XCH_SENT && u[1] != XCH_SENT && u[2] != XCH_SENT && u[3] != XCH_SENT) return v;
+        if (++spins > XCH_SPIN_LIMIT) { atomicMax(&status[gidx], 2); return v; }   // (the host reports the lost dependency)
+        asm volatile("" ::: "memory");          // the load is re-issued every turn
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// LDS floats of chain_split<NS> (host: launch size)
+template <int NS> __host__ __device__ constexpr int chain_split_vec_floats(int Cp) { return 3 * (MFAS_MAX_CELLS * 5 * (8 / NS) * 16 + Cp); }
+template <int NS> __host__ __device__ constexpr size_t chain_split_lds_floats(int Rp, int Cp) {
+    return (size_t)2 * 16 * (Rp + 4) + (size_t)16 * (Cp + 4) + (size_t)MFAS_MAX_CELLS * Rp + 48 + 16 +
+           (size_t)MFAS_MAX_CELLS * (8 / NS) * 256 + (size_t)chain_split_vec_floats<NS>(Cp) + (size_t)2 * (8 / NS) * 8 * 256;
+}
+
+template <int NS>
+__device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep& cs, const int bid, const int part, float* lds) {
+#ifdef MFAS_CHAIN_TIMING
+    const unsigned long long ct0 = __builtin_readcyclecounter();
+#define CS_STAMP(slot) do { if (threadIdx.x == 0 && bid == 0 && part == 0 && cs.gstep == 3) a.status[64 + (slot)] = (int32_t)(__builtin_readcyclecounter() - ct0); } while (0)
+#else
+#define CS_STAMP(slot) do { } while (0)
+#endif
+    constexpr int NRO = 8 / NS;                  // row blocks (= main waves) of this part
+    constexpr int Bp = 16, MB = 1;
+    const CandDev& cd = a.cands[bid];
+    const Geo& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int Rp = g.Rp, nrb = 8, Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = cd.L;
+    const int SX = Rp + 4, SC = Cp + 4;
+    constexpr int LPR = 16;
+    float* xo_l = lds;                                   // [2][16][SX] out_i ping-pong; backward: dy_i
+    float* dy_l = xo_l;
+    float* lg_l = xo_l + 2 * Bp * SX;                    // [16][SC]
+    float* rstd_l = lg_l + Bp * SC;                      // [L][Rp]
+    float* red_l = rstd_l + MFAS_MAX_CELLS * Rp;         // [48]
+    int* lab_l = reinterpret_cast<int*>(red_l + 48);     // [16]
+    float* yf_l = reinterpret_cast<float*>(lab_l + 16);  // [L][NRO][256]  this part's reduced feature sums
+    constexpr int NCOL = NRO * 16;                       // this part's columns
+    float* vl = yf_l + MFAS_MAX_CELLS * NRO * 256;       // [3 planes][L][5 kinds][NCOL] | [3][Cp] head bias
+    const int nvec = MFAS_MAX_CELLS * 5 * NCOL;
+    const int vplane = nvec + Cp;
+    float* tb = vl + 3 * vplane;                         // [2][NRO * 8][256] weight tiles of the current / the next product
+    const int64_t sav_plane = (int64_t)MFAS_MAX_CELLS * nrb * MB * 256;
+
+    float* W = a.plane;
+    float* Mv = a.plane + a.plane_stride;
+    float* Vv = Mv + a.plane_stride;
+    float* sb = a.stepbuf + cd.step_off;
+    float* sav = sb + g.sb_sav;
+    const int64_t cvec_off = cd.vec_off;
+    int nlbits = 0;
+#pragma unroll
+    for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
+    const int cgidx = cd.gidx;
+    const int nvalid = cs.nvalid;
+    const float nf = (float)nvalid;
+    const AdamC ac = adam_consts(a.ac, cs.ss, cs.bc2s);
+    const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(cs.gstep + 1));
+    const int64_t sbo = cd.step_off;
+    const int rb0 = part * NRO;                          // first own row block
+    const bool main_w = wave < NRO;
+    const int rb = rb0 + (main_w ? wave : 0);            // a main wave's row block
+    // exchange area of this candidate: this launch's parity / the other one
+    const int64_t xq = (int64_t)cgidx * XCH_CAND_FLOATS;
+    const int64_t xcur_par = xq + (int64_t)a.xpar * (XCH_SLOTS * 8 * 256);
+    const int64_t xoth_par = xq + (int64_t)(a.xpar ^ 1) * (XCH_SLOTS * 8 * 256);
+
+    // ---- entry: everything that does not depend on the step's data is requested first
+    if (tid < Bp) {
+        int lab = 0;
+        if (tid < nvalid) {
+            const int32_t* ord = cand_order(a.order, g, cd.gidx);
+            const int64_t row = ord ? (int64_t)ord[cs.pos_t + tid] : (int64_t)(cs.base_t + tid);
+            lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;
+        }
+        lab_l[tid] = lab;
+    }
+    // the head's tiles: class block (wave - 4) of every part, in registers until the head product
+    f32x4 hw[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) hw[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool head_w = wave >= 4 && wave - 4 < ncb;
+    if (head_w) issue_tiles<false>(hw, W, cd.head_off + (int64_t)(wave - 4) * nrb * 256, nrb, lane);
+    // tile staging: the NRO * 8 tiles of a product (own row blocks x k-blocks; fewer k-blocks for the head's transpose), wave w takes
+    // tiles w, w + 8, ...: tile e = (own row block e / nk, k-block e % nk), source = base + (rb0 + e / nk) * nk * 256 + (e % nk) * 256
+    f32x4 stg[NRO];
+    auto stage_issue = [&](const float* base, const int64_t off0, const int nk) {
+#pragma unroll
+        for (int u = 0; u < NRO; ++u) {
+            const int e = wave + 8 * u;
+            const int j = e / nk, k = e - j * nk;
+            if (e < NRO * nk) stg[u] = *reinterpret_cast<const f32x4*>(base + off0 + ((int64_t)(rb0 + j) * nk + k) * 256 + lane * 4);
+        }
+    };
+    auto stage_store = [&](float* dst, const int nk) {
+#pragma unroll
+        for (int u = 0; u < NRO; ++u) {
+            const int e = wave + 8 * u;
+            const int j = e / nk, k = e - j * nk;
+            if (e < NRO * nk) *as_lds(reinterpret_cast<f32x4*>(dst + (j * 8 + k) * 256 + lane * 4)) = stg[u];
+        }
+    };
+    if (L > 1) stage_issue(W, cd.seg_off[1][2], nrb);        // P_1 -> tb[1]
+    // this part's pieces of the OTHER parity back to "not written" (read by nobody in this launch)
+    for (int e = tid; e < XCH_SLOTS * NRO * 64; e += CHAIN_THREADS) {
+        const int s = e / (NRO * 64), r = e - s * (NRO * 64);
+        stc4<true>(a.xch, xoth_par + ((int64_t)s * 8 + rb0) * 256 + r * 4, __builtin_bit_cast(f32x4, (u32x4){XCH_SENT, XCH_SENT, XCH_SENT, XCH_SENT}));
+    }
+    // vector block: own columns of every cell (W, m, v), head bias
+    for (int e = tid; e < nvec; e += CHAIN_THREADS) {
+        const int i = e / (5 * NCOL), r5 = e - i * (5 * NCOL), kind = r5 / NCOL, c = r5 - kind * NCOL;
+        const int64_t o = cvec_off + (int64_t)i * g.vec_cell_stride + kind * Rp + rb0 * 16 + c;
+        vl[e] = W[o]; vl[vplane + e] = Mv[o]; vl[2 * vplane + e] = Vv[o];
+    }
+    for (int e = tid; e < Cp; e += CHAIN_THREADS) {
+        const int64_t o = cvec_off + g.vec_head + e;
+        vl[nvec + e] = W[o]; vl[vplane + nvec + e] = Mv[o]; vl[2 * vplane + nvec + e] = Vv[o];
+    }
+    // reduced feature sums of the own row blocks: [L][NRO][64 lanes] float4 items
+    {
+        const int n = L * NRO * 64;
+        if (a.yf_reduced) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(sb + g.sb_yf);
+            for (int e = tid; e < n; e += CHAIN_THREADS) {
+                const int i = e / (NRO * 64), r = e - i * (NRO * 64);
+                *as_lds(reinterpret_cast<f32x4*>(yf_l + (int64_t)e * 4)) = src[(i * nrb + rb0) * 64 + r];
+            }
+        } else {
+            for (int e = tid; e < n; e += CHAIN_THREADS) {
+                const int i = e / (NRO * 64), r = e - i * (NRO * 64);
+                const int ns = cd.nch_s[i], nch = ns + cd.nch_v[i];
+                const int64_t pbase = sbo + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8) + ((int64_t)rb0 * 64 + r) * 4;
+                f32x4 accS = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
+                constexpr int PB = 8;
+                for (int ch0 = 0; ch0 < nch; ch0 += PB) {
+                    f32x4 p8[PB];
+#pragma unroll
+                    for (int u = 0; u < PB; ++u)
+                        if (ch0 + u < nch) p8[u] = ldc4<true>(a.stepbuf, pbase + (((int64_t)(ch0 + u) * nrb * MB) << 8));
+#pragma unroll
+                    for (int u = 0; u < PB; ++u)
+                        if (ch0 + u < nch) { if (ch0 + u < ns) accS += p8[u]; else accV += p8[u]; }
+                }
+                *as_lds(reinterpret_cast<f32x4*>(yf_l + (int64_t)e * 4)) = accS + accV;
+            }
+        }
+    }
+    if (L > 1) stage_store(tb + 1 * (NRO * 8 * 256), nrb);
+    CS_STAMP(22);
+    __syncthreads();
+    CS_STAMP(0);
+
+    // piece of another part -> the LDS operand buffer (row-major [b][SX]); one 16-byte piece per thread: wave w takes row block
+    // (rb0 + NRO + w) mod 8 — the foreign row blocks come first, so the MAIN waves poll too (their poll's returned load is also
+    // what says their own earlier stores were acknowledged), and the last NRO waves would map to own row blocks: nothing to fetch
+    auto fetch_others = [&](const int slot, float* dst) {
+        const int prb = (rb0 + NRO + wave) & 7;
+        if (wave < 8 - NRO) {
+            const f32x4 v = xch_wait(a.xch, xcur_par + ((int64_t)slot * 8 + prb) * 256 + lane * 4, a.status, cgidx);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[(4 * lg + q) * SX + prb * 16 + l15] = v[q];
+        }
+    };
+    // acc += X[16][16 nk] . tiles (LDS, [nk][256]): chain_body's even / odd chains
+    auto mma_lds = [&](f32x4& acc, const float* X, const int sx, const float* tiles, const int nk) {
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nk) {
+                const f32x4 w4 = *as_lds(reinterpret_cast<const f32x4*>(tiles + u * 256 + lane * 4));
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(X + l15 * sx + u * 16 + 4 * lg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (u & 1) acc2 = MFMA16(x4[q], w4[q], acc2);
+                    else acc = MFMA16(x4[q], w4[q], acc);
+                }
+            }
+        acc += acc2;
+    };
+    const int vcol = (main_w ? wave : 0) * 16 + l15;     // column inside the part's vector block
+
+    // ------------------------------------------------------------------ forward chain
+    for (int i = 0; i < L; ++i) {
+        CS_STAMP(1 + i);
+        // next product's tiles: P_{i+1} -> tb[(i+1) & 1]; after the last cell the first backward product (head^T, ncb k-blocks) -> tb[L & 1]
+        const bool st_fw = i + 1 < L && i >= 1;          // (P_1 was staged at entry)
+        const bool st_hd = i + 1 == L;
+        if (st_fw) stage_issue(W, cd.seg_off[i + 1][2], nrb);
+        else if (st_hd) stage_issue(a.wt, cd.headT_off, ncb);
+        const float* xprev = xo_l + ((i + 1) & 1) * Bp * SX;
+        float* xcur = xo_l + (i & 1) * Bp * SX;
+        if (main_w) {
+            const int nl = (nlbits >> (2 * i)) & 3;
+            const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
+            const float* vc = vl + i * 5 * NCOL;
+            const int r = rb * 16 + l15;
+            const bool colok = r < R;
+            const float bias = vc[VEC_B * NCOL + vcol];
+            float gam = 1.f, bet = 0.f;
+            if (g.bn) { gam = vc[VEC_G * NCOL + vcol]; bet = vc[VEC_BE * NCOL + vcol]; }
+            f32x4 acc = *as_lds(reinterpret_cast<const f32x4*>(yf_l + ((i * NRO + wave) << 8) + lane * 4));
+            if (i > 0) mma_lds(acc, xprev, SX, tb + (i & 1) * (NRO * 8 * 256) + wave * 8 * 256, nrb);
+            if (i == 1) CS_STAMP(13);
+            float av[4];
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = 4 * lg + q;
+                const float v = act_fwd(acc[q] + bias, nl);
+                av[q] = v;
+                if (b < nvalid) s += v;
+            }
+            float zv[4];
+            if (g.bn) {
+                const float mu = colsum(s) / nf;
+                float s2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = 4 * lg + q;
+                    const float dlt = av[q] - mu;
+                    if (b < nvalid) s2 += dlt * dlt;
+                }
+                const float var = colsum(s2) / nf;
+                const float rstd = 1.0f / sqrtf(var + g.bn_eps);
+                f32x4 xh4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xh = (av[q] - mu) * rstd;
+                    xh4[q] = xh;
+                    zv[q] = xh * gam + bet;
+                }
+                if (lg == 0) {
+                    rstd_l[i * Rp + r] = rstd;
+                    if (colok) {
+                        float rm = vc[VEC_RM * NCOL + vcol], rv = vc[VEC_RV * NCOL + vcol];
+                        const float unb = var * (nf / (nf - 1.0f));
+                        rm += g.bn_mom * (mu - rm);
+                        rv += g.bn_mom * (unb - rv);
+                        W[vb + VEC_RM * Rp + r] = rm;
+                        W[vb + VEC_RV * Rp + r] = rv;
+                    }
+                }
+                *reinterpret_cast<f32x4*>(sav + sav_plane + ((((int64_t)i * nrb + rb) * MB) << 8) + lane * 4) = xh4;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zv[q] = av[q];
+            }
+            *reinterpret_cast<f32x4*>(sav + ((((int64_t)i * nrb + rb) * MB) << 8) + lane * 4) = (f32x4){av[0], av[1], av[2], av[3]};
+            float* xo_g = sb + g.sb_xo + (int64_t)i * Bp * Rp;
+            f32x4 o4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = 4 * lg + q;
+                float o = zv[q];
+                if (g.use_drop) o = drop_keep(h0, i, (uint32_t)(b * R + r), g.drop_thr) ? o * g.drop_scale : 0.0f;
+                if (!(colok && b < nvalid)) o = 0.0f;
+                o4[q] = o;
+            }
+            stc4<true>(a.xch, xcur_par + ((int64_t)i * 8 + rb) * 256 + lane * 4, o4);     // slot i: out_i, first thing out
+            if (i == 1) CS_STAMP(14);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = 4 * lg + q;
+                xcur[b * SX + r] = o4[q];
+                stc1<true>(xo_g + b * Rp + r, o4[q]);
+            }
+        }
+        if (st_fw) stage_store(tb + ((i + 1) & 1) * (NRO * 8 * 256), nrb);
+        else if (st_hd) stage_store(tb + (L & 1) * (NRO * 8 * 256), ncb);
+        if (i == 1) CS_STAMP(15);
+        fetch_others(i, xcur);
+        if (i == 1) CS_STAMP(16);
+        lds_barrier();
+    }
+
+    CS_STAMP(5);
+    // ------------------------------------------------------------------ head (replicated) + loss
+    if (head_w) {
+        const float* xl = xo_l + ((L - 1) & 1) * Bp * SX;
+        f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+        const int c = (wave - 4) * 16 + l15;
+        const float bias = vl[nvec + c];
+        mma_tiles<1>(acc, xl, SX, hw, nrb, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lg_l[(4 * lg + q) * SC + c] = acc[0][q] + bias;
+    }
+    lds_barrier();
+    CS_STAMP(6);
+    if (g.loss_mode == 1) {
+        if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
+    } else if (tid < LPR * Bp) {
+        softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
+    }
+    CS_STAMP(21);
+    lds_barrier();
+    if (part == 0) {
+        if (tid == CHAIN_THREADS - 64 && a.stats) {
+            float ls = 0.f, ncor = 0.f;
+            for (int b = 0; b < Bp; ++b) { ls += red_l[b]; ncor += red_l[Bp + b]; }
+            DevStats& st = a.stats[(int64_t)cgidx * a.E + cs.epoch];
+            st.train_loss += (double)ls;
+            st.train_corr += (long long)ncor;
+            if (!(fabsf(ls) <= 3.0e38f)) atomicMax(&a.status[cgidx], 1);
+        }
+        float* dlg = sb + g.sb_dlog;
+        for (int e = tid; e < Bp * Cp; e += CHAIN_THREADS) {
+            const int b = e / Cp, c = e - b * Cp;
+            stc1<true>(dlg + e, lg_l[b * SC + c]);
+        }
+        const int hc = tid - (CHAIN_THREADS - 256);
+        if (hc >= 0 && hc < C) {
+            float gsum = 0.f;
+            for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + hc];
+            const int64_t o = cvec_off + g.vec_head + hc;
+            float w = vl[nvec + hc], m = vl[vplane + nvec + hc], v = vl[2 * vplane + nvec + hc];
+            adam1(w, m, v, gsum, ac);
+            W[o] = w; Mv[o] = m; Vv[o] = v;
+        }
+    }
+    CS_STAMP(7);
+
+    // ------------------------------------------------------------------ backward chain
+    for (int i = L - 1; i >= 0; --i) {
+        CS_STAMP(8 + (L - 1 - i));
+        const int j = L - 1 - i;                          // backward cell j reads tb[(L + j) & 1]
+        const bool st_bw = i >= 1;                        // next product: d out_{i-1} = dy_i . OUT_i (transposed tiles of cell i)
+        if (st_bw) stage_issue(a.wt, cd.outT_off[i], nrb);
+        const bool from_head = (i == L - 1);
+        const float* src = from_head ? lg_l : dy_l + ((i + 1) & 1) * Bp * SX;
+        const int sstride = from_head ? SC : SX;
+        const int nkk = from_head ? ncb : nrb;
+        float* dcur = dy_l + (i & 1) * Bp * SX;
+        if (main_w) {
+            const int nl = (nlbits >> (2 * i)) & 3;
+            const int64_t vb = cvec_off + (int64_t)i * g.vec_cell_stride;
+            const float* vc = vl + i * 5 * NCOL;
+            const int r = rb * 16 + l15;
+            const bool colok = r < R;
+            float gr = 0.f;
+            if (g.bn) gr = vc[VEC_G * NCOL + vcol] * rstd_l[i * Rp + r];
+            const int64_t ob = vb + VEC_B * Rp + r, og = vb + VEC_G * Rp + r, obe = vb + VEC_BE * Rp + r;
+            float pw[3] = {0.f, 0.f, 0.f}, pm[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f};
+            if (lg == 0 && colok) {
+                pw[0] = vc[VEC_B * NCOL + vcol]; pm[0] = vc[vplane + VEC_B * NCOL + vcol]; pv[0] = vc[2 * vplane + VEC_B * NCOL + vcol];
+                if (g.bn) {
+                    pw[1] = vc[VEC_G * NCOL + vcol]; pm[1] = vc[vplane + VEC_G * NCOL + vcol]; pv[1] = vc[2 * vplane + VEC_G * NCOL + vcol];
+                    pw[2] = vc[VEC_BE * NCOL + vcol]; pm[2] = vc[vplane + VEC_BE * NCOL + vcol]; pv[2] = vc[2 * vplane + VEC_BE * NCOL + vcol];
+                }
+            }
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(sav + ((((int64_t)i * nrb + rb) * MB) << 8) + lane * 4);
+            f32x4 xh4 = {0.f, 0.f, 0.f, 0.f};
+            if (g.bn) xh4 = *reinterpret_cast<const f32x4*>(sav + sav_plane + ((((int64_t)i * nrb + rb) * MB) << 8) + lane * 4);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_lds(acc, src, sstride, tb + ((L + j) & 1) * (NRO * 8 * 256) + wave * 8 * 256, nkk);
+            if (i == 2) CS_STAMP(17);
+            float dz[4];
+            float sdz = 0.f, sdzx = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = 4 * lg + q;
+                float d = acc[q];
+                if (g.use_drop) d = drop_keep(h0, i, (uint32_t)(b * R + r), g.drop_thr) ? d * g.drop_scale : 0.0f;
+                if (!(b < nvalid)) d = 0.f;
+                dz[q] = d;
+                sdz += d;
+                if (g.bn) sdzx += d * xh4[q];
+            }
+            float dgam = 0.f, dbet = 0.f;
+            if (g.bn) {
+                dbet = colsum(sdz);
+                dgam = colsum(sdzx);
+                const float k1 = dbet / nf, k2 = dgam / nf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = 4 * lg + q;
+                    const float da = gr * (dz[q] - k1 - xh4[q] * k2);
+                    dz[q] = b < nvalid ? da : 0.f;
+                }
+            }
+            float sdy = 0.f;
+            float* dy_g = sb + g.sb_dy + (int64_t)i * Bp * Rp;
+            f32x4 d4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float dy = act_bwd(a4[q], dz[q], nl);
+                if (!colok) dy = 0.f;
+                sdy += dy;
+                d4[q] = dy;
+            }
+            if (i >= 1) stc4<true>(a.xch, xcur_par + ((int64_t)(4 + j) * 8 + rb) * 256 + lane * 4, d4);    // slot 4 + j: dy_i
+            if (i == 2) CS_STAMP(18);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = 4 * lg + q;
+                dcur[b * SX + r] = d4[q];
+                stc1<true>(dy_g + b * Rp + r, d4[q]);
+            }
+            const float db = colsum(sdy);
+            if (lg == 0 && colok) {
+                adam1(pw[0], pm[0], pv[0], db, ac);
+                W[ob] = pw[0]; Mv[ob] = pm[0]; Vv[ob] = pv[0];
+                if (g.bn) {
+                    adam1(pw[1], pm[1], pv[1], dgam, ac);
+                    W[og] = pw[1]; Mv[og] = pm[1]; Vv[og] = pv[1];
+                    adam1(pw[2], pm[2], pv[2], dbet, ac);
+                    W[obe] = pw[2]; Mv[obe] = pm[2]; Vv[obe] = pv[2];
+                }
+            }
+        }
+        if (st_bw) stage_store(tb + ((L + j + 1) & 1) * (NRO * 8 * 256), nrb);
+        if (i == 2) CS_STAMP(19);
+        if (i >= 1) fetch_others(4 + j, dcur);
+        if (i == 2) CS_STAMP(20);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave's stores (dy_i, dlogits, Adam) acknowledged: free behind a poll
+        lds_barrier();
+        // dy_i of this part is out (a wave that polled has seen its earlier stores acknowledged; the last cell drained): arrive
+        if (a.cellflag && tid == 0)
+            __hip_atomic_fetch_add(a.cellflag + (size_t)cgidx * CELLFLAG_STRIDE + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    CS_STAMP(12);
+#undef CS_STAMP
 }

@@ -17,6 +17,8 @@ struct EvalArgs {
     long long* corr_out;  // optional single counter
     const float* pos_w;   // loss_mode 1
     int32_t nblk, ncand;  // row tiles per candidate, candidates of this launch (the 1-D grid of the B3 build)
+    int32_t wl_safe, _padw;  // WL walk: wait for EVERYTHING (vmcnt(0)) instead of counting the row requests behind the tile copies (MFAS_EVAL_NO_WL;
+                             // compile-time in builds whose instruction schedule is not the -O3 one: -DMFAS_EVAL_WL_SAFE, the ASAN variant)
 };
 
 #define EVAL_CE 128   // staged feature columns per pass
@@ -289,7 +291,14 @@ __global__ void __launch_bounds__(256, NRBW == 1 ? 4 : ((B3 && MBE <= 4) ? 2 : 1
                     wl_rows_store(r, c);
                     // this wave's copies of chunk c's tiles have landed; only the youngest row set (chunk c + 2, requested behind them) may
                     // still be in flight — and at c = 0 the tiles are the youngest
-                    if (c > 0 && c + 2 < nchunks) __builtin_amdgcn_s_waitcnt(0x0F70 | MBE); else __builtin_amdgcn_s_waitcnt(0x0F70);
+                    // (the counted form is exact only while exactly MBE compiler-visible vector-memory operations follow a chunk's tile copies —
+                    //  no spill reloads of rA / rB / rC, no load sunk past this point: true of the -O3 product build, whose resource usage
+                    //  tools/build_remarks.sh prints; any other build, or MFAS_EVAL_NO_WL=1, waits for everything)
+#ifdef MFAS_EVAL_WL_SAFE
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+#else
+                    if (c > 0 && c + 2 < nchunks && !a.wl_safe) __builtin_amdgcn_s_waitcnt(0x0F70 | MBE); else __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
                     __syncthreads();
                     if (c + 1 < nchunks) wl_tiles(c + 1);
                     if (c + 3 < nchunks) wl_rows_load(r, c + 3);

@@ -75,12 +75,17 @@ __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
 // candidates in one launch; a sweep unit waits for its cell's dy (per-cell flags published by the chain as the backward pass
 // reaches the cell) instead of for a kernel boundary, so the sweeps of cells L-1 .. 1 overlap the rest of the backward pass.
 // The work list is ordered last cell first; chain blocks have the lowest block indices (dispatched first).
-template <int MB, bool NT>
+// NS > 1 (MB = 1, eight row blocks): every candidate's chain runs on NS workgroups (chain_split): chain block b = part * Kp + candidate
+// with Kp = the candidate count rounded up to 8 — block b lands on XCD b % 8, so a candidate's parts share an XCD and its L2.
+template <int MB, bool NT, int NS = 1>
 __global__ void __launch_bounds__(STEP_THREADS, 4) k_step_same(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bid = (int)blockIdx.x;
     if (bid < a.nchain) {
-        chain_body<MB, false, true>(a.ca, chain_step_of(a.ca), bid, lds);
+        if constexpr (NS > 1) {
+            const int Kp = a.nchain / NS, part = bid / Kp, c = bid - part * Kp;
+            if (c < a.ca.ncand) chain_split<NS>(a.ca, chain_step_of(a.ca), c, part, lds);
+        } else chain_body<MB, false, true>(a.ca, chain_step_of(a.ca), bid, lds);
     } else sweep_body<MB, NT, SweepU<MB, 4>::v, true>(a.sa, sweep_step_of(a.sa), bid - a.nchain, lds);
 }
 
@@ -98,10 +103,112 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_chain(const ChainArgs a) {
 #include "pack.hip.h"
 
 // ================================================================================================
+// Tuning — EVERY environment switch of the library, parsed in ONE place (tuning_from_env) when a population is created or planned
+// and kept in the population: nothing else in this translation unit calls getenv, so a variable that changes after create() cannot
+// change the schedule of a population that was laid out (and parity-tested) without it.  An empty environment gives the defaults
+// below = the configuration the test suites run; INTEGRATION.md lists the switches, mfas_tuning_describe() prints the parsed set
+// (tests/test_host_cpu.py::test_empty_environment_selects_the_tested_defaults).  They are A/B and debugging aids, not API.
+// ================================================================================================
+struct Tuning {
+    int persist = -1;               // MFAS_PERSIST            0: never take the resident schedule (k_president); unset / 1: where it fits
+    int no_lean_chain = 0;          // MFAS_NO_LEAN_CHAIN      general chain_body also at R <= 16
+    int persist_no_resident = 0;    // MFAS_PERSIST_NO_RESIDENT   } either one: no resident units, i.e. launch per phase
+    int persist_no_res_chain = 0;   // MFAS_PERSIST_NO_RES_CHAIN  }
+    int subchunks = 0;              // MFAS_SUBCHUNKS=n        multi-chunk sweep units (measured negative, opt-in)
+    int subchunk_skip = 0;          // MFAS_SUBCHUNK_SKIP=n    every n-th candidate keeps one-chunk units
+    int groups = 0;                 // MFAS_GROUPS=1|2         force one / two candidate groups (0: by population size)
+    int same_group = -1;            // MFAS_SAME_GROUP         0: never k_step_same, 2: whatever the size (-1: by state bytes)
+    int no_tap_major = 0;           // MFAS_NO_TAP_MAJOR       per-segment sweep units also at R < 128
+    int force_tap_major = 0;        // MFAS_FORCE_TAP_MAJOR    tap-major units even with < 192 workgroups
+    int no_red_in_sweep = 0;        // MFAS_NO_RED_IN_SWEEP    the chain reduces the partial slabs itself
+    double occ_bytes = -1.0;        // MFAS_OCC_BYTES          MB == 2: crossover between the 2- and 4-waves-per-SIMD sweep builds
+    int no_xcd_placement = 0;       // MFAS_NO_XCD_PLACEMENT   resident launch: block b runs role b
+    int n_xcd = 0;                  // MFAS_XCDS=n             XCDs the placement assumes (0: 8 — MI355X in SPX mode)
+    int persist_trace = 0;          // MFAS_PERSIST_TRACE      allocate the step-phase timestamp buffer
+    int nt = -1;                    // MFAS_NT=0|1             force cached / nontemporal W/m/v streaming (-1: by plane size)
+    int eval_no_x16 = 0;            // MFAS_EVAL_NO_X16        dev pass: f32 row tiles also over bf16 tables
+    int eval_no_msplit = 0;         // MFAS_EVAL_NO_MSPLIT     dev pass at R <= 32: one wave per row block
+    int eval_no_b3 = 0;             // MFAS_EVAL_NO_B3         dev pass at R = 72..128: f32 feature products
+    int eval_no_wl = 0;             // MFAS_EVAL_NO_WL         dev pass at R <= 16: every wait for the LDS weight tiles is vmcnt(0) (rows one chunk deep)
+    int no_gather = 0;              // MFAS_NO_GATHER          feature units stage rows through the order table
+    int gather_verbose = 0;         // MFAS_GATHER_VERBOSE
+    int no_plain_chain = 0;         // MFAS_NO_PLAIN_CHAIN     resident chain: the general (BN / alphas / multitask capable) instantiation
+    int persist_verbose = 0;        // MFAS_PERSIST_VERBOSE=1|2
+    int prof_every = 16;            // MFAS_PROF_EVERY=n       HIP events around every n-th sweep launch when profiling is on
+    int chain_split = -1;           // MFAS_CHAIN_SPLIT=0|2|4  R = 128 general chain over that many CUs per candidate (-1: the planner decides)
+    // test hooks: parsed only by the -DMFAS_TEST_HOOKS build variant (__graft_entry__.build_variant("hooks", ...)); the product library
+    // never reads these variables
+    int test_not_resident = -1;     // MFAS_PERSIST_TEST_NOT_RESIDENT=e   every roll call from epoch e on "fails"
+    int test_lose_step = -1;        // MFAS_PERSIST_TEST_LOSE_STEP=t      candidate 0's chain never publishes step t
+};
+
+static Tuning tuning_from_env() {
+    Tuning t;
+    auto flag = [](const char* n) { return getenv(n) ? 1 : 0; };
+    auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+    t.persist = getenv("MFAS_PERSIST") ? (atoi(getenv("MFAS_PERSIST")) != 0 ? 1 : 0) : -1;
+    t.no_lean_chain = flag("MFAS_NO_LEAN_CHAIN");
+    t.persist_no_resident = flag("MFAS_PERSIST_NO_RESIDENT");
+    t.persist_no_res_chain = flag("MFAS_PERSIST_NO_RES_CHAIN");
+    t.subchunks = num("MFAS_SUBCHUNKS", 0);
+    t.subchunk_skip = num("MFAS_SUBCHUNK_SKIP", 0);
+    t.groups = num("MFAS_GROUPS", 0);
+    t.same_group = num("MFAS_SAME_GROUP", -1);
+    t.no_tap_major = flag("MFAS_NO_TAP_MAJOR");
+    t.force_tap_major = flag("MFAS_FORCE_TAP_MAJOR");
+    t.no_red_in_sweep = flag("MFAS_NO_RED_IN_SWEEP");
+    if (const char* e = getenv("MFAS_OCC_BYTES")) t.occ_bytes = atof(e);
+    t.no_xcd_placement = flag("MFAS_NO_XCD_PLACEMENT");
+    t.n_xcd = num("MFAS_XCDS", 0);
+    t.persist_trace = flag("MFAS_PERSIST_TRACE");
+    t.nt = getenv("MFAS_NT") ? (atoi(getenv("MFAS_NT")) != 0 ? 1 : 0) : -1;
+    t.eval_no_x16 = flag("MFAS_EVAL_NO_X16");
+    t.eval_no_msplit = flag("MFAS_EVAL_NO_MSPLIT");
+    t.eval_no_b3 = flag("MFAS_EVAL_NO_B3");
+    t.eval_no_wl = flag("MFAS_EVAL_NO_WL");
+    t.no_gather = flag("MFAS_NO_GATHER");
+    t.gather_verbose = flag("MFAS_GATHER_VERBOSE");
+    t.no_plain_chain = flag("MFAS_NO_PLAIN_CHAIN");
+    t.persist_verbose = num("MFAS_PERSIST_VERBOSE", 0);
+    t.prof_every = std::max(1, num("MFAS_PROF_EVERY", 16));
+    t.chain_split = num("MFAS_CHAIN_SPLIT", -1);
+#ifdef MFAS_TEST_HOOKS
+    t.test_not_resident = num("MFAS_PERSIST_TEST_NOT_RESIDENT", -1);
+    t.test_lose_step = num("MFAS_PERSIST_TEST_LOSE_STEP", -1);
+#endif
+    return t;
+}
+
+// "name=value ..." of the switches as parsed from the CURRENT environment, in declaration order (hooks=1 marks the test-hook variant)
+extern "C" int mfas_tuning_describe(char* buf, int32_t cap) {
+    if (!buf || cap <= 0) return MFAS_EINVAL;
+    const Tuning t = tuning_from_env();
+    char tmp[1024];
+    snprintf(tmp, sizeof(tmp),
+             "persist=%d no_lean_chain=%d persist_no_resident=%d persist_no_res_chain=%d subchunks=%d subchunk_skip=%d groups=%d same_group=%d "
+             "no_tap_major=%d force_tap_major=%d no_red_in_sweep=%d occ_bytes=%g no_xcd_placement=%d n_xcd=%d persist_trace=%d nt=%d eval_no_x16=%d "
+             "eval_no_msplit=%d eval_no_b3=%d eval_no_wl=%d no_gather=%d gather_verbose=%d no_plain_chain=%d persist_verbose=%d prof_every=%d "
+             "chain_split=%d test_not_resident=%d test_lose_step=%d hooks=%d",
+             t.persist, t.no_lean_chain, t.persist_no_resident, t.persist_no_res_chain, t.subchunks, t.subchunk_skip, t.groups, t.same_group,
+             t.no_tap_major, t.force_tap_major, t.no_red_in_sweep, t.occ_bytes, t.no_xcd_placement, t.n_xcd, t.persist_trace, t.nt, t.eval_no_x16,
+             t.eval_no_msplit, t.eval_no_b3, t.eval_no_wl, t.no_gather, t.gather_verbose, t.no_plain_chain, t.persist_verbose, t.prof_every,
+             t.chain_split, t.test_not_resident, t.test_lose_step,
+#ifdef MFAS_TEST_HOOKS
+             1
+#else
+             0
+#endif
+    );
+    snprintf(buf, (size_t)cap, "%s", tmp);
+    return MFAS_OK;
+}
+
+// ================================================================================================
 // Host side: C ABI
 // ================================================================================================
 struct mfas_population {
     mfas_hyper hp;
+    Tuning tune;                    // the environment switches as they stood when the population was created
     Geo g;
     int K = 0, device = 0;
     hipStream_t stream = nullptr;
@@ -154,6 +261,9 @@ struct mfas_population {
     bool res_wide = false;          // resident units of more than 512 columns (16-bit staging): f32 tables cannot be trained
     bool same_group = false;        // one launch per step: chain blocks + sweep blocks of the same candidates, per-cell dy flags (k_step_same)
     uint32_t* d_cellflag = nullptr; // [K][CELLFLAG_STRIDE]
+    int chain_split = 0;            // CUs per candidate chain in the same-group launch (0 / 1: chain_body on one CU; 4: chain_split<4>)
+    float* d_xch = nullptr;         // chain_split's exchange area [K][XCH_CAND_FLOATS]
+    size_t lds_split = 0;           // dynamic LDS of the k_step_same<1, *, 4> launches
     bool res_chain = false;         // resident lean chain: owns OUT / HEAD + vector block on chip; persistent units = feature units only
     int res_nu = 1;                 // resident units per workgroup (2: a workgroup serves units of two candidates)
     int nres_wg = 0;                // resident workgroups = ceil(nres / res_nu)
@@ -247,7 +357,7 @@ static size_t plan_res_lds(const mfas_hyper* hp, const Geo& g, int cc, int nu) {
 }
 
 static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs, const int32_t* n_cells, int K, int chunk_cols,
-                        int n_cus, bool allow_persist, LayoutPlan& lp) {
+                        int n_cus, bool allow_persist, const Tuning& tu, LayoutPlan& lp) {
     // A workgroup should stream >= ~64 tiles (amortises staging / reduction and keeps the number of partial-sum chunks the
     // chain has to reduce small), the launch should still have a few hundred workgroups, and x_t / x_{t+1} for the chunk must
     // fit the LDS budget.
@@ -257,15 +367,14 @@ static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs
     // Default (measured, profiles/r02_popsweep_*.log, r03_popsweep.log): ON where the resident form fits (x1.6-2.1 over the
     // launch-per-phase schedule at 4..28 candidates per GPU).  Nothing else is persistent: the streaming form of round 2 (larger R,
     // or units that do not fit; x0.8-0.9 of launch-per-phase) was removed in round 3.  MFAS_PERSIST=0 turns the schedule off.
-    lp.want_persist = allow_persist;
-    if (const char* e = getenv("MFAS_PERSIST")) lp.want_persist = allow_persist && atoi(e) != 0;
+    lp.want_persist = allow_persist && tu.persist != 0;
     // (lean-chain feasibility, same formula as the LDS budget in create_impl: resident units exist only together with the resident
     // lean chain — k_president; a population without both runs launch-per-phase)
     const size_t lean_bytes = ((size_t)2 * MFAS_MAX_CELLS * g.Bp * 20 + (size_t)g.Bp * (g.Cp + 4) + MFAS_MAX_CELLS * 16 + 3 * g.Bp + 16
                                + (size_t)(g.alphas ? 2 : 1) * MFAS_MAX_CELLS * g.MB * 256 + (size_t)3 * (MFAS_MAX_CELLS * g.vec_cell_stride + g.Cp)
                                + LEAN_SCR + 8 + LeanLds<1>::stage_floats() + (size_t)g.Bp * 64) * 4;
-    lp.lean_ok = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean_bytes <= 78 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
-    lp.plan_res = lp.want_persist && g.nrb == 1 && g.MB <= 2 && !getenv("MFAS_PERSIST_NO_RESIDENT") && !getenv("MFAS_PERSIST_NO_RES_CHAIN") && lp.lean_ok;
+    lp.lean_ok = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean_bytes <= 78 * 1024 && !tu.no_lean_chain;
+    lp.plan_res = lp.want_persist && g.nrb == 1 && g.MB <= 2 && !tu.persist_no_resident && !tu.persist_no_res_chain && lp.lean_ok;
     auto feat_units = [&](int cc_target, int* max_cc) {
         int64_t n = 0;
         int mx = 0;
@@ -331,9 +440,8 @@ static void plan_layout(const mfas_hyper* hp, const Geo& g, const int32_t* confs
     // (measured, profiles/r04_subchunks.log: uniform groups of 2 / 4 / 8 / 16 chunks are SLOWER — 314 / 320 / 327 / 327 us per launch
     //  against 299 on the same box — because 4x larger units leave ~4 units per workgroup slot and the launch's tail grows faster
     //  than the slab traffic shrinks: the default stays one chunk per unit, MFAS_SUBCHUNKS / MFAS_SUBCHUNK_SKIP select the other forms)
-    if (const char* e = getenv("MFAS_SUBCHUNKS"))
-        if (g.nrb == STEP_NW && K >= 28 && !lp.plan_res) lp.group = std::max(1, std::min(64, atoi(e)));
-    if (const char* e = getenv("MFAS_SUBCHUNK_SKIP")) lp.group_skip = atoi(e);
+    if (tu.subchunks > 0 && g.nrb == STEP_NW && K >= 28 && !lp.plan_res) lp.group = std::max(1, std::min(64, tu.subchunks));
+    lp.group_skip = tu.subchunk_skip;
     {
         int mx = 0;
         lp.nfeat = (int)feat_units(lp.target, &mx);
@@ -398,12 +506,14 @@ static std::vector<SegDesc> merge_units(const std::vector<SegDesc>& in) {
 
 static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t* n_cells,
                        const uint32_t* drop_seeds, int32_t K, int32_t device, void* hip_stream,
-                       int32_t chunk_cols, mfas_population** out, const bool allow_persist) {
+                       int32_t chunk_cols, mfas_population** out, const bool allow_persist, const Tuning* inherit = nullptr) {
     if (!out) return fail(MFAS_EINVAL, "null argument or K <= 0");
     if (int vrc = validate_inputs(hp, confs, n_cells, K)) return vrc;
     mfas_population* p = new (std::nothrow) mfas_population();
     if (!p) return fail(MFAS_ENOMEM, "host alloc");
     p->hp = *hp;
+    p->tune = inherit ? *inherit : tuning_from_env();      // (persist_fallback rebuilds a population under the switches it was created with)
+    const Tuning& tu = p->tune;
     p->K = K;
     p->device = device;
     p->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -436,7 +546,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         p->n_cus = ncu;
     }
     LayoutPlan lp;
-    plan_layout(hp, g, confs, n_cells, K, chunk_cols, p->n_cus, allow_persist, lp);
+    plan_layout(hp, g, confs, n_cells, K, chunk_cols, p->n_cus, allow_persist, tu, lp);
     const bool want_persist = lp.want_persist;
     int target = lp.target;
     const int plan_nu = lp.nu;
@@ -604,7 +714,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                              + (g.alphas ? 2 : 1) * plane + vec / 4 + LEAN_SCR + 8 + LeanLds<1>::stage_floats() + (size_t)g.Bp * 64) * 4;
         // (the chain form must not depend on the sweep's chunk size: since round 2 the lean chain sums bias gradients and BN
         // statistics in its own — element-parallel — order, so lean and general chains agree to rounding, not bit for bit)
-        p->lean_chain = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean <= 78 * 1024 && !getenv("MFAS_NO_LEAN_CHAIN");
+        p->lean_chain = g.nrb == 1 && g.ncb <= 4 && g.MB <= 2 && lean <= 78 * 1024 && !tu.no_lean_chain;
         if (p->lean_chain) { p->lds_chain = lean; p->lds_step = std::max(p->lds_step, lean); }
         p->res_chain = res_ok && p->lean_chain;
         if (res_ok && !p->lean_chain) {   // (cannot happen while lean_ok_early mirrors the formula above)
@@ -672,7 +782,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         // round 2, general chain with reduce-in-sweep (chain 48 -> 38 us at R=128): fused from 8 candidates
         // (R=128 cand/s unfused+reduce vs fused+reduce: 12 candidates 18.1 vs 20.2, 16: 21.0 vs 23.6, 24: 22.9 (old default) vs 26.6)
         int ngroups = p->lean_chain ? ((K >= 40 && K < 224) ? 2 : 1) : (K >= 8 ? 2 : 1);
-        if (const char* e = getenv("MFAS_GROUPS")) ngroups = (atoi(e) >= 2 && K >= 2) ? 2 : 1;
+        if (tu.groups > 0) ngroups = (tu.groups >= 2 && K >= 2) ? 2 : 1;
         {   // persistent step loop: small populations (one workgroup per CU must hold every chain + a useful number of sweep workgroups)
             const bool want = want_persist;
             const bool fits = K <= p->n_cus / 4 && g.MB != 4 && K + p->nres_wg <= p->n_cus;
@@ -685,17 +795,19 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         }
         // same-group fused launch (k_step_same): general chain, one group, R >= 128 (no tap-major units), launch-per-phase
         {
-            const int sgenv = getenv("MFAS_SAME_GROUP") ? atoi(getenv("MFAS_SAME_GROUP")) : -1;     // 0: never, 2: whatever the size (A/B runs)
+            const int sgenv = tu.same_group;     // 0: never, 2: whatever the size (A/B runs)
             // measured (MI355X, conf 4, B=16): pays while the population's W/m/v stream is <= ~260 MB per step — R=128: 1 / 3 / 6 / 8 / 12
             // candidates 56 / 65 / 76 / 81 / 91 -> 50 / 54 / 63 / 70 / 88 us per step (16: equal); R=64: 6 / 12 / 16: 52 / 61 / 64 -> 45 / 55 / 61
             // (24: 74 -> 79); R=32: 6 / 12 / 32: 45 / 54 / 68 -> 36 / 41 / 60 (64: 85 -> 90)
             double state_bytes = 0;
             for (const SegDesc& d : p->descs) state_bytes += 24.0 * d.cc * d.rows_p;
-            const bool two_forced = getenv("MFAS_GROUPS") && atoi(getenv("MFAS_GROUPS")) >= 2;      // (tests: the two-group fused schedule)
+            const bool two_forced = tu.groups >= 2;      // (tests: the two-group fused schedule)
             p->same_group = !p->persist && !p->lean_chain && g.MB <= 2 && (state_bytes <= 260e6 || sgenv == 2) && sgenv != 0 && !two_forced &&
                             lp.group == 1;      // (multi-chunk units exist in k_step's sweep only)
         }
         if (p->same_group) ngroups = 1;
+        // the chain of one candidate over 4 CUs (chain.hip.h, chain_split): eight row blocks, one batch tile, <= 4 class blocks, no alphas
+        p->chain_split = (p->same_group && g.MB == 1 && g.nrb == 8 && g.ncb <= 4 && !g.alphas && tu.chain_split != 0 && tu.chain_split != 1) ? 4 : 0;
         p->lp_group = lp.group;
         int split = K;
         if (ngroups == 2) {
@@ -722,7 +834,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             std::vector<SegDesc> sorted;
             std::vector<TapDesc> taps;
             // (tap-major workgroups stage a batch's rows ONCE for several candidates: not with per-candidate sample orders)
-            const bool tap_major = (g.nrb == 1 || g.nrb == 2 || g.nrb == 4) && !getenv("MFAS_NO_TAP_MAJOR") && !p->persist && !p->same_group &&
+            const bool tap_major = (g.nrb == 1 || g.nrb == 2 || g.nrb == 4) && !tu.no_tap_major && !p->persist && !p->same_group &&
                                    !hp->order_per_candidate;
             if (tap_major) {
                 const int per_wg = STEP_NW / g.nrb;
@@ -748,7 +860,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
                     taps.push_back(t);
                 }
                 std::stable_sort(taps.begin(), taps.end(), [](const TapDesc& x, const TapDesc& y) { return x.nitems * x.cc > y.nitems * y.cc; });
-                if (taps.size() < 192 && !getenv("MFAS_FORCE_TAP_MAJOR")) {   // too few workgroups to fill 256 CUs: per-segment path
+                if (taps.size() < 192 && !tu.force_tap_major) {   // too few workgroups to fill 256 CUs: per-segment path
                     taps.clear();
                     sorted = all;
                 }
@@ -776,7 +888,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     }
     // reduce-in-sweep: one group (the chain is on the critical path), general chain, per-segment units only
     // (beyond ~28 candidates the co-scheduled chain is hidden anyway and the extra write-through traffic costs: 29.0 vs 26.7 cand/s at 32)
-    p->red_in_sweep = K < 28 && !p->lean_chain && !p->persist && !getenv("MFAS_NO_RED_IN_SWEEP");
+    p->red_in_sweep = K < 28 && !p->lean_chain && !p->persist && !tu.no_red_in_sweep;
     for (const auto& gr : p->groups) if (gr.ntap != 0) p->red_in_sweep = false;     // (tap-major workgroups serve several candidates)
     if (p->red_in_sweep) {
         CREATE_CHK(hipMalloc(&p->d_red_cnt, sizeof(uint32_t) * K * MFAS_MAX_CELLS));
@@ -786,6 +898,12 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         CREATE_CHK(hipMalloc(&p->d_cellflag, sizeof(uint32_t) * K * CELLFLAG_STRIDE));
         CREATE_CHK(set_lds((k_step_same<1, false>), p->lds_step)); CREATE_CHK(set_lds((k_step_same<1, true>), p->lds_step));
         CREATE_CHK(set_lds((k_step_same<2, false>), p->lds_step)); CREATE_CHK(set_lds((k_step_same<2, true>), p->lds_step));
+        if (p->chain_split) {
+            p->lds_split = std::max(p->lds_step, chain_split_lds_floats<4>(g.Rp, g.Cp) * 4);
+            CREATE_CHK(set_lds((k_step_same<1, false, 4>), p->lds_split)); CREATE_CHK(set_lds((k_step_same<1, true, 4>), p->lds_split));
+            CREATE_CHK(hipMalloc(&p->d_xch, sizeof(float) * (size_t)K * XCH_CAND_FLOATS));
+            if ((size_t)K * XCH_CAND_FLOATS >= (1ull << 30)) { mfas_population_destroy(p); return fail(MFAS_EINVAL, "internal: exchange area beyond the 32-bit buffer offsets"); }
+        }
     }
     CREATE_CHK(hipMemsetAsync(p->plane, 0, sizeof(float) * 3 * (size_t)p->plane_stride, p->stream));
     CREATE_CHK(hipMemsetAsync(p->wt, 0, sizeof(float) * (size_t)std::max<int64_t>(p->wt_size, 64), p->stream));
@@ -793,7 +911,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     // measured crossover (MI355X, B=20): R=16 between 165 and 330 MB of group state per launch, R=128 between 300 and 600 MB
     // (the spilling chain of the occupancy build takes ~40 / ~125 us there)
     p->occ_bytes = g.nrb >= 8 ? 450e6 : 250e6;
-    if (const char* e = getenv("MFAS_OCC_BYTES")) p->occ_bytes = atof(e);
+    if (tu.occ_bytes >= 0) p->occ_bytes = tu.occ_bytes;
 #define SET_STEP(M, W, F) CREATE_CHK(set_lds((k_step<M, false, W, F>), p->lds_step)); CREATE_CHK(set_lds((k_step<M, true, W, F>), p->lds_step))
     SET_STEP(1, 4, false); SET_STEP(2, 2, false); SET_STEP(2, 4, false); SET_STEP(4, 2, false);
     SET_STEP(1, 4, true); SET_STEP(2, 2, true); SET_STEP(2, 4, true);
@@ -818,13 +936,16 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             if (d.kind <= KIND_V) need[d.cand]++;
         CREATE_CHK(hipMalloc(&p->d_need, sizeof(int32_t) * K));
         CREATE_CHK(hipMemcpy(p->d_need, need.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice));
-        if (!getenv("MFAS_NO_XCD_PLACEMENT")) {
+        if (!tu.no_xcd_placement) {
             // XCD-aware placement (round 5): consecutive workgroups of a launch are dealt round-robin to the 8 XCDs (block b -> XCD b % 8,
             // MI355X_MICROARCH.md), each with its own L2.  A candidate's chain and the workgroups that hold its units exchange 60 KB of
             // slabs and 8 KB of dy per step: deal the roles so that they share an XCD wherever its 32 slots allow (greedy, candidate by
             // candidate; two-unit workgroups are grouped by their FIRST unit's candidate, and the chain of a candidate that only ever
             // comes second goes where most of its units are).  Placement only: the exchanges do not depend on it.
-            const int nwg = p->nres_wg, G = K + nwg, NX = 8;
+            // (NX: 8 XCDs on MI355X in SPX mode, block b -> XCD b % 8; MFAS_XCDS=n for another partition mode.  A wrong NX costs
+            //  only the co-location.  prim / sec below mirror sweep_resident's unit mapping — unit u of workgroup w is unit w + u * nwg,
+            //  persist.hip.h `const int ui = wg + u * nwg` — and must change with it.)
+            const int nwg = p->nres_wg, G = K + nwg, NX = tu.n_xcd > 0 ? std::min(tu.n_xcd, 64) : 8;
             std::vector<std::vector<int>> slots(NX);
             for (int b = G - 1; b >= 0; --b) slots[b % NX].push_back(b);       // (pop_back hands out the lowest block of an XCD first)
             std::vector<int32_t> role(G, -1);
@@ -866,20 +987,19 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             }
         }
         CREATE_CHK(hipMalloc(&p->d_sync, sizeof(uint32_t) * ((size_t)K * PERSIST_SYNC_STRIDE + 64)));
-        if (getenv("MFAS_PERSIST_TRACE")) {
+        if (tu.persist_trace) {
             CREATE_CHK(hipMalloc(&p->d_trace, sizeof(unsigned long long) * 256));
             CREATE_CHK(hipMemset(p->d_trace, 0, sizeof(unsigned long long) * 256));
         }
 #define SET_RES(M, P) CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 1, P>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 2, P>), p->lds_president)); \
                    CREATE_CHK(set_lds((k_president<M, PERSIST_NTR16, true, 1, P>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 1, P>), p->lds_president)); \
-                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2, P>), p->lds_president)); \
-                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2, P, true>), p->lds_president))
+                   CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2, P>), p->lds_president))
         SET_RES(1, false); SET_RES(2, false); SET_RES(1, true); SET_RES(2, true);
 #undef SET_RES
     }
     // W/m/v beyond what the 256 MiB Infinity Cache can keep between steps are streamed nontemporally
     p->nontemporal = (double)p->plane_stride * 12.0 > 200.0 * 1024 * 1024;
-    if (const char* e = getenv("MFAS_NT")) p->nontemporal = atoi(e) != 0;
+    if (tu.nt >= 0) p->nontemporal = tu.nt != 0;
     CREATE_CHK(hipStreamSynchronize(p->stream));
     *out = p;
     return MFAS_OK;
@@ -911,9 +1031,10 @@ extern "C" int mfas_population_plan(const mfas_hyper* hp, const int32_t* confs, 
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
     LayoutPlan lp;
-    plan_layout(hp, g, confs, n_cells, K, chunk_cols, ncu, true, lp);
+    const Tuning tu = tuning_from_env();
+    plan_layout(hp, g, confs, n_cells, K, chunk_cols, ncu, true, tu, lp);
     if (!lp.resident && lp.plan_res)      // the resident chunking does not stand: what create would fall back to (launch per phase)
-        plan_layout(hp, g, confs, n_cells, K, chunk_cols, ncu, false, lp);
+        plan_layout(hp, g, confs, n_cells, K, chunk_cols, ncu, false, tu, lp);
     info[0] = lp.resident ? 1 : 0; info[1] = lp.resident ? lp.nfeat : 0; info[2] = lp.resident ? lp.nres_wg : 0; info[3] = lp.nu;
     info[4] = lp.target; info[5] = lp.lean_ok ? 1 : 0; info[6] = ncu; info[7] = K;
     return MFAS_OK;
@@ -931,6 +1052,7 @@ extern "C" void mfas_population_destroy(mfas_population* p) {
     hipFree(p->d_red_cnt);
     hipFree(p->d_gather);
     hipFree(p->d_cellflag);
+    hipFree(p->d_xch);
     hipFree(p->d_sync); hipFree(p->d_need); hipFree(p->d_role); hipFree(p->d_scal); hipFree(p->d_trace); hipFree(p->d_pdescs);
     delete p;
 }
@@ -1108,6 +1230,7 @@ static hipError_t launch_eval_t(mfas_population* p, const EvalArgs& a, int ncand
     EvalArgs b = a;
     b.nblk = (int32_t)nblk;
     b.ncand = ncand;
+    b.wl_safe = p->tune.eval_no_wl;
     hipLaunchKernelGGL((k_eval<MBE, NRBW, MSP, XB, B3>), B3 ? dim3(nblk * (unsigned)ncand) : dim3(nblk, ncand), dim3(256), lds, st, b);
     return hipGetLastError();
 }
@@ -1115,13 +1238,13 @@ static hipError_t launch_eval_t(mfas_population* p, const EvalArgs& a, int ncand
 static hipError_t launch_eval(mfas_population* p, const EvalArgs& a, int ncand, hipStream_t st) {
     // one or two row blocks (R <= 32): the m-blocks of a row tile are split over the four waves (eval.hip.h)
     // (bf16 tables: the rows stay 16-bit in LDS)
-    const bool xb = a.tab.dtype == MFAS_DT_BF16 && !getenv("MFAS_EVAL_NO_X16");
-#define EV_SPLIT(M, S) if (p->mbe == M && p->nrbw == 1 && p->g.nrb == S && !getenv("MFAS_EVAL_NO_MSPLIT")) \
+    const bool xb = a.tab.dtype == MFAS_DT_BF16 && !p->tune.eval_no_x16;
+#define EV_SPLIT(M, S) if (p->mbe == M && p->nrbw == 1 && p->g.nrb == S && !p->tune.eval_no_msplit) \
         return xb ? launch_eval_t<M, 1, S, true>(p, a, ncand, st) : launch_eval_t<M, 1, S, false>(p, a, ncand, st);
     EV_SPLIT(4, 1) EV_SPLIT(4, 2) EV_SPLIT(2, 1) EV_SPLIT(2, 2) EV_SPLIT(1, 1) EV_SPLIT(1, 2)
 #undef EV_SPLIT
     // two row blocks per wave (R = 72 .. 128), bf16 tables: exact bf16 x 3 feature products on the bf16 matrix pipe
-    if (a.tab.dtype == MFAS_DT_BF16 && p->nrbw == 2 && !getenv("MFAS_EVAL_NO_B3")) {
+    if (a.tab.dtype == MFAS_DT_BF16 && p->nrbw == 2 && !p->tune.eval_no_b3) {
         if (p->mbe == 4) return launch_eval_t<4, 2, 0, false, true>(p, a, ncand, st);
         if (p->mbe == 2) return launch_eval_t<2, 2, 0, false, true>(p, a, ncand, st);
         if (p->mbe == 1) return launch_eval_t<1, 2, 0, false, true>(p, a, ncand, st);
@@ -1153,7 +1276,7 @@ static int persist_fallback(mfas_population* p) {
         maxp = std::max(maxp, p->nparams[k]);
     }
     mfas_population* q = nullptr;
-    int rc = create_impl(&p->hp, confs.data(), ncells.data(), seeds.data(), K, p->device, p->stream, p->chunk_cols_req, &q, false);
+    int rc = create_impl(&p->hp, confs.data(), ncells.data(), seeds.data(), K, p->device, p->stream, p->chunk_cols_req, &q, false, &p->tune);
     if (rc) return rc;
     float* flat = nullptr;
     hipError_t e = hipMalloc(&flat, sizeof(float) * (size_t)maxp);
@@ -1249,6 +1372,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
 
     // Candidate groups A/B: every launch pairs the sweep of one group with the chain of the other (k_step).
     int NG = 0;
+    int64_t split_launches = 0;         // chain_split launches of this call (exchange parity)
     StepArgs st;
     auto init_args = [&]() -> hipError_t {     // (again after persist_fallback: the population's buffers and layout have changed)
         NG = (int)p->groups.size();
@@ -1265,6 +1389,10 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         hipError_t e_ = hipSuccess;
         if (p->red_in_sweep) e_ = hipMemsetAsync(p->d_red_cnt, 0, sizeof(uint32_t) * K * MFAS_MAX_CELLS, p->stream);
         if (e_ == hipSuccess && p->same_group) e_ = hipMemsetAsync(p->d_cellflag, 0, sizeof(uint32_t) * K * CELLFLAG_STRIDE, p->stream);
+        // chain_split: every piece of both parities "not written" (all-ones words), parity counter back to 0
+        if (e_ == hipSuccess && p->chain_split) e_ = hipMemsetAsync(p->d_xch, 0xFF, sizeof(float) * (size_t)K * XCH_CAND_FLOATS, p->stream);
+        st.ca.xch = p->d_xch; st.ca.nsplit = p->chain_split; st.ca.xpar = 0;
+        split_launches = 0;
         return e_;
     };
     HIPCHK(init_args());
@@ -1282,7 +1410,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     bool use_gather = false;
     int64_t g_par_stride = 0, g_cand_stride = 0;
     auto setup_gather = [&]() -> hipError_t {
-        use_gather = NG == 2 && !p->persist && order && p->g.order_stride > 0 && p->lp_group == 1 && !getenv("MFAS_NO_GATHER");
+        use_gather = NG == 2 && !p->persist && order && p->g.order_stride > 0 && p->lp_group == 1 && !p->tune.no_gather;
         if (!use_gather) return hipSuccess;
         int64_t totw = 0;
         for (int u = 0; u < MFAS_MAX_TAPS; ++u) totw += p->g.sw[u] + p->g.vw[u];
@@ -1295,7 +1423,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             if (e != hipSuccess) { use_gather = false; (void)hipGetLastError(); return hipSuccess; }   // an optimisation: train without it
             p->gather_cap = need;
         }
-        if (getenv("MFAS_GATHER_VERBOSE")) fprintf(stderr, "[gather] on: %d candidates, %.1f MB of gathered rows\n", K, (double)need / 1e6);
+        if (p->tune.gather_verbose) fprintf(stderr, "[gather] on: %d candidates, %.1f MB of gathered rows\n", K, (double)need / 1e6);
         return hipSuccess;
     };
     HIPCHK(setup_gather());
@@ -1375,6 +1503,14 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             st.sa.cellflag = p->d_cellflag; st.ca.cellflag = p->d_cellflag;
             st.sa.flag_target = st.ca.flag_target = (uint32_t)st.ca.gstep + 1u;
             st.sa.flag_status = p->d_status;
+            if (p->chain_split) {      // NS parts per candidate: the per-cell flags count arrivals, chain blocks = NS * ceil8(candidates)
+                const int NS = p->chain_split, Kp = (int)((nch + 7) & ~7u);
+                st.sa.flag_target = st.ca.flag_target = (uint32_t)NS * ((uint32_t)st.ca.gstep + 1u);
+                st.ca.ncand = (int)nch; st.ca.xpar = (int)(split_launches++ & 1);
+                st.nchain = NS * Kp;
+                if (p->nontemporal) hipLaunchKernelGGL((k_step_same<1, true, 4>), dim3(st.nchain + nsw), dim3(STEP_THREADS), p->lds_split, p->stream, st);
+                else hipLaunchKernelGGL((k_step_same<1, false, 4>), dim3(st.nchain + nsw), dim3(STEP_THREADS), p->lds_split, p->stream, st);
+            } else
             if (g.MB == 1) { if (p->nontemporal) hipLaunchKernelGGL((k_step_same<1, true>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st);
                              else hipLaunchKernelGGL((k_step_same<1, false>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st); }
             else { if (p->nontemporal) hipLaunchKernelGGL((k_step_same<2, true>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st);
@@ -1414,8 +1550,8 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         HIPCHK(hipMemcpyAsync(p->d_scal, step_scalars, sizeof(float) * have, hipMemcpyHostToDevice, p->stream));
     }
     // one persistent launch = all train steps of one epoch (persist.hip.h)
-    const int test_not_resident = getenv("MFAS_PERSIST_TEST_NOT_RESIDENT") ? atoi(getenv("MFAS_PERSIST_TEST_NOT_RESIDENT")) : -1;   // test hook: from
-                                                                           // this epoch on every roll call "fails" (nothing is launched)
+    const int test_not_resident = p->tune.test_not_resident;   // (-1 in the product library; the MFAS_TEST_HOOKS variant: from this epoch on
+                                                               //  every roll call "fails" — nothing is launched)
     auto persist_epoch_once = [&](int ep, int64_t T) -> hipError_t {
         if (test_not_resident >= 0 && ep >= test_not_resident) { aborts[ep] = PERSIST_ABORT_NOT_RESIDENT; return hipSuccess; }
         hipError_t e = hipMemsetAsync(p->d_sync, 0, sizeof(uint32_t) * ((size_t)K * PERSIST_SYNC_STRIDE + 64), p->stream);
@@ -1428,15 +1564,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         pa.nchain = K; pa.nitems = p->n_pdescs; pa.nres = p->nres; pa.res_chain = p->res_chain ? 1 : 0; pa.res_wide = p->res_wide ? 1 : 0;
         pa.res_nu = p->res_nu; pa.nres_wg = p->nres_wg; pa.res_buf_words = p->res_buf_words;
         pa.T = (int)T; pa.epoch = ep;
-        pa.lose_step = getenv("MFAS_PERSIST_TEST_LOSE_STEP") ? atoi(getenv("MFAS_PERSIST_TEST_LOSE_STEP")) : -1;
-        // deferred unit hand-off (persist.hip.h, k_president<..., DEFER = true>): OPT-IN (MFAS_RES_DEFER=1; two units per workgroup, 16-bit
-        // tables).  Measured NEGATIVE against the kernels it would replace: 22 / 28 candidates 15.3 / 15.2 -> 16.4 / 16.4 us per step, 16
-        // candidates 11.1 -> 13.6 (profiles/r05_defer_ab.log, final build) — what it saves in waits it loses to the 17-24 spilled VGPRs its
-        // extra live state costs the unit loop (scratch reloads on the serial path); an earlier "+6 %" compared it with a merged kernel
-        // whose non-deferred path carried the same spills.
-        pa.res_defer = 0;
-        if (const char* e = getenv("MFAS_RES_DEFER")) pa.res_defer = (atoi(e) != 0 && p->res_nu == 2) ? 1 : 0;
-        if (getenv("MFAS_RES_NO_DEFER")) pa.res_defer = 0;
+        pa.lose_step = p->tune.test_lose_step;
         pa.N = N; pa.pos0 = (int64_t)ep * N;
         pa.B = B; pa.gstep0 = (int)((int64_t)ep * nb);
         pa.scal = p->d_scal; pa.sync = p->d_sync; pa.need = p->d_need; pa.role = p->d_role; pa.trace = p->d_trace;
@@ -1454,18 +1582,14 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         {      // one instantiation per unit form
             const int lw = (int)(p->lds_president / 4) - PERSIST_LDS_WORDS;
             // the search default — no BatchNorm, no alphas, single-task softmax CE — runs the chain compiled for exactly that (chain_lean PLAIN)
-            const bool plain = !g.bn && !g.alphas && !g.multitask && g.loss_mode == 0 && !getenv("MFAS_NO_PLAIN_CHAIN");
+            const bool plain = !g.bn && !g.alphas && !g.multitask && g.loss_mode == 0 && !p->tune.no_plain_chain;
 #define RES_LAUNCH(M, NTR, X, NU) do { if (plain) hipLaunchKernelGGL((k_president<M, NTR, X, NU, true>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); \
                                        else hipLaunchKernelGGL((k_president<M, NTR, X, NU, false>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); } while (0)
-#define RES_LAUNCH_D(M, NTR, X, NU) do { if (plain) hipLaunchKernelGGL((k_president<M, NTR, X, NU, true, true>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); \
-                                         else hipLaunchKernelGGL((k_president<M, NTR, X, NU, false, true>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); } while (0)
 #define RES_PICK(M) do { if (train->dtype == MFAS_DT_F32) { if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, false, 2); else RES_LAUNCH(M, PERSIST_NTR, false, 1); } \
                          else if (pa.res_wide) RES_LAUNCH(M, PERSIST_NTR16, true, 1); \
-                         else if (pa.res_nu == 2 && pa.res_defer) RES_LAUNCH_D(M, PERSIST_NTR, true, 2); \
                          else if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, true, 2); else RES_LAUNCH(M, PERSIST_NTR, true, 1); } while (0)
             if (g.MB == 1) RES_PICK(1); else RES_PICK(2);
 #undef RES_PICK
-#undef RES_LAUNCH_D
 #undef RES_LAUNCH
         }
         if (prof) {
@@ -1488,10 +1612,10 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             if (e != hipSuccess) return e;
             e = hipStreamSynchronize(p->stream);
             if (e != hipSuccess) return e;
-            if (getenv("MFAS_PERSIST_VERBOSE") && atoi(getenv("MFAS_PERSIST_VERBOSE")) >= 2)
+            if (p->tune.persist_verbose >= 2)
                 fprintf(stderr, "[persist] epoch %d attempt %d: abort word %u\n", ep, attempt, aborts[ep]);
             if (aborts[ep] != PERSIST_ABORT_NOT_RESIDENT || attempt >= PERSIST_MAX_RELAUNCHES || test_not_resident >= 0) {
-                if (attempt && getenv("MFAS_PERSIST_VERBOSE")) fprintf(stderr, "[persist] epoch %d: grid not resident at once, relaunched %d time(s)\n", ep, attempt);
+                if (attempt && p->tune.persist_verbose) fprintf(stderr, "[persist] epoch %d: grid not resident at once, relaunched %d time(s)\n", ep, attempt);
                 return hipSuccess;
             }
             if (p->profiling && ev_used >= 2) { ev_used -= 2; ev_bytes.pop_back(); }       // the failed attempt is not a measurement
@@ -1511,7 +1635,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             HIPCHK(persist_epoch(ep, T));
             if (aborts[ep] == PERSIST_ABORT_NOT_RESIDENT) {
                 // every attempt failed its roll call: nothing of this epoch has run.  Train it — and the rest — launch per phase.
-                if (getenv("MFAS_PERSIST_VERBOSE")) fprintf(stderr, "[persist] epoch %d: the resident grid never became resident; falling back to launch-per-phase\n", ep);
+                if (p->tune.persist_verbose) fprintf(stderr, "[persist] epoch %d: the resident grid never became resident; falling back to launch-per-phase\n", ep);
                 rc = persist_fallback(p);
                 if (rc) return rc;
                 HIPCHK(init_args());
@@ -1606,10 +1730,14 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     if (status) memcpy(status, hstatus.data(), sizeof(int32_t) * K);
 #ifdef MFAS_CHAIN_TIMING
     {
-        int32_t ts[16];
+        int32_t ts[24];
         if (hipMemcpy(ts, p->d_status + 64, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[chain timing, shader cycles since kernel entry, candidate 0 step 3]");
             for (int i = 0; i < 13; ++i) fprintf(stderr, " %d", ts[i]);
+            if (p->chain_split) {      // chain_split's extra stamps: forward cell 1 product done | out sent | tail done | fetched;  backward cell 2 the same;  softmax done;  entry staged
+                fprintf(stderr, "  | split:");
+                for (int i = 13; i < 23; ++i) fprintf(stderr, " %d", ts[i]);
+            }
             fprintf(stderr, "\n");
             int32_t cs[24];
             if (hipMemcpy(cs, p->d_status + 96, sizeof(cs), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1796,14 +1924,14 @@ extern "C" int mfas_population_set_best_threshold(mfas_population* p, double thr
 extern "C" int mfas_population_set_profiling(mfas_population* p, int32_t on) {
     if (!p) return fail(MFAS_EINVAL, "null");
     p->profiling = on != 0;
-    if (const char* e = getenv("MFAS_PROF_EVERY")) p->prof_every = std::max(1, atoi(e));
+    p->prof_every = p->tune.prof_every;
     return MFAS_OK;
 }
 
 extern "C" int mfas_population_schedule(const mfas_population* p, int32_t info[8]) {
     if (!p || !info) return fail(MFAS_EINVAL, "null");
     info[0] = p->persist ? 1 : 0; info[1] = p->nres; info[2] = p->nres_wg; info[3] = p->res_nu;
-    info[4] = p->res_chain ? 1 : 0; info[5] = p->lean_chain ? 1 : 0; info[6] = p->same_group ? -1 : (int32_t)p->groups.size(); info[7] = p->K;
+    info[4] = p->res_chain ? 1 : 0; info[5] = (p->lean_chain ? 1 : 0) | (std::max(1, p->chain_split) << 8); info[6] = p->same_group ? -1 : (int32_t)p->groups.size(); info[7] = p->K;
     return MFAS_OK;
 }
 

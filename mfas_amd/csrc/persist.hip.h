@@ -32,9 +32,8 @@ struct PersistArgs {
                                       // LDS words of one staged batch
     int32_t nres, res_chain;   // units [0, nres) are RESIDENT feature units: one workgroup each (blocks K .. K + nres);
                                // res_chain: the (lean) chain owns OUT / HEAD and keeps them + its vector block on chip
-    int32_t lose_step, res_defer;  // res_defer (round 5, two-unit workgroups, 16-bit staging): a unit's arrival and the staging of its batch after next are
-                               // finished while the workgroup already serves its OTHER unit (sweep_resident); lose_step: test hook (MFAS_PERSIST_TEST_LOSE_STEP): candidate 0's chain never publishes this step (-1: off) -- the
-                               // bounded waits must then end the launch with an error instead of hanging
+    int32_t lose_step, _padl;  // lose_step: -1 in the product library; the -DMFAS_TEST_HOOKS variant reads MFAS_PERSIST_TEST_LOSE_STEP: candidate 0's chain
+                               // never publishes this step — the bounded waits must then end the launch with an error instead of hanging
     int32_t T, epoch;          // train steps of this launch, epoch index (statistics slot)
     int64_t N, pos0;           // N_train, epoch * N_train (position in the sample-order table)
     int32_t B, gstep0;         // batch size, epoch * batches-per-epoch (Adam / dropout step counter base)
@@ -170,7 +169,7 @@ struct ResUnit {              // wave-uniform constants of one resident unit
 };
 __device__ __forceinline__ int res_xbo(const ResUnit& un, int which) { return un.xb0 + (which ? un.xbw : 0); }
 
-template <int MB, int NTR, bool X16, int NU, bool DEFER>
+template <int MB, int NTR, bool X16, int NU>
 __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int wg, const int nwg, float* lds, int* ldsw) {
     const SweepArgs& sa = a.sa;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -280,7 +279,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         }
     };
     // cross-wave reduction of a forward partial (fixed order 0..7, as sweep_body) -> partial slot (write-through) -> arrive
-    auto reduce_publish = [&](const ResUnit& un, const f32x4 (&yacc)[MB], const int nv_next, const bool defer_arrival) {
+    auto reduce_publish = [&](const ResUnit& un, const f32x4 (&yacc)[MB], const int nv_next) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
             *reinterpret_cast<f32x4*>(wred + ((wave * MB + mb) << 8) + lane * 4) = yacc[mb];
@@ -297,63 +296,11 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         // Only the MB waves that stored the slab wait for the stores' acknowledgements; the LAST of them to see its own arrive counts
         // the unit's arrival (an LDS ticket).  The other waves go on — the poller (wave 7) already looks for the workgroup's next
         // unit while waves 0 .. MB-1 drain: no workgroup barrier behind the publish any more.
-        if (!defer_arrival) arrive(un.cnt);
+        arrive(un.cnt);
     };
-    // ---- deferred hand-off (DEFER instantiation, selected by a.res_defer = MFAS_RES_DEFER=1; two units per workgroup, 16-bit staging;
-    // measured slower than the default, kept opt-in).  After a unit's step the workgroup sits through
-    // two latencies before it could turn to its other unit: the slab stores' acknowledgements (~1 us, then the arrival) and the round
-    // trip of the table rows of the batch after next (order entry -> row -> registers -> LDS, ~2 us).  Both are only WAITS, so with a
-    // second unit to serve they are left pending: the rows travel by LDS-DMA (one `global_load_lds_dwordx4` per row and wave — a row
-    // of <= 512 columns is the 64 lanes' 16-byte pieces — into the SAME row-major image the cooperative staging writes; no registers,
-    // no store pass; the order entries were fetched by scalar loads under the unit's MFMAs), and once the OTHER unit's dy has been
-    // requested, ONE `s_waitcnt vmcnt(0)` per wave covers stores, copies and dy; there the pending unit's arrival is counted.  When
-    // the first look at the flags finds no unit ready the pending work is finished at once (pick -4): an arrival is never held back
-    // by a wait for a flag.  Every wave passes that wait, and a workgroup barrier follows, before anyone reads the copied rows.
-    // Rows beyond the batch size are never copied: they are the zeros the prologue's cooperative staging left in both buffers.
-    // Arithmetic, reduction order and the staged image are unchanged: results are bit-identical with and without it.
-    constexpr bool CAN_DEFER = DEFER && NU == 2 && X16 && !DMA;      // (its own instantiation: the other forms carry none of it)
-    constexpr int NROWQ = Bp / STEP_NW;        // rows per wave: wave w copies rows w, w + 8, ... (2 or 4: a power of two);  row codes: -1 = zeros (short last batch), -2 = nothing to copy
-    constexpr bool defer_on = CAN_DEFER;
-    int pend = -1;                             // unit whose arrival is pending
-    // (the rows wait in ONE vector register — lane j holds the table row of this wave's j-th piece — not in NROWQ scalars: the merged
-    //  kernel's scalar file is full and every scalar kept across the MFMAs is spilled to lanes of a VGPR.  Either way this form's
-    //  unit loop carries 17-24 spilled VGPRs the default one does not, and loses to it: OPT-IN only)
-    int rowv = -2;
-    auto rows_order = [&](const ResUnit& un, const int t) {
-        const int nv = (int)min((int64_t)a.B, a.N - (int64_t)t * a.B);
-        const int32_t* ord = cand_order(sa.order, sa.g, un.gidx);
-        const int64_t pos = a.pos0 + (int64_t)t * a.B;
-        const int b = wave + STEP_NW * (lane & (NROWQ - 1));      // lanes 0 .. NROWQ-1 matter
-        rowv = b < a.B ? -1 : -2;
-        if (b < nv) rowv = ord ? ord[pos + b] : t * a.B + b;
-    };
-    auto rows_dma = [&](const ResUnit& un, const int dst_word) {
-        const int vpr = un.cc >> 3;            // 16-byte pieces per row
-        const uint32_t dst0 = lds_base + ((uint32_t)dst_word << 2);
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-#pragma unroll
-        for (int j = 0; j < NROWQ; ++j) {
-            const int row = __builtin_amdgcn_readlane(rowv, j);
-            if (row != -2) {
-                const int b = wv + STEP_NW * j;
-                const uint16_t* grow = reinterpret_cast<const uint16_t*>(un.tp) + (int64_t)row * un.width + un.k0;
-                for (int p0 = 0; p0 < vpr; p0 += 64) {
-                    if (p0 + lane < vpr) {
-                        const void* src = row >= 0 ? static_cast<const void*>(grow + ((p0 + lane) << 3)) : zeros;
-                        glds16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((b * un.S + (p0 << 3)) << 1)));
-                    }
-                }
-            }
-        }
-    };
-    // every wave: its copies (and, on the slab-storing waves, the stores) have landed; then the pending unit's arrival
-    auto finish_pending = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-            if (pend == u) arrive(U[u].cnt);
-        pend = -1;
-    };
+    // (Round 5's deferred unit hand-off — the pending arrival and the LDS-DMA copy of the batch after next finished while the workgroup
+    //  already serves its other unit — was a measured negative, 15.1 / 15.5 -> 16.1 / 16.4 us per step at 22 / 28 candidates, and is gone:
+    //  profiles/r05_defer_ab.log, DESIGN_HISTORY.md.)
     constexpr int POLL_TID = STEP_THREADS - 64;      // the unit loop's poller: lane 0 of the last wave (waves 0 .. MB-1 drain the slab stores)
     if (tid == 0) ldsw[4] = 0;
 
@@ -379,7 +326,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     }
                 }
             }
-            reduce_publish(U[u], yacc, (int)min((int64_t)a.B, a.N), false);
+            reduce_publish(U[u], yacc, (int)min((int64_t)a.B, a.N));
             if (1 < a.T) stage(U[u], lds + res_xbo(U[u], 1), 1);
         }
     }
@@ -443,7 +390,6 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                     }
                 }
                 if (pick >= 0 || !pending) break;
-                if constexpr (CAN_DEFER) { if (pend >= 0) { pick = -4; break; } }     // nothing to serve yet: finish the pending arrival / rows first
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 0x3FFu) == 0 && (spins > PERSIST_SPIN_LIMIT || ld_u32_relaxed(abortw) != 0)) {
                     __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -456,13 +402,6 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
         __syncthreads();
         const int pick = ldsw[0];
         if (pick == -3) return;
-        if constexpr (CAN_DEFER) {
-            if (pick == -4) {
-                __syncthreads();   // everyone has read the pick before the poller overwrites it
-                finish_pending();
-                continue;
-            }
-        }
         if (pick < 0) break;
         const int t = nxt[pick];
         __syncthreads();   // everyone has read the pick / step before lane 0 can overwrite them
@@ -486,16 +425,6 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 const float a_ss = a.scal[2 * (int64_t)(a.gstep0 + t)], a_bc2s = a.scal[2 * (int64_t)(a.gstep0 + t) + 1];
                 // this wave's own LDS-DMA copies (batch t+1, requested after the unit's previous step) have landed: nothing else reads them
                 if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                // the other unit's pending arrival and rows: their round trips have run alongside the poll and this unit's dy request
-                if constexpr (CAN_DEFER) {
-                    if (pend >= 0) {      // (always the OTHER unit: a unit cannot be published again before its own arrival)
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        arrive(U[1 - u].cnt);
-                        pend = -1;
-                    }
-                }
-                const bool rows_next = defer_on && fwd && t + 2 < a.T;
-                if constexpr (CAN_DEFER) { if (rows_next) rows_order(un, t + 2); }     // (order entries of the batch after next: scalar loads, back before the MFMAs end)
                 f32x4 yacc[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) yacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -521,7 +450,7 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 PTRACE(2);
                 PTRACE_UNIT(128);   // compute done
                 if (fwd) {
-                    reduce_publish(un, yacc, (int)min((int64_t)a.B, a.N - (int64_t)(t + 1) * a.B), defer_on);
+                    reduce_publish(un, yacc, (int)min((int64_t)a.B, a.N - (int64_t)(t + 1) * a.B));
                 } else {
                     wg_publish_barrier();
                     if (tid == 0) __hip_atomic_fetch_add(un.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -531,14 +460,10 @@ __device__ __forceinline__ void sweep_resident(const PersistArgs& a, const int w
                 if (tid == POLL_TID) nxt[u] = t + 1;
                 cur[u] ^= 1;
                 // batch t+2 into the buffer batch t just vacated: it lands while this unit's chain runs step t+1
-                if (defer_on && fwd) {
-                    pend = u;
-                    if constexpr (CAN_DEFER) { if (rows_next) rows_dma(un, res_xbo(un, cur[u] ^ 1)); }
-                } else if (t + 2 < a.T) stage(un, lds + res_xbo(un, cur[u] ^ 1), t + 2);
+                if (t + 2 < a.T) stage(un, lds + res_xbo(un, cur[u] ^ 1), t + 2);
             }
         }
     }
-    if constexpr (CAN_DEFER) { if (pend >= 0) finish_pending(); }
     // ---- state back to memory (dev evaluation, parameter export and the next epoch's launch read it there)
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -594,7 +519,7 @@ __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_president<MB, NTR, X16, NU, PLAIN, DEFER> — the RESIDENT schedule (the default for small populations at R <= 16): ONE launch per epoch,
+// k_president<MB, NTR, X16, NU, PLAIN> — the RESIDENT schedule (the default for small populations at R <= 16): ONE launch per epoch,
 // blocks [0, K) = the resident lean chain of candidate blockIdx.x, blocks [K, K + nres_wg) = workgroups of resident feature
 // units.  One instantiation per unit form (staging width, tiles per wave, units per workgroup): an instantiation carries exactly
 // the two bodies its grid runs.  (Round 3 also ran the two roles as two kernels on two streams, each with its own register budget — the unit
@@ -603,7 +528,7 @@ __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, c
 // hardware queues, which HIP does not promise: after a few hundred stream creations in one process the second launch queued
 // behind the first and every roll call failed.  One launch cannot be split by the runtime.)
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NTR, bool X16, int NU, bool PLAIN, bool DEFER = false>
+template <int MB, int NTR, bool X16, int NU, bool PLAIN>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs a, const int lds_word) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
@@ -613,7 +538,7 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
     const int K = a.nchain;
     if (!persist_roll_call(a.sync, K, gridDim.x, ldsw)) return;
     if (bid >= K) {
-        sweep_resident<MB, NTR, X16, NU, DEFER>(a, bid - K, a.nres_wg, lds, ldsw);
+        sweep_resident<MB, NTR, X16, NU>(a, bid - K, a.nres_wg, lds, ldsw);
         return;
     }
     uint32_t* abortw = a.sync + (size_t)K * PERSIST_SYNC_STRIDE;
@@ -642,7 +567,11 @@ __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs
         chain_lean<MB, 2, 16, PLAIN>(a.ca, cs, bid, lds, lpre, keep, labp);
         PTRACE(2);
         wg_publish_barrier();
+#ifdef MFAS_TEST_HOOKS
         if (tid == 0 && !(bid == 0 && t == a.lose_step))
+#else
+        if (tid == 0)
+#endif
             __hip_atomic_store(PERSIST_FLAG(a.sync, bid), (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PTRACE(3);
         keep = lean_keep_bits<MB>(a.ca.cands[bid], a.ca.g, cs.gstep + 1);      // (next step's: ~200 integer instructions off the critical path)

@@ -443,7 +443,11 @@ class Population:
         info = (C.c_int32 * 8)()
         _lib.check(self.lib.mfas_population_schedule(self._h, info))
         keys = ("persistent", "resident_units", "resident_workgroups", "units_per_workgroup", "resident_chain", "lean_chain", "groups", "candidates")
-        return dict(zip(keys, (int(x) for x in info)))
+        d = dict(zip(keys, (int(x) for x in info)))
+        # info[5] bits 8..15: CUs one candidate's general chain runs on in the same-group launch (round 6: chain_split; 1 otherwise)
+        d["chain_cus"] = max(1, (d["lean_chain"] >> 8) & 0xFF)
+        d["lean_chain"] &= 0xFF
+        return d
 
     def sweep_profile(self):
         n, ms, by = C.c_int64(0), C.c_double(0), C.c_double(0)

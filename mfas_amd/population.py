@@ -62,17 +62,23 @@ def assign(costs: Sequence[int], world: int) -> List[int]:
 
 
 def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: int, device=None,
-                      cap: int | None = None, failed: bool = False, strict: bool = True):
+                      cap: int | None = None, failed: bool = False, strict: bool = True, fatal: bool = False):
     """All ranks end up with the K accuracies in input order: ONE all_gather of `cap` (index, accuracy) pairs per rank (+ one
     status row) and one device-to-host copy — latency-bound, a few hundred bytes.  `cap` (the largest per-rank share) is known to
     every rank from assign(); without it ceil(K/W)+1 is only an upper bound for round-robin-like assignments, so callers that
     shard with assign() pass it.  `failed`: this rank could not train (all of) its share — it still joins the collective, so
-    nobody hangs.  strict: raise when a candidate was trained by no rank; else return (accuracies with NaN holes, failed ranks)."""
+    nobody hangs.  `fatal` (with failed): the failure is an argument / programming error (a bad configuration, a missing tap) that a
+    re-queue on another rank would only repeat — the status row says so and every rank learns it from the same collective
+    (FATAL_RANKS holds them after the call).  strict: raise when a candidate was trained by no rank; else return (accuracies with
+    NaN holes, failed ranks)."""
+    global FATAL_RANKS
+    FATAL_RANKS = []
     rank, world = dist_info()
     if world == 1:
         out = [float("nan")] * K if not strict else [0.0] * K
         for i, a in zip(local_idx, local_acc):
             out[i] = float(a)
+        FATAL_RANKS = [0] if (failed and fatal) else []
         return out if strict else (out, [0] if failed else [])
     backend = dist.get_backend(_GROUP)
     dev = torch.device("cpu") if backend == "gloo" else (device or torch.device("cuda", torch.cuda.current_device()))
@@ -83,13 +89,14 @@ def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: i
     for j, (i, a) in enumerate(zip(local_idx, local_acc)):
         host[j, 0] = float(i)
         host[j, 1] = float(a)
-    host[cap, 0] = -2.0 if failed else -3.0          # status row
+    host[cap, 0] = (-4.0 if fatal else -2.0) if failed else -3.0          # status row: -3 fine, -2 failed (re-queue), -4 failed for good
     buf = torch.from_numpy(host).to(dev)
     allb = torch.empty((world * (cap + 1), 2), dtype=torch.float64, device=dev)   # rank-major concatenation
     dist.all_gather_into_tensor(allb, buf, group=_GROUP)
     out = [float("nan")] * K
     rows = allb.cpu().numpy().reshape(world, cap + 1, 2)
-    bad = [r for r in range(world) if rows[r, cap, 0] == -2.0]
+    bad = [r for r in range(world) if rows[r, cap, 0] in (-2.0, -4.0)]
+    FATAL_RANKS = [r for r in range(world) if rows[r, cap, 0] == -4.0]
     for r in range(world):
         for i, a in rows[r, :cap]:
             if i >= 0:
@@ -101,13 +108,19 @@ def gather_accuracies(local_idx: Sequence[int], local_acc: Sequence[float], K: i
     return out, bad
 
 
+FATAL_RANKS: list = []      # ranks whose status row of the LAST gather said "failed for good" (set by gather_accuracies)
+FATAL_ERRORS = (ValueError, TypeError, NotImplementedError, AssertionError)
+
+
 def train_sharded(wanted: Sequence[int], owner: Sequence[int], cap: int, K: int, costs: Sequence[int], train_share, device=None):
     """Run `train_share(indices) -> {index: accuracy}` on this rank's share and gather everyone's results (ONE collective when
     nothing goes wrong).  A rank whose share raises — out of memory, a kernel error, a persistent-loop timeout — does not take the
     job down with a hang in the collective: it reports the failure in the gather, and the candidates it could not deliver are
     RE-QUEUED once over the ranks that did not fail (candidates are independent, /root/reference/models/search/ntu_searchable.py:38-94;
     per-candidate seeds make the result independent of who trains it).  If the second attempt fails too, or every rank failed,
-    all ranks raise the same RuntimeError.  (A rank that DIES — killed, segfault — cannot be survived inside one process group:
+    all ranks raise the same RuntimeError.  An argument / programming error (FATAL_ERRORS: a bad configuration or a missing tap is
+    raised only by the rank that owns that candidate) ALSO travels through the gather — every rank enters the collective whatever
+    happened — and is not re-queued: the owning rank re-raises its exception, the others raise a RuntimeError naming it.  (A rank that DIES — killed, segfault — cannot be survived inside one process group:
     torchrun tears the job down.)  Returns the K accuracies (entries outside `wanted` are 0)."""
     rank, world = dist_info()
     mine = [i for i, o in zip(wanted, owner) if o == rank]
@@ -120,15 +133,19 @@ def train_sharded(wanted: Sequence[int], owner: Sequence[int], cap: int, K: int,
     err, got = None, {}
     try:
         got = train_share(mine)
-    except (ValueError, TypeError, NotImplementedError, AssertionError):
-        raise                   # a programming / argument error is the same on every rank: nothing to re-queue, fail loudly here
-    except Exception as e:      # noqa: BLE001 — runtime / device errors: reported through the collective, re-queued below
+    except Exception as e:      # noqa: BLE001 — every failure is reported through the collective: nobody may skip the gather
         err = e
-        import traceback
-        import warnings
-        warnings.warn(f"mfas_amd: rank {rank} failed to train its share of {len(mine)} candidate(s):\n{traceback.format_exc()}")
+        if not isinstance(e, FATAL_ERRORS):     # runtime / device errors: re-queued below
+            import traceback
+            import warnings
+            warnings.warn(f"mfas_amd: rank {rank} failed to train its share of {len(mine)} candidate(s):\n{traceback.format_exc()}")
     have = [i for i in mine if i in got]
-    out, bad = gather_accuracies(have, [got[i] for i in have], K, device, cap=cap, failed=err is not None, strict=False)
+    out, bad = gather_accuracies(have, [got[i] for i in have], K, device, cap=cap, failed=err is not None, strict=False,
+                                 fatal=isinstance(err, FATAL_ERRORS))
+    if FATAL_RANKS:             # the same verdict on every rank, from the same collective
+        if isinstance(err, FATAL_ERRORS):
+            raise err
+        raise RuntimeError(f"rank(s) {FATAL_RANKS} raised an argument / programming error while training their share; nothing was re-queued")
     missing = [i for i in wanted if np.isnan(out[i])]
     if missing:
         good = [r for r in range(world) if r not in bad]

@@ -162,8 +162,10 @@ def timed_search(searcher, seed=0, surrogate_device="cpu"):
     """Run `searcher.search()` under fixed seeds (torch / numpy / random: every decision of the controller is then a function of
     the accuracies the engine returns) with the wall time split into candidate training and controller / surrogate, and a digest
     of the decision stream (every configuration list the controller asked to be trained, in order).  Returns
-    (surrogate dataset, report dict).  Used by `main_searchable_ntu.py --timing`, by bench.py's `config.search_c3` entry (BASELINE
-    configs[3]: --num_samples 50 --search_iterations 5 --max_fusions 4 -> 20 calls, 982 candidates) and by the GPU test of that schedule."""
+    (surrogate dataset, report dict).  Used by bench.py's `config.search_c3` entry (BASELINE
+    configs[3]: --num_samples 50 --search_iterations 5 --max_fusions 4 -> 20 calls, 982 candidates) and by the GPU test of that schedule.
+    (`main_searchable_ntu.py --timing` keeps its own, smaller wrapper: it must time the USER's run — unseeded, random search and N > 1
+    ranks included — without reseeding it or hashing its decisions.)"""
     import hashlib
     import random
     import time

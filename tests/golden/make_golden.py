@@ -763,6 +763,8 @@ def g15():
 def g15merge():
     import glob
     parts = [np.load(f) for f in sorted(glob.glob(os.path.join(HERE, "g15_part_*.npz")))]
+    if parts and int(parts[0]["seeds"][0]) != 0:      # extension run (round 6): the committed fixture holds seeds 0 … n-1, the parts go on from n
+        parts.insert(0, np.load(os.path.join(HERE, "g15_bench_workload.npz")))
     assert parts and all(np.array_equal(p["meta"], parts[0]["meta"]) for p in parts)
     seeds = np.concatenate([p["seeds"] for p in parts])
     assert np.array_equal(seeds, np.arange(len(seeds))), seeds
@@ -1156,6 +1158,8 @@ def g19b():
 def g19bmerge():
     import glob
     parts = [np.load(f) for f in sorted(glob.glob(os.path.join(HERE, "g19b_part_*.npz")))]
+    if parts and int(parts[0]["seeds"][0]) != 0:      # extension run (round 6): committed fixture first, the parts go on from its last seed
+        parts.insert(0, np.load(os.path.join(HERE, "g19b_search_default_streams.npz")))
     assert parts and all(np.array_equal(p["meta"], parts[0]["meta"]) and np.array_equal(p["confs"], parts[0]["confs"]) for p in parts)
     seeds = np.concatenate([p["seeds"] for p in parts])
     assert np.array_equal(seeds, np.arange(len(seeds))), seeds

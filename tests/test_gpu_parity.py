@@ -900,58 +900,6 @@ def test_persistent_schedule_fuzz_bit_identical(dev, seed):
     print("schedule:", sched["default"])
 
 
-@pytest.mark.parametrize("K,mixed,N", [(24, True, 4010), (22, False, 4000), (28, True, 4010)])
-def test_deferred_handoff_bit_identical(dev, K, mixed, N):
-    """Round 5 (late), opt-in form of the resident unit loop (MFAS_RES_DEFER=1, k_president<..., DEFER = true>): two-unit workgroups
-    finish a unit's arrival and the LDS-DMA copy of its batch after next under the OTHER unit's dy request (persist.hip.h).  Measured
-    slower than the default and therefore off, but kept buildable and correct: it only moves WHEN things happen, so statistics (train
-    and dev), parameters and both Adam moments must equal the default run bit for bit — 22 / 24 / 28 candidates (two units per
-    workgroup), N = 4,010 ends every epoch on a 10-row batch (rows past the batch are copied from the zero line), E = 3, and a second
-    train() call goes through the prologue's staging again."""
-    import os
-    from mfas_amd import FeatureTable, Hyper, Population
-    hp = Hyper(R=16, C=60, B=20, bn=False, drpt=0.5, tap_bits=16)
-    rng = np.random.default_rng(11)
-    confs = [np.array(CONFS["c4"])] * K
-    if mixed:
-        confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 2, L)], 1) for L in rng.integers(2, 5, K)]
-    tr = FeatureTable.synthetic(N, 1, dev, torch.bfloat16, snr=0.5)
-    dv = FeatureTable.synthetic(1200, 2, dev, torch.bfloat16, snr=0.5)
-    E = 3
-    nb = -(-N // 20)
-    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / 20, E * nb)
-    g = torch.Generator(device=dev)
-    g.manual_seed(4)
-    order = torch.stack([torch.randperm(N, generator=g, device=dev) for _ in range(E)]).to(torch.int32)
-    out, sched = {}, {}
-    for mode in ("off", "on"):
-        if mode == "on":
-            os.environ["MFAS_RES_DEFER"] = "1"
-        try:
-            pop = Population(hp, confs, dev, drop_seeds=list(range(50, 50 + K)))
-            sched[mode] = pop.schedule()
-            pop.init(list(range(1, K + 1)))
-            stats, status = pop.train(tr, dv, E, etas, order=order)
-            assert not status.any()
-            out[mode] = (stats, [[pop.get_params(k, pl).cpu().numpy() for pl in range(3)] for k in range(K)])
-            # a second call on the same population starts from whichever plane set the first one ended on
-            stats2, status2 = pop.train(tr, dv, 2, etas[:2 * nb], order=order[:2])
-            out[mode] += (stats2, [pop.get_params(k, 0).cpu().numpy() for k in range(K)])
-            pop.close()
-        finally:
-            os.environ.pop("MFAS_RES_DEFER", None)
-    assert sched["on"]["persistent"] and sched["on"] == sched["off"]
-    assert sched["on"]["units_per_workgroup"] == 2
-    assert out["off"][0].tobytes() == out["on"][0].tobytes()
-    assert out["off"][2].tobytes() == out["on"][2].tobytes()
-    for k in range(K):
-        for pl in range(3):
-            assert np.array_equal(out["off"][1][k][pl], out["on"][1][k][pl]), (k, pl)
-        assert np.array_equal(out["off"][3][k], out["on"][3][k]), k
-    assert (out["on"][0]["train_loss_sum"][:, -1] < out["on"][0]["train_loss_sum"][:, 0]).all()      # and it trains
-    assert (out["on"][0]["dev_corrects"] > 0).all()                                                    # every epoch's dev pass ran
-
-
 @pytest.mark.parametrize("seed", range(8))
 def test_same_group_launch_fuzz_bit_identical(dev, seed):
     """Random small populations with the general chain (R = 32 / 64 / 128): the same-group fused launch — chain and sweep of the
@@ -998,11 +946,96 @@ def test_same_group_launch_fuzz_bit_identical(dev, seed):
             assert np.array_equal(out["two-launch"][2][k][pl], out["default"][2][k][pl]), (k, pl)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_chain_split_bit_identical(dev, seed):
+    """Round 6: at R = 113 .. 128 with one batch tile (B <= 16) the same-group launch runs every candidate's cell chain on FOUR CUs
+    (chain.hip.h, chain_split: column split, 16 x 128 exchanges through sentinel-polled pieces, replicated head / softmax, per-cell
+    arrival counters).  The arithmetic per row block is chain_body's, so against the one-CU chain (MFAS_CHAIN_SPLIT=0) and against the
+    two-launch schedule everything must be bit-identical: statistics, W, m, v of every candidate — BatchNorm on / off, dropout on /
+    off, mixed depths (1 .. 4 cells) and non-linearities, C = 60 / 23 / 7, R = 128 / 120 / 113 (padded columns), ragged last batch,
+    bf16 / f32 tables, reduce-in-sweep on / off, 1 .. 10 candidates, a second train() call (parities restart), E = 2 epochs."""
+    import os
+    from mfas_amd import FeatureTable, Hyper, Population
+    rng = np.random.default_rng(6000 + seed)
+    R = int(rng.choice([128, 128, 120, 113]))
+    B = int(rng.choice([16, 16, 12, 5]))
+    bn = bool(rng.integers(0, 2)) or seed == 0
+    drpt = float(rng.choice([0.0, 0.5])) if bn else 0.5
+    C = int(rng.choice([60, 23, 7]))
+    K = int(rng.choice([1, 2, 3, 6, 10]))
+    dtype = [torch.bfloat16, torch.float32][int(rng.integers(0, 2))]
+    N = int(rng.integers(3 * B + 2, 9 * B))
+    if N % B == 1:
+        N += 1
+    no_red = bool(rng.integers(0, 2))
+    hp = Hyper(R=R, C=C, B=B, bn=bn, drpt=drpt, alphas=False)
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in rng.integers(1, 5, K)]
+    if seed == 0:
+        confs = [np.array(CONFS["c4"])] * K
+    tr = FeatureTable.synthetic(N, 1 + seed, dev, dtype, snr=0.5, C=C)
+    dv = FeatureTable.synthetic(2 * B + 3, 100 + seed, dev, dtype, snr=0.5, C=C)
+    nb = -(-N // B)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, 2 * nb)
+    out, sched = {}, {}
+    for mode in ("two-launch", "one-cu", "split"):
+        env = {"two-launch": {"MFAS_SAME_GROUP": "0"}, "one-cu": {"MFAS_CHAIN_SPLIT": "0"}, "split": {}}[mode]
+        if no_red:
+            env = dict(env, MFAS_NO_RED_IN_SWEEP="1")
+        os.environ.update(env)
+        try:
+            pop = Population(hp, confs, dev, drop_seeds=list(range(3, 3 + K)), chunk_cols=128)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        sched[mode] = pop.schedule()
+        pop.init(list(range(1, K + 1)))
+        stats, status = pop.train(tr, dv, 2, etas)
+        planes = [[pop.get_params(k, pl).cpu().numpy() for pl in range(3)] for k in range(K)]
+        stats2, status2 = pop.train(tr, dv, 1, etas[:nb])           # a second call: fresh Adam state, exchange parities from 0 again
+        out[mode] = (stats, status, planes, stats2, [pop.get_params(k, 0).cpu().numpy() for k in range(K)])
+        assert not status.any() and not status2.any(), (mode, status, status2)
+        pop.close()
+    assert sched["split"]["groups"] == -1 and sched["one-cu"]["groups"] == -1 and sched["two-launch"]["groups"] in (1, 2), sched
+    assert sched["split"]["chain_cus"] == 4 and sched["one-cu"]["chain_cus"] == 1, sched
+    assert (out["split"][0]["train_loss_sum"] != 0).all()
+    for ref in ("one-cu", "two-launch"):
+        assert out[ref][0].tobytes() == out["split"][0].tobytes(), (ref, R, B, bn, C, K)
+        assert out[ref][3].tobytes() == out["split"][3].tobytes(), (ref, "second call")
+        for k in range(K):
+            for pl in range(3):
+                assert np.array_equal(out[ref][2][k][pl], out["split"][2][k][pl]), (ref, k, pl)
+            assert np.array_equal(out[ref][4][k], out["split"][4][k]), (ref, k, "second call")
+
+
+def _hooks_variant_loaded():
+    from mfas_amd import _lib
+    return _lib.tuning()["hooks"] == "1"
+
+
+def test_hook_tests_run_on_the_hooks_variant():
+    """The test hooks (MFAS_PERSIST_TEST_LOSE_STEP / _NOT_RESIDENT) are compiled only into the -DMFAS_TEST_HOOKS variant of the library
+    (libmfas_hip_hooks.so); the product library never parses them.  The two tests that need them run here, in a subprocess that
+    loads the variant through MFAS_LIB."""
+    import os, subprocess, sys
+    import __graft_entry__ as ge
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert not _hooks_variant_loaded() or os.environ.get("MFAS_LIB", "").endswith("_hooks.so")
+    if _hooks_variant_loaded():
+        pytest.skip("already inside the hooks-variant run")
+    lib = ge.build_variant("hooks", ["-DMFAS_TEST_HOOKS"])
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                          "lost_dependency_ends_with_an_error or falls_back_to_launch_per_phase_when_never_resident"],
+                         env=dict(os.environ, MFAS_LIB=lib), capture_output=True, text=True, timeout=1200, cwd=root)
+    assert res.returncode == 0 and "2 passed" in res.stdout and "skipped" not in res.stdout, (res.stdout[-2000:], res.stderr[-2000:])
+
+
 def test_persistent_loop_lost_dependency_ends_with_an_error(dev, monkeypatch):
     """The persistent step loop's waits are bounded: when a dependency never arrives (test hook: candidate 0's chain does not
     publish step 3) the launch ends by itself — the starved workgroups time out, set the abort word, everybody leaves — and
     train() reports an error instead of hanging the GPU; the device is usable afterwards."""
     from mfas_amd import FeatureTable, Hyper, Population
+    if not _hooks_variant_loaded():
+        pytest.skip("needs the -DMFAS_TEST_HOOKS variant (run by test_hook_tests_run_on_the_hooks_variant)")
     hp = Hyper(R=16, C=60, B=20, bn=False, drpt=0.5, tap_bits=16)
     confs = [np.array(CONFS["c4"])] * 4
     tr = FeatureTable.synthetic(400, 1, dev, torch.bfloat16, snr=0.5)
@@ -1062,6 +1095,8 @@ def test_resident_schedule_falls_back_to_launch_per_phase_when_never_resident(de
     fixed, per-segment units) every schedule gives the same bits, so a run that switches after epoch 0 or 1 must equal the run
     that never switches — statistics, parameters and both Adam moments."""
     from mfas_amd import FeatureTable, Hyper, Population
+    if not _hooks_variant_loaded():
+        pytest.skip("needs the -DMFAS_TEST_HOOKS variant (run by test_hook_tests_run_on_the_hooks_variant)")
     hp = Hyper(R=16, C=60, B=20, bn=True, drpt=0.5, alphas=True, tap_bits=16)
     rng = np.random.default_rng(11)
     K = 5

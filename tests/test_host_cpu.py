@@ -37,6 +37,58 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().mfas_version() >= 100
 
 
+def test_empty_environment_selects_the_tested_defaults():
+    """The library's switches live in ONE struct parsed in ONE place (mfas_hip.hip::tuning_from_env, at create / plan time).  With no
+    MFAS_* variable set the parsed set is exactly the defaults the suites run; every documented variable moves exactly its own
+    field; the product library never parses the test hooks; INTEGRATION.md's table names every switch (and nothing else in the
+    engine sources calls getenv, apart from the process-wide MFAS_NO_ROCTX marker switch)."""
+    code = r"""
+import sys, os, json
+sys.path.insert(0, %r)
+from mfas_amd import _lib
+print(json.dumps(_lib.tuning()))
+""" % ROOT
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("MFAS_")}
+
+    def parsed(**extra):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(clean, **extra), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        import json
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    defaults = {"persist": "-1", "no_lean_chain": "0", "persist_no_resident": "0", "persist_no_res_chain": "0", "subchunks": "0",
+                "subchunk_skip": "0", "groups": "0", "same_group": "-1", "no_tap_major": "0", "force_tap_major": "0", "no_red_in_sweep": "0",
+                "occ_bytes": "-1", "no_xcd_placement": "0", "n_xcd": "0", "persist_trace": "0", "nt": "-1", "eval_no_x16": "0",
+                "eval_no_msplit": "0", "eval_no_b3": "0", "eval_no_wl": "0", "no_gather": "0", "gather_verbose": "0", "no_plain_chain": "0",
+                "persist_verbose": "0", "prof_every": "16", "chain_split": "-1", "test_not_resident": "-1", "test_lose_step": "-1", "hooks": "0"}
+    assert parsed() == defaults
+    env_of = {"persist": ("MFAS_PERSIST", "0", "0"), "no_lean_chain": ("MFAS_NO_LEAN_CHAIN", "1", "1"),
+              "persist_no_resident": ("MFAS_PERSIST_NO_RESIDENT", "1", "1"), "persist_no_res_chain": ("MFAS_PERSIST_NO_RES_CHAIN", "1", "1"),
+              "subchunks": ("MFAS_SUBCHUNKS", "4", "4"), "subchunk_skip": ("MFAS_SUBCHUNK_SKIP", "3", "3"), "groups": ("MFAS_GROUPS", "2", "2"),
+              "same_group": ("MFAS_SAME_GROUP", "2", "2"), "no_tap_major": ("MFAS_NO_TAP_MAJOR", "1", "1"),
+              "force_tap_major": ("MFAS_FORCE_TAP_MAJOR", "1", "1"), "no_red_in_sweep": ("MFAS_NO_RED_IN_SWEEP", "1", "1"),
+              "occ_bytes": ("MFAS_OCC_BYTES", "3e8", "3e+08"), "no_xcd_placement": ("MFAS_NO_XCD_PLACEMENT", "1", "1"), "n_xcd": ("MFAS_XCDS", "4", "4"),
+              "persist_trace": ("MFAS_PERSIST_TRACE", "1", "1"), "nt": ("MFAS_NT", "1", "1"), "eval_no_x16": ("MFAS_EVAL_NO_X16", "1", "1"),
+              "eval_no_msplit": ("MFAS_EVAL_NO_MSPLIT", "1", "1"), "eval_no_b3": ("MFAS_EVAL_NO_B3", "1", "1"), "eval_no_wl": ("MFAS_EVAL_NO_WL", "1", "1"),
+              "no_gather": ("MFAS_NO_GATHER", "1", "1"), "gather_verbose": ("MFAS_GATHER_VERBOSE", "1", "1"),
+              "no_plain_chain": ("MFAS_NO_PLAIN_CHAIN", "1", "1"), "persist_verbose": ("MFAS_PERSIST_VERBOSE", "2", "2"),
+              "prof_every": ("MFAS_PROF_EVERY", "4", "4"), "chain_split": ("MFAS_CHAIN_SPLIT", "0", "0")}
+    assert set(env_of) | {"test_not_resident", "test_lose_step", "hooks"} == set(defaults)
+    everything = parsed(**{var: val for var, val, _ in env_of.values()})
+    for field, (var, val, shown) in env_of.items():
+        assert everything[field] == shown, (field, everything[field])
+    # the product library does not parse the hooks
+    hooked = parsed(MFAS_PERSIST_TEST_NOT_RESIDENT="1", MFAS_PERSIST_TEST_LOSE_STEP="3")
+    assert hooked == defaults
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for var, _, _ in env_of.values():
+        assert var in doc, var
+    src = "".join(open(os.path.join(ROOT, "mfas_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "mfas_amd", "csrc"))
+                  if f.endswith((".hip", ".hip.h")))
+    body = src.split("static Tuning tuning_from_env()")[1].split("extern \"C\" int mfas_tuning_describe")[0]
+    assert src.count("getenv(") - body.count("getenv(") == 1, "a getenv outside tuning_from_env (other than MFAS_NO_ROCTX)"
+
+
 def test_struct_layouts_match_header(tmp_path):
     """The ctypes mirrors must match what a C compiler makes of include/mfas_hip.h (sizes and key offsets)."""
     from mfas_amd import _lib
@@ -417,6 +469,23 @@ try:
 except RuntimeError as e:
     raised = "every rank failed" in str(e)
 assert raised
+# 4. an argument error that only ONE rank sees (a bad configuration in its share, engine.py raises ValueError for it): that rank
+#    re-raises it, the other learns of it from the same gather and raises too — nobody is left waiting in the collective, and
+#    nothing is re-queued (one call of `share` per rank)
+calls.clear()
+def bad_conf(idx):
+    calls.append(list(idx))
+    if rank == 1:
+        raise ValueError("configuration entry out of range")
+    return {{i: 0.01 * (i + 1) for i in idx}}
+try:
+    P.train_sharded(wanted, owner, cap, K, costs, bad_conf)
+    verdict = "returned"
+except ValueError as e:
+    verdict = "value" if rank == 1 and "out of range" in str(e) else "wrong"
+except RuntimeError as e:
+    verdict = "runtime" if rank == 0 and "[1]" in str(e) and "argument / programming error" in str(e) else "wrong"
+assert verdict == ("value" if rank == 1 else "runtime") and len(calls) == 1, (verdict, calls)
 print("rank", rank, "requeue ok", flush=True)
 dist.destroy_process_group()
 """
