@@ -678,6 +678,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
         }
     } else if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
+    } else if (Cp <= 64 && !g.multitask) {
+        // (round 6: <= 64 classes, single task — every NTU / AV-MNIST head — take the eight-lanes-per-row form written for the lean chain:
+        //  ~1/3 of the instructions on the serial path; chain_body and chain_split call the same function, so every schedule of the
+        //  general chain still rounds identically)
+        if (tid < 8 * Bp) softmax_rows_lean<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
     } else if (tid < LPR * Bp) {
         softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
     }
@@ -1842,10 +1847,10 @@ __device__ __forceinline__ f32x4 xch_wait(const float* base, const int64_t idx, 
 }
 
 // LDS floats of chain_split<NS> (host: launch size)
-template <int NS> __host__ __device__ constexpr int chain_split_vec_floats(int Cp) { return 3 * (MFAS_MAX_CELLS * 5 * (8 / NS) * 16 + Cp); }
 template <int NS> __host__ __device__ constexpr size_t chain_split_lds_floats(int Rp, int Cp) {
-    return (size_t)2 * 16 * (Rp + 4) + (size_t)16 * (Cp + 4) + (size_t)MFAS_MAX_CELLS * Rp + 48 + 16 +
-           (size_t)MFAS_MAX_CELLS * (8 / NS) * 256 + (size_t)chain_split_vec_floats<NS>(Cp) + (size_t)2 * (8 / NS) * 8 * 256;
+    return (size_t)2 * 16 * (Rp + 4) + (size_t)16 * (Cp + 4) + (size_t)MFAS_MAX_CELLS * (8 / NS) * 16 + 48 + 16 +
+           (size_t)MFAS_MAX_CELLS * (8 / NS) * 256 + (size_t)(MFAS_MAX_CELLS * 5 * (8 / NS) * 16 + Cp) + (size_t)(8 / NS) * 8 * 256 +
+           (size_t)2 * MFAS_MAX_CELLS * (8 / NS) * 256 + (size_t)(8 / NS) * 256;
 }
 
 template <int NS>
@@ -1853,6 +1858,8 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
 #ifdef MFAS_CHAIN_TIMING
     const unsigned long long ct0 = __builtin_readcyclecounter();
 #define CS_STAMP(slot) do { if (threadIdx.x == 0 && bid == 0 && part == 0 && cs.gstep == 3) a.status[64 + (slot)] = (int32_t)(__builtin_readcyclecounter() - ct0); } while (0)
+    // absolute time (100 MHz): entry / end of the chain in steps 3 and 4 -> the step period and what of it is the chain
+    if (threadIdx.x == 0 && bid == 0 && part == 0 && (cs.gstep == 3 || cs.gstep == 4)) a.status[64 + 23 + 2 * (cs.gstep - 3)] = (int32_t)wall_clock64();
 #else
 #define CS_STAMP(slot) do { } while (0)
 #endif
@@ -1868,27 +1875,36 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
     float* xo_l = lds;                                   // [2][16][SX] out_i ping-pong; backward: dy_i
     float* dy_l = xo_l;
     float* lg_l = xo_l + 2 * Bp * SX;                    // [16][SC]
-    float* rstd_l = lg_l + Bp * SC;                      // [L][Rp]
-    float* red_l = rstd_l + MFAS_MAX_CELLS * Rp;         // [48]
+    float* rstd_l = lg_l + Bp * SC;                      // [L][own columns]
+    float* red_l = rstd_l + MFAS_MAX_CELLS * (8 / NS) * 16;   // [48]
     int* lab_l = reinterpret_cast<int*>(red_l + 48);     // [16]
     float* yf_l = reinterpret_cast<float*>(lab_l + 16);  // [L][NRO][256]  this part's reduced feature sums
     constexpr int NCOL = NRO * 16;                       // this part's columns
-    float* vl = yf_l + MFAS_MAX_CELLS * NRO * 256;       // [3 planes][L][5 kinds][NCOL] | [3][Cp] head bias
+    float* vl = yf_l + MFAS_MAX_CELLS * NRO * 256;       // [L][5 kinds][NCOL] | [Cp] head bias: the W plane (Adam moments: read where they are stepped)
     const int nvec = MFAS_MAX_CELLS * 5 * NCOL;
     const int vplane = nvec + Cp;
-    float* tb = vl + 3 * vplane;                         // [2][NRO * 8][256] weight tiles of the current / the next product
-    const int64_t sav_plane = (int64_t)MFAS_MAX_CELLS * nrb * MB * 256;
+    // ONE tile buffer: a product's tiles are read (main + helper waves) BEFORE the product's barrier, the next product's are written
+    // behind it — and everything is kept under 80 KB so that two workgroups of the launch (its dynamic LDS size is also the sweep units')
+    // still share a CU
+    float* tb = vl + vplane;                             // [NRO * 8][256] weight tiles of the current product
+    float* sv_l = tb + NRO * 8 * 256;                    // [2: act, x-hat][L][NRO][256] saved for the backward pass (chain_body: L2 scratch)
+    float* odd_l = sv_l + 2 * MFAS_MAX_CELLS * NRO * 256; // [NRO][256] the odd k-blocks' MFMA chain of a product, computed by the helper wave
 
     float* W = a.plane;
     float* Mv = a.plane + a.plane_stride;
     float* Vv = Mv + a.plane_stride;
     float* sb = a.stepbuf + cd.step_off;
-    float* sav = sb + g.sb_sav;
     const int64_t cvec_off = cd.vec_off;
     int nlbits = 0;
 #pragma unroll
     for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
     const int cgidx = cd.gidx;
+    // the candidate record's offsets the cell loops need, read ONCE (behind a barrier a field of `cd` is a fresh scalar load: a few hundred
+    // cycles in front of every product's tile requests)
+    const int64_t oP1 = cd.seg_off[1][2], oP2 = cd.seg_off[2][2], oP3 = cd.seg_off[3][2];
+    const int64_t oT1 = cd.outT_off[1], oT2 = cd.outT_off[2], oT3 = cd.outT_off[3], oHT = cd.headT_off;
+    auto offP = [&](const int i) { return i == 1 ? oP1 : (i == 2 ? oP2 : oP3); };
+    auto offT = [&](const int i) { return i == 1 ? oT1 : (i == 2 ? oT2 : oT3); };
     const int nvalid = cs.nvalid;
     const float nf = (float)nvalid;
     const AdamC ac = adam_consts(a.ac, cs.ss, cs.bc2s);
@@ -1903,21 +1919,25 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
     const int64_t xoth_par = xq + (int64_t)(a.xpar ^ 1) * (XCH_SLOTS * 8 * 256);
 
     // ---- entry: everything that does not depend on the step's data is requested first
-    if (tid < Bp) {
-        int lab = 0;
-        if (tid < nvalid) {
-            const int32_t* ord = cand_order(a.order, g, cd.gidx);
-            const int64_t row = ord ? (int64_t)ord[cs.pos_t + tid] : (int64_t)(cs.base_t + tid);
-            lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;
-        }
-        lab_l[tid] = lab;
+    // (the labels — order entry -> label: two dependent loads behind the candidate record — are requested here and only dropped into LDS
+    //  in front of the head's barrier: nothing at entry waits for them)
+    int lab_r = 0;
+    if (tid < Bp && tid < nvalid) {
+        const int32_t* ord = cand_order(a.order, g, cd.gidx);
+        const int64_t row = ord ? (int64_t)ord[cs.pos_t + tid] : (int64_t)(cs.base_t + tid);
+        lab_r = g.loss_mode == 0 ? a.tab.label[row] : (int)row;
     }
     // the head's tiles: class block (wave - 4) of every part, in registers until the head product
-    f32x4 hw[8];
+    // (wave w: class block w & 3, the even (w < 4) or odd (w >= 4) k-blocks — chain_body's two MFMA chains on two waves; four tiles =
+    //  16 registers per wave: eight cost the 128-register build spills)
+    f32x4 hw[4];
+    const int hcb = wave & 3, hpar = wave >> 2;
+    const bool head_w = hcb < ncb;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) hw[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool head_w = wave >= 4 && wave - 4 < ncb;
-    if (head_w) issue_tiles<false>(hw, W, cd.head_off + (int64_t)(wave - 4) * nrb * 256, nrb, lane);
+    for (int u = 0; u < 4; ++u) {
+        hw[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (head_w) hw[u] = *reinterpret_cast<const f32x4*>(W + cd.head_off + ((int64_t)hcb * nrb + 2 * u + hpar) * 256 + lane * 4);
+    }
     // tile staging: the NRO * 8 tiles of a product (own row blocks x k-blocks; fewer k-blocks for the head's transpose), wave w takes
     // tiles w, w + 8, ...: tile e = (own row block e / nk, k-block e % nk), source = base + (rb0 + e / nk) * nk * 256 + (e % nk) * 256
     f32x4 stg[NRO];
@@ -1937,22 +1957,25 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             if (e < NRO * nk) *as_lds(reinterpret_cast<f32x4*>(dst + (j * 8 + k) * 256 + lane * 4)) = stg[u];
         }
     };
-    if (L > 1) stage_issue(W, cd.seg_off[1][2], nrb);        // P_1 -> tb[1]
+    if (L > 1) stage_issue(W, oP1, nrb);        // P_1
     // this part's pieces of the OTHER parity back to "not written" (read by nobody in this launch)
     for (int e = tid; e < XCH_SLOTS * NRO * 64; e += CHAIN_THREADS) {
         const int s = e / (NRO * 64), r = e - s * (NRO * 64);
         stc4<true>(a.xch, xoth_par + ((int64_t)s * 8 + rb0) * 256 + r * 4, __builtin_bit_cast(f32x4, (u32x4){XCH_SENT, XCH_SENT, XCH_SENT, XCH_SENT}));
     }
-    // vector block: own columns of every cell (W, m, v), head bias
-    for (int e = tid; e < nvec; e += CHAIN_THREADS) {
-        const int i = e / (5 * NCOL), r5 = e - i * (5 * NCOL), kind = r5 / NCOL, c = r5 - kind * NCOL;
-        const int64_t o = cvec_off + (int64_t)i * g.vec_cell_stride + kind * Rp + rb0 * 16 + c;
-        vl[e] = W[o]; vl[vplane + e] = Mv[o]; vl[2 * vplane + e] = Vv[o];
+    // vector block (W plane): own columns of every cell, head bias — REQUESTED here (two elements per thread cover 4 x 5 x NCOL <= 1024),
+    // dropped into LDS behind the slab sums below: every load of the entry is in flight at once (one round trip, not one per loop)
+    static_assert(MFAS_MAX_CELLS * 5 * (8 / NS) * 16 <= 2 * CHAIN_THREADS, "two vector elements per thread");
+    float vreg[2] = {0.f, 0.f}, vbias = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + u * CHAIN_THREADS;
+        if (e < nvec) {
+            const int i = e / (5 * NCOL), r5 = e - i * (5 * NCOL), kind = r5 / NCOL, c = r5 - kind * NCOL;
+            vreg[u] = W[cvec_off + (int64_t)i * g.vec_cell_stride + kind * Rp + rb0 * 16 + c];
+        }
     }
-    for (int e = tid; e < Cp; e += CHAIN_THREADS) {
-        const int64_t o = cvec_off + g.vec_head + e;
-        vl[nvec + e] = W[o]; vl[vplane + nvec + e] = Mv[o]; vl[2 * vplane + nvec + e] = Vv[o];
-    }
+    if (tid < Cp) vbias = W[cvec_off + g.vec_head + tid];
     // reduced feature sums of the own row blocks: [L][NRO][64 lanes] float4 items
     {
         const int n = L * NRO * 64;
@@ -1968,7 +1991,7 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
                 const int ns = cd.nch_s[i], nch = ns + cd.nch_v[i];
                 const int64_t pbase = sbo + g.sb_part + (((int64_t)cd.part_cell_off[i] * nrb * MB) << 8) + ((int64_t)rb0 * 64 + r) * 4;
                 f32x4 accS = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
-                constexpr int PB = 8;
+                constexpr int PB = 10;      // (conf 4 at 256-column chunks: <= 10 slabs per cell — ONE round of loads; 12 spill in the 128-register build)
                 for (int ch0 = 0; ch0 < nch; ch0 += PB) {
                     f32x4 p8[PB];
 #pragma unroll
@@ -1982,7 +2005,25 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             }
         }
     }
-    if (L > 1) stage_store(tb + 1 * (NRO * 8 * 256), nrb);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + u * CHAIN_THREADS;
+        if (e < nvec) vl[e] = vreg[u];
+    }
+    if (tid < Cp) vl[nvec + tid] = vbias;
+    // dropout keep-bits of this lane's four elements, bit 4 i + q for cell i: hashed a cell AHEAD (behind the exchange store, while the
+    // other parts' pieces are in flight) and kept for the backward pass — same hash, same bits as chain_body's in-place calls
+    uint32_t keepm = 0;
+    auto keep_bits = [&](const int i) {
+        if (g.use_drop && main_w) {
+            const int r = rb * 16 + l15;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                keepm |= (drop_keep(h0, i, (uint32_t)((4 * lg + q) * R + r), g.drop_thr) ? 1u : 0u) << (4 * i + q);
+        }
+    };
+    keep_bits(0);
+    if (L > 1) stage_store(tb, nrb);
     CS_STAMP(22);
     __syncthreads();
     CS_STAMP(0);
@@ -1998,22 +2039,23 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             for (int q = 0; q < 4; ++q) dst[(4 * lg + q) * SX + prb * 16 + l15] = v[q];
         }
     };
-    // acc += X[16][16 nk] . tiles (LDS, [nk][256]): chain_body's even / odd chains
-    auto mma_lds = [&](f32x4& acc, const float* X, const int sx, const float* tiles, const int nk) {
-        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+    // acc += X[16][16 nk] . tiles (LDS, [nk][256]) in chain_body's two MFMA chains — even k-blocks on top of acc, odd k-blocks from zero,
+    // summed at the end — but the chains run on TWO waves: main wave w the even one, helper wave w + NRO (another SIMD) the odd one,
+    // handed over through LDS at a workgroup barrier every wave of the part passes (mma_half + the barrier + `acc += odd`): same sums
+    auto mma_half = [&](f32x4& acc, const float* X, const int sx, const float* tiles, const int nk, const int odd) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u2 = 0; u2 < 4; ++u2) {
+            const int u = 2 * u2 + odd;
             if (u < nk) {
                 const f32x4 w4 = *as_lds(reinterpret_cast<const f32x4*>(tiles + u * 256 + lane * 4));
                 const f32x4 x4 = *reinterpret_cast<const f32x4*>(X + l15 * sx + u * 16 + 4 * lg);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (u & 1) acc2 = MFMA16(x4[q], w4[q], acc2);
-                    else acc = MFMA16(x4[q], w4[q], acc);
-                }
+                for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], w4[q], acc);
             }
-        acc += acc2;
+        }
     };
+    const bool help_w = wave >= NRO && wave < 2 * NRO;   // helper of main wave (wave - NRO)
+    static_assert(2 * (8 / NS) <= 4, "main + helper waves below the head waves");
     const int vcol = (main_w ? wave : 0) * 16 + l15;     // column inside the part's vector block
 
     // ------------------------------------------------------------------ forward chain
@@ -2022,8 +2064,8 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
         // next product's tiles: P_{i+1} -> tb[(i+1) & 1]; after the last cell the first backward product (head^T, ncb k-blocks) -> tb[L & 1]
         const bool st_fw = i + 1 < L && i >= 1;          // (P_1 was staged at entry)
         const bool st_hd = i + 1 == L;
-        if (st_fw) stage_issue(W, cd.seg_off[i + 1][2], nrb);
-        else if (st_hd) stage_issue(a.wt, cd.headT_off, ncb);
+        if (st_fw) stage_issue(W, offP(i + 1), nrb);
+        else if (st_hd) stage_issue(a.wt, oHT, ncb);
         const float* xprev = xo_l + ((i + 1) & 1) * Bp * SX;
         float* xcur = xo_l + (i & 1) * Bp * SX;
         if (main_w) {
@@ -2036,7 +2078,11 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             float gam = 1.f, bet = 0.f;
             if (g.bn) { gam = vc[VEC_G * NCOL + vcol]; bet = vc[VEC_BE * NCOL + vcol]; }
             f32x4 acc = *as_lds(reinterpret_cast<const f32x4*>(yf_l + ((i * NRO + wave) << 8) + lane * 4));
-            if (i > 0) mma_lds(acc, xprev, SX, tb + (i & 1) * (NRO * 8 * 256) + wave * 8 * 256, nrb);
+            if (i > 0) {
+                mma_half(acc, xprev, SX, tb + wave * 8 * 256, nrb, 0);
+                lds_barrier();
+                acc += *as_lds(reinterpret_cast<const f32x4*>(odd_l + wave * 256 + lane * 4));
+            }
             if (i == 1) CS_STAMP(13);
             float av[4];
             float s = 0.f;
@@ -2067,7 +2113,7 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
                     zv[q] = xh * gam + bet;
                 }
                 if (lg == 0) {
-                    rstd_l[i * Rp + r] = rstd;
+                    rstd_l[i * NCOL + vcol] = rstd;
                     if (colok) {
                         float rm = vc[VEC_RM * NCOL + vcol], rv = vc[VEC_RV * NCOL + vcol];
                         const float unb = var * (nf / (nf - 1.0f));
@@ -2077,24 +2123,25 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
                         W[vb + VEC_RV * Rp + r] = rv;
                     }
                 }
-                *reinterpret_cast<f32x4*>(sav + sav_plane + ((((int64_t)i * nrb + rb) * MB) << 8) + lane * 4) = xh4;
+                *as_lds(reinterpret_cast<f32x4*>(sv_l + ((MFAS_MAX_CELLS + i) * NRO + wave) * 256 + lane * 4)) = xh4;
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) zv[q] = av[q];
             }
-            *reinterpret_cast<f32x4*>(sav + ((((int64_t)i * nrb + rb) * MB) << 8) + lane * 4) = (f32x4){av[0], av[1], av[2], av[3]};
+            *as_lds(reinterpret_cast<f32x4*>(sv_l + (i * NRO + wave) * 256 + lane * 4)) = (f32x4){av[0], av[1], av[2], av[3]};
             float* xo_g = sb + g.sb_xo + (int64_t)i * Bp * Rp;
             f32x4 o4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int b = 4 * lg + q;
                 float o = zv[q];
-                if (g.use_drop) o = drop_keep(h0, i, (uint32_t)(b * R + r), g.drop_thr) ? o * g.drop_scale : 0.0f;
+                if (g.use_drop) o = ((keepm >> (4 * i + q)) & 1u) ? o * g.drop_scale : 0.0f;
                 if (!(colok && b < nvalid)) o = 0.0f;
                 o4[q] = o;
             }
             stc4<true>(a.xch, xcur_par + ((int64_t)i * 8 + rb) * 256 + lane * 4, o4);     // slot i: out_i, first thing out
             if (i == 1) CS_STAMP(14);
+            if (i + 1 < L) keep_bits(i + 1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int b = 4 * lg + q;
@@ -2102,8 +2149,16 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
                 stc1<true>(xo_g + b * Rp + r, o4[q]);
             }
         }
-        if (st_fw) stage_store(tb + ((i + 1) & 1) * (NRO * 8 * 256), nrb);
-        else if (st_hd) stage_store(tb + (L & 1) * (NRO * 8 * 256), ncb);
+        if (!main_w && i > 0) {         // the odd chain of main wave (wave - NRO), or nothing: every wave meets the product's barrier
+            if (help_w) {
+                f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+                mma_half(acc2, xprev, SX, tb + (wave - NRO) * 8 * 256, nrb, 1);
+                *as_lds(reinterpret_cast<f32x4*>(odd_l + (wave - NRO) * 256 + lane * 4)) = acc2;
+            }
+            lds_barrier();
+        }
+        if (st_fw) stage_store(tb, nrb);
+        else if (st_hd) stage_store(tb, ncb);
         if (i == 1) CS_STAMP(15);
         fetch_others(i, xcur);
         if (i == 1) CS_STAMP(16);
@@ -2112,19 +2167,37 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
 
     CS_STAMP(5);
     // ------------------------------------------------------------------ head (replicated) + loss
-    if (head_w) {
+    {
+        // logits (replicated on every part): class block hcb by the wave pair (hcb, hcb + 4) — even / odd k-blocks, chain_body's two chains;
+        // the odd sums cross through the activation buffer the last cell did not write
         const float* xl = xo_l + ((L - 1) & 1) * Bp * SX;
-        f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-        const int c = (wave - 4) * 16 + l15;
-        const float bias = vl[nvec + c];
-        mma_tiles<1>(acc, xl, SX, hw, nrb, lane);
+        float* hodd = xo_l + (L & 1) * Bp * SX;          // [ncb][256]
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (head_w) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lg_l[(4 * lg + q) * SC + c] = acc[0][q] + bias;
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xl + l15 * SX + (2 * u + hpar) * 16 + 4 * lg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = MFMA16(x4[q], hw[u][q], acc);
+            }
+            if (hpar) *as_lds(reinterpret_cast<f32x4*>(hodd + hcb * 256 + lane * 4)) = acc;
+        }
+        lds_barrier();
+        if (head_w && !hpar) {
+            acc += *as_lds(reinterpret_cast<const f32x4*>(hodd + hcb * 256 + lane * 4));
+            const int c = hcb * 16 + l15;
+            const float bias = vl[nvec + c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lg_l[(4 * lg + q) * SC + c] = acc[q] + bias;
+        }
     }
+    if (tid < Bp) lab_l[tid] = lab_r;
     lds_barrier();
     CS_STAMP(6);
     if (g.loss_mode == 1) {
         if (tid < 4 * Bp) bce_rows(lg_l, SC, red_l, Bp, lab_l, a.tab.multilabel, a.pos_w, C, Cp, nvalid, tid);
+    } else if (Cp <= 64 && !g.multitask) {
+        if (tid < 8 * Bp) softmax_rows_lean<MB>(a, lg_l, SC, red_l, lab_l, nvalid, nf, tid);
     } else if (tid < LPR * Bp) {
         softmax_rows<MB>(a, cs, lg_l, SC, red_l, lab_l, nvalid, nf, tid, cand_order(a.order, g, cgidx));
     }
@@ -2149,7 +2222,7 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             float gsum = 0.f;
             for (int b = 0; b < Bp; ++b) gsum += lg_l[b * SC + hc];
             const int64_t o = cvec_off + g.vec_head + hc;
-            float w = vl[nvec + hc], m = vl[vplane + nvec + hc], v = vl[2 * vplane + nvec + hc];
+            float w = vl[nvec + hc], m = Mv[o], v = Vv[o];
             adam1(w, m, v, gsum, ac);
             W[o] = w; Mv[o] = m; Vv[o] = v;
         }
@@ -2161,7 +2234,7 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
         CS_STAMP(8 + (L - 1 - i));
         const int j = L - 1 - i;                          // backward cell j reads tb[(L + j) & 1]
         const bool st_bw = i >= 1;                        // next product: d out_{i-1} = dy_i . OUT_i (transposed tiles of cell i)
-        if (st_bw) stage_issue(a.wt, cd.outT_off[i], nrb);
+        if (st_bw) stage_issue(a.wt, offT(i), nrb);
         const bool from_head = (i == L - 1);
         const float* src = from_head ? lg_l : dy_l + ((i + 1) & 1) * Bp * SX;
         const int sstride = from_head ? SC : SX;
@@ -2174,21 +2247,23 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             const int r = rb * 16 + l15;
             const bool colok = r < R;
             float gr = 0.f;
-            if (g.bn) gr = vc[VEC_G * NCOL + vcol] * rstd_l[i * Rp + r];
+            if (g.bn) gr = vc[VEC_G * NCOL + vcol] * rstd_l[i * NCOL + vcol];
             const int64_t ob = vb + VEC_B * Rp + r, og = vb + VEC_G * Rp + r, obe = vb + VEC_BE * Rp + r;
             float pw[3] = {0.f, 0.f, 0.f}, pm[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f};
             if (lg == 0 && colok) {
-                pw[0] = vc[VEC_B * NCOL + vcol]; pm[0] = vc[vplane + VEC_B * NCOL + vcol]; pv[0] = vc[2 * vplane + VEC_B * NCOL + vcol];
+                pw[0] = vc[VEC_B * NCOL + vcol]; pm[0] = Mv[ob]; pv[0] = Vv[ob];
                 if (g.bn) {
-                    pw[1] = vc[VEC_G * NCOL + vcol]; pm[1] = vc[vplane + VEC_G * NCOL + vcol]; pv[1] = vc[2 * vplane + VEC_G * NCOL + vcol];
-                    pw[2] = vc[VEC_BE * NCOL + vcol]; pm[2] = vc[vplane + VEC_BE * NCOL + vcol]; pv[2] = vc[2 * vplane + VEC_BE * NCOL + vcol];
+                    pw[1] = vc[VEC_G * NCOL + vcol]; pm[1] = Mv[og]; pv[1] = Vv[og];
+                    pw[2] = vc[VEC_BE * NCOL + vcol]; pm[2] = Mv[obe]; pv[2] = Vv[obe];
                 }
             }
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(sav + ((((int64_t)i * nrb + rb) * MB) << 8) + lane * 4);
+            const f32x4 a4 = *as_lds(reinterpret_cast<const f32x4*>(sv_l + (i * NRO + wave) * 256 + lane * 4));
             f32x4 xh4 = {0.f, 0.f, 0.f, 0.f};
-            if (g.bn) xh4 = *reinterpret_cast<const f32x4*>(sav + sav_plane + ((((int64_t)i * nrb + rb) * MB) << 8) + lane * 4);
+            if (g.bn) xh4 = *as_lds(reinterpret_cast<const f32x4*>(sv_l + ((MFAS_MAX_CELLS + i) * NRO + wave) * 256 + lane * 4));
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            mma_lds(acc, src, sstride, tb + ((L + j) & 1) * (NRO * 8 * 256) + wave * 8 * 256, nkk);
+            mma_half(acc, src, sstride, tb + wave * 8 * 256, nkk, 0);
+            lds_barrier();
+            acc += *as_lds(reinterpret_cast<const f32x4*>(odd_l + wave * 256 + lane * 4));
             if (i == 2) CS_STAMP(17);
             float dz[4];
             float sdz = 0.f, sdzx = 0.f;
@@ -2196,7 +2271,7 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             for (int q = 0; q < 4; ++q) {
                 const int b = 4 * lg + q;
                 float d = acc[q];
-                if (g.use_drop) d = drop_keep(h0, i, (uint32_t)(b * R + r), g.drop_thr) ? d * g.drop_scale : 0.0f;
+                if (g.use_drop) d = ((keepm >> (4 * i + q)) & 1u) ? d * g.drop_scale : 0.0f;
                 if (!(b < nvalid)) d = 0.f;
                 dz[q] = d;
                 sdz += d;
@@ -2244,7 +2319,15 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
                 }
             }
         }
-        if (st_bw) stage_store(tb + ((L + j + 1) & 1) * (NRO * 8 * 256), nrb);
+        if (!main_w) {
+            if (help_w) {
+                f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+                mma_half(acc2, src, sstride, tb + (wave - NRO) * 8 * 256, nkk, 1);
+                *as_lds(reinterpret_cast<f32x4*>(odd_l + (wave - NRO) * 256 + lane * 4)) = acc2;
+            }
+            lds_barrier();
+        }
+        if (st_bw) stage_store(tb, nrb);
         if (i == 2) CS_STAMP(19);
         if (i >= 1) fetch_others(4 + j, dcur);
         if (i == 2) CS_STAMP(20);
@@ -2255,5 +2338,8 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             __hip_atomic_fetch_add(a.cellflag + (size_t)cgidx * CELLFLAG_STRIDE + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     CS_STAMP(12);
+#ifdef MFAS_CHAIN_TIMING
+    if (threadIdx.x == 0 && bid == 0 && part == 0 && (cs.gstep == 3 || cs.gstep == 4)) a.status[64 + 24 + 2 * (cs.gstep - 3)] = (int32_t)wall_clock64();
+#endif
 #undef CS_STAMP
 }

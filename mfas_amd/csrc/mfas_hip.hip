@@ -869,6 +869,24 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
             }
             std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) {
                 return (int64_t)x.cc * x.rows_p * std::max(1, x.nsub) > (int64_t)y.cc * y.rows_p * std::max(1, y.nsub); });
+            if (p->same_group) {
+                // OUT / HEAD units one ROW BLOCK each (round 6): as ONE workgroup per 128 x 128 segment every wave walked its row block's eight
+                // tiles in four dependent load -> Adam -> store rounds of ~2.5 us behind the dy it waits for — OUT_1, released by the LAST dy of
+                // the step, ended 12.7 us after the chain where the cell-0 feature units end after 6.2 (profiles/r06_chain_split_r128.log).
+                // Row-split units (SegDesc::rb0 / seg_nrb, one tile per wave: the k-split walk) update the same tiles with the same arithmetic.
+                std::vector<SegDesc> fine;
+                for (const SegDesc& d : sorted) {
+                    const int nrb_d = d.rows_p / 16;
+                    if (d.kind <= KIND_V || nrb_d <= 1) { fine.push_back(d); continue; }
+                    for (int r0 = 0; r0 < nrb_d; ++r0) {
+                        SegDesc u = d;
+                        u.rb0 = r0; u.rows_p = 16; u.seg_nrb = nrb_d;
+                        u.w_off = d.w_off + (int64_t)r0 * (d.cc / 16) * 256;
+                        fine.push_back(u);
+                    }
+                }
+                sorted.swap(fine);
+            }
             if (p->same_group)   // the order the chain releases the units in
                 std::stable_sort(sorted.begin(), sorted.end(), [](const SegDesc& x, const SegDesc& y) {
                     // (the slot each unit waits for: feature units of cell i -> i, OUT_i -> i - 1, HEAD -> the last cell; highest slot first)
@@ -888,7 +906,10 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     }
     // reduce-in-sweep: one group (the chain is on the critical path), general chain, per-segment units only
     // (beyond ~28 candidates the co-scheduled chain is hidden anyway and the extra write-through traffic costs: 29.0 vs 26.7 cand/s at 32)
-    p->red_in_sweep = K < 28 && !p->lean_chain && !p->persist && !tu.no_red_in_sweep;
+    // (not with chain_split: the reducing unit's drain + arrival + summing pass behind the LAST dy of the step ends the launch 3.5 us later,
+    //  while the chain's four parts sum their own row blocks of the slabs at entry, every load in flight at once; measured, K = 1: 41.3 with
+    //  the reduction in the sweep, 38.4 without, 43.0 with a hybrid — cells >= 1 in the sweep, cell 0 in the chain — profiles/r06_chain_split_r128.log)
+    p->red_in_sweep = K < 28 && !p->lean_chain && !p->persist && !tu.no_red_in_sweep && !p->chain_split;
     for (const auto& gr : p->groups) if (gr.ntap != 0) p->red_in_sweep = false;     // (tap-major workgroups serve several candidates)
     if (p->red_in_sweep) {
         CREATE_CHK(hipMalloc(&p->d_red_cnt, sizeof(uint32_t) * K * MFAS_MAX_CELLS));
@@ -1352,6 +1373,11 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     }
     HIPCHK(hipMemsetAsync(p->d_stats, 0, sizeof(DevStats) * K * epochs, p->stream));
     HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int32_t) * K, p->stream));
+#ifdef MFAS_CHAIN_TIMING
+    HIPCHK(hipMemsetAsync(p->d_status + 64 + 27, 0, sizeof(int32_t), p->stream));
+    HIPCHK(hipMemsetAsync(p->d_status + 128, 0, 16 * sizeof(int32_t), p->stream));
+    HIPCHK(hipMemsetAsync(p->d_status + 64 + 28, 0xFF, sizeof(int32_t), p->stream));
+#endif
     // every call is a freshly built torch.optim.Adam (ntu_searchable.py:65; main_found_ntu.py:108,128): zero exp_avg / exp_avg_sq
     HIPCHK(hipMemsetAsync(p->plane + p->plane_stride, 0, sizeof(float) * 2 * (size_t)p->plane_stride, p->stream));
     if (snapshot_best && !p->best) HIPCHK(hipMalloc(&p->best, sizeof(float) * (size_t)p->plane_stride));
@@ -1730,13 +1756,22 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
     if (status) memcpy(status, hstatus.data(), sizeof(int32_t) * K);
 #ifdef MFAS_CHAIN_TIMING
     {
-        int32_t ts[24];
+        int32_t ts[40];
         if (hipMemcpy(ts, p->d_status + 64, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[chain timing, shader cycles since kernel entry, candidate 0 step 3]");
             for (int i = 0; i < 13; ++i) fprintf(stderr, " %d", ts[i]);
             if (p->chain_split) {      // chain_split's extra stamps: forward cell 1 product done | out sent | tail done | fetched;  backward cell 2 the same;  softmax done;  entry staged
                 fprintf(stderr, "  | split:");
                 for (int i = 13; i < 23; ++i) fprintf(stderr, " %d", ts[i]);
+                fprintf(stderr, "  | 10 ns ticks: chain of step 3 %d, end of chain 3 -> entry of chain 4 %d, chain of step 4 %d", ts[24] - ts[23], ts[25] - ts[24], ts[26] - ts[25]);
+                fprintf(stderr, "; end of chain 3 -> first cell-0 unit sees its flag %d -> last sweep unit of the launch ends %d -> entry of chain 4 %d", (int32_t)((uint32_t)ts[28] - (uint32_t)ts[24]), (int32_t)((uint32_t)ts[27] - (uint32_t)ts[28]), (int32_t)((uint32_t)ts[25] - (uint32_t)ts[27]));
+                fprintf(stderr, "; unit (cell 0, S, chunk 0) after the end of chain 3: flag seen %d, dy staged %d, tiles done %d, slab drained %d, arrival counted %d",
+                        ts[29] - ts[24], ts[30] - ts[24], ts[31] - ts[24], ts[32] - ts[24], ts[33] - ts[24]);
+                int32_t ue[16];
+                if (hipMemcpy(ue, p->d_status + 128, sizeof(ue), hipMemcpyDeviceToHost) == hipSuccess) {
+                    fprintf(stderr, "; last unit end after the end of chain 3, per cell [S V OUT HEAD]:");
+                    for (int i = 0; i < 16; ++i) fprintf(stderr, "%s%d", (i & 3) ? " " : " | ", ue[i] ? (int32_t)((uint32_t)ue[i] - (uint32_t)ts[24]) : 0);
+                }
             }
             fprintf(stderr, "\n");
             int32_t cs[24];

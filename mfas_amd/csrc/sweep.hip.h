@@ -53,10 +53,10 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
                         __builtin_nontemporal_store(m4[u], reinterpret_cast<f32x4*>(Mp + off));
                         __builtin_nontemporal_store(v4[u], reinterpret_cast<f32x4*>(Vp + off));
                     } else {
-                        // COH (persistent schedule): OUT / HEAD weights are read by the chain workgroup on another CU in the
-                        // same launch -> write-through; feature segments (T == nullptr) are private to this workgroup
-                        if (COH && T) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w4[u]), mk_rsrc(Wp), (int)(uint32_t)(off << 2), 0, MFAS_AUX_SC1);
-                        else *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
+                        // (COH = the same-group launch, one launch per step: the chain that reads OUT / HEAD runs in the NEXT launch, so plain
+                        //  stores do — the write-through forms the removed multi-step persistent kernel needed here cost the OUT units
+                        //  their L2 residency)
+                        *reinterpret_cast<f32x4*>(Wp + off) = w4[u];
                         *reinterpret_cast<f32x4*>(Mp + off) = m4[u];
                         *reinterpret_cast<f32x4*>(Vp + off) = v4[u];
                     }
@@ -64,7 +64,7 @@ __device__ __forceinline__ void tile_run(float* Wp, float* Mp, float* Vp, const 
                         float* Tt = T + ((int64_t)kb * tstride_rb + rb) * 256;
                         const int base = (((l15 >> 2) * 16 + 4 * lg) << 2) + (l15 & 3);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) stc1<COH>(Tt + base + 4 * q, w4[u][q]);
+                        for (int q = 0; q < 4; ++q) Tt[base + 4 * q] = w4[u][q];
                     }
                 }
                 if (fwd) {
@@ -204,6 +204,16 @@ __device__ __forceinline__ SweepStep sweep_step_of(const SweepArgs& a) {
 }
 
 
+#ifdef MFAS_CHAIN_TIMING
+// (timing build, same-group launch of step 3 with a 4-part chain: flag_target = 4 * 4) when the LAST sweep unit of the launch ended and when
+// the FIRST unit of cell 0 saw its flag, 100 MHz ticks, next to the chain's absolute stamps (status slots 64 + 27 / 28)
+#define SW_UNIT_STAMP(k) do { if (COH && a.cellflag && a.flag_target == 16u && threadIdx.x == 0 && d.cell == 0 && d.kind == KIND_S && d.k0 == 0 && d.cand == 0) a.flag_status[64 + 29 + (k)] = (int32_t)wall_clock64(); } while (0)
+#define SW_END_STAMP() do { if (COH && a.cellflag && a.flag_target == 16u && threadIdx.x == 0) { atomicMax(reinterpret_cast<uint32_t*>(&a.flag_status[64 + 27]), (uint32_t)wall_clock64()); \
+        atomicMax(reinterpret_cast<uint32_t*>(&a.flag_status[128 + d.cell * 4 + d.kind]), (uint32_t)wall_clock64()); } } while (0)
+#else
+#define SW_END_STAMP() do { } while (0)
+#define SW_UNIT_STAMP(k) do { } while (0)
+#endif
 template <int MB, bool NT, int U, bool COH = false>
 __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& st, const int bid, float* lds) {
     const SegDesc d = a.desc[bid];
@@ -256,9 +266,13 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
                     if (++spins > CELLFLAG_SPIN_LIMIT) { go = 0; atomicMax(&a.flag_status[cd.gidx], 2); break; }
                 }
                 s_go = go;
+#ifdef MFAS_CHAIN_TIMING
+                if (a.flag_target == 16u && slot == 0 && d.kind <= KIND_V) atomicMin(reinterpret_cast<uint32_t*>(&a.flag_status[64 + 28]), (uint32_t)wall_clock64());
+#endif
             }
             __syncthreads();
             if (!s_go) return;
+            SW_UNIT_STAMP(0);
         }
     }
     if (upd) {
@@ -271,6 +285,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
         stage_f32<COH>(dyl, SD, a.stepbuf, dsrc + d.rb0 * 16, d.seg_nrb * 16, rows_p, Bp, tid, STEP_THREADS);
     }
     __syncthreads();
+    SW_UNIT_STAMP(1);
 
     float* Wp = a.plane + d.w_off;
     float* Mp = Wp + a.plane_stride;
@@ -310,7 +325,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
             }
         }
     }
-    if (!fwd) return;
+    SW_UNIT_STAMP(2);
+    if (!fwd) { SW_END_STAMP(); return; }
     if (split_k) {
         __syncthreads();
         // deterministic cross-wave reduction (fixed order 0..7)
@@ -324,11 +340,12 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
             else stc4<COH>(a.stepbuf, part + (slot << 8) + ln * 4, s);
         }
     }
-    if (!red) return;
+    if (!red) { SW_END_STAMP(); return; }
     // ---- reduce-in-sweep: arrive on the cell's counter; the last arriver sums the cell's slabs (write-through stores + every
     // wave's drain + barrier + relaxed agent-scope counter on the producer side, sc1 loads on the reader's: G16 R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    SW_UNIT_STAMP(3);
     int* flagw = reinterpret_cast<int*>(lds);      // (the staging tiles are dead by now)
     const int ns_c = cd.nch_s[d.cell], nch_c = ns_c + cd.nch_v[d.cell];
     if (tid == 0) {
@@ -339,7 +356,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
         flagw[0] = last;
     }
     __syncthreads();
-    if (!flagw[0]) return;
+    SW_UNIT_STAMP(4);
+    if (!flagw[0]) { SW_END_STAMP(); return; }
     {
         const int snrb = d.seg_nrb;
         const int per_cell = snrb * MB * 64;            // float4 items of the cell's [nrb][MB][256] slab
@@ -368,6 +386,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const SweepStep& 
             }
         }
     }
+    SW_END_STAMP();
 }
 
 // ------------------------------------------------------------------------------------------------

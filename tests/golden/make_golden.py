@@ -743,17 +743,24 @@ def g15():
     torch.set_num_threads(nthreads)
     loaders = {"train": ShuffleLoader(ttr, 16), "dev": ListLoader(tdv, 16)}
     bests, hists = [], []
-    for seed in range(seed0, seed0 + NS):
+    meta = np.array([10000, 5600, snr, 128, 16, E, 1, 0.5])   # N,Ndev,snr,R,B,epochs,bn,drpt
+    cmd = np.array(f"G15_SNR={snr} G15_NS={NS} G15_SEED0={seed0} G15_E={E} G15_THREADS={nthreads} make_golden.py g15")
+    part = os.path.join(HERE, f"g15_part_{seed0:03d}.npz")
+    if "G15_SEED0" in os.environ and os.path.exists(part):       # resume an interrupted part (every seed is independent)
+        old = np.load(part)
+        if np.array_equal(old["meta"], meta) and int(old["seeds"][0]) == seed0:
+            bests, hists = list(old["best_acc"]), list(old["hist"])
+    for seed in range(seed0 + len(bests), seed0 + NS):
         torch.manual_seed(300 + seed)
         accs, _, hist = run_tsm([conf], args, loaders, 3000 + 10 * seed)
         bests.append(accs[0])
         hists.append(hist)
         print("g15 seed", seed, accs[0], hist[1::2, 2], flush=True)
+        if "G15_SEED0" in os.environ and not os.environ.get("G15_PROBE"):
+            np.savez_compressed(part, best_acc=np.array(bests), hist=np.array(hists), seeds=np.arange(seed0, seed0 + len(bests)), meta=meta, cmd=cmd)
     if os.environ.get("G15_PROBE"):
         return
-    arrs = dict(best_acc=np.array(bests), hist=np.array(hists), seeds=np.arange(seed0, seed0 + NS),
-                meta=np.array([10000, 5600, snr, 128, 16, E, 1, 0.5]),   # N,Ndev,snr,R,B,epochs,bn,drpt
-                cmd=np.array(f"G15_SNR={snr} G15_NS={NS} G15_SEED0={seed0} G15_E={E} G15_THREADS={nthreads} make_golden.py g15"))
+    arrs = dict(best_acc=np.array(bests), hist=np.array(hists), seeds=np.arange(seed0, seed0 + NS), meta=meta, cmd=cmd)
     if "G15_SEED0" in os.environ:
         save(f"g15_part_{seed0:03d}.npz", **arrs)
     else:

@@ -7,5 +7,5 @@ NPROC=${NPROC:-6}
 mkdir -p gpurun_out/golden_logs
 {
   for a in $(seq 64 8 120); do echo "G19_SEED0=$a G19_NS=8 python tests/golden/make_golden.py g19b > gpurun_out/golden_logs/g19b_$a.log 2>&1"; done
-  for a in $(seq 256 32 992); do echo "G15_SEED0=$a G15_NS=32 G15_THREADS=1 python tests/golden/make_golden.py g15 > gpurun_out/golden_logs/g15_$a.log 2>&1"; done
+  for a in $(seq 256 16 1008); do echo "G15_SEED0=$a G15_NS=16 G15_THREADS=1 python tests/golden/make_golden.py g15 >> gpurun_out/golden_logs/g15_$a.log 2>&1"; done
 } | PYTHONDONTWRITEBYTECODE=1 OMP_NUM_THREADS=1 MKL_NUM_THREADS=1 nice -n 19 xargs -P "$NPROC" -I{} bash -c "{}"

@@ -13,7 +13,8 @@ from oracle import np_oracle as O
 
 Ks = [int(x) for x in sys.argv[1].split(",")]
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+B = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 16
+cc = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("cc=")), 0)
 N, Nd = 10000, 5600
 dev = torch.device("cuda:0")
 tr = M.FeatureTable.synthetic(N, 1, dev, torch.bfloat16, snr=0.12)
@@ -23,14 +24,14 @@ conf4 = np.array([[3, 1, 1], [1, 3, 0], [1, 1, 1], [3, 3, 0]])
 nb = -(-N // B)
 etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, E * nb)
 order = M.ntu_searchable.make_order(N, E, True, 5, dev)
-print(f"# R=128 B={B} bn E={E} N={N}/{Nd} conf 4: K | one-CU chain us/step (cand/s at E=10) | default us/step (cand/s) | schedule")
+print(f"# R=128 B={B} bn E={E} N={N}/{Nd} conf 4 chunk_cols={cc or 'auto'}: K | one-CU chain us/step (cand/s at E=10) | default us/step (cand/s) | schedule")
 for K in Ks:
     res = {}
     for mode in ("0", "default"):
         if mode == "0":
             os.environ["MFAS_CHAIN_SPLIT"] = "0"
         try:
-            pop = M.Population(hp, [conf4] * K, dev, drop_seeds=list(range(100, 100 + K)))
+            pop = M.Population(hp, [conf4] * K, dev, drop_seeds=list(range(100, 100 + K)), chunk_cols=cc)
         finally:
             os.environ.pop("MFAS_CHAIN_SPLIT", None)
         sched = pop.schedule()
