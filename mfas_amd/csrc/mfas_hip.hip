@@ -56,11 +56,17 @@ struct StepArgs {
     GatherArgs ga;          // nblocks gather workgroups (one per chain candidate) right after the chain blocks
 };
 
-template <int MB, bool NT, int WPE, bool LEAN>
+// NS > 1 (its own instantiation: the headline k_step<1, true, 4, false> carries none of it): the chain blocks are chain_split parts,
+// block b = part * (nchain / NS) + candidate (k_step_same below).
+template <int MB, bool NT, int WPE, bool LEAN, int NS = 1>
 __global__ void __launch_bounds__(STEP_THREADS, WPE) k_step(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bid = (int)blockIdx.x;
     if (bid < a.nchain) {
+        if constexpr (NS > 1) {
+            const int Kp = a.nchain / NS, part = bid / Kp, c = bid - part * Kp;
+            if (c < a.ca.ncand) chain_split<NS>(a.ca, chain_step_of(a.ca), c, part, lds);
+        } else
         if constexpr (LEAN) { chain_lean<MB, 0, (WPE >= 4 ? 8 : 16)>(a.ca, chain_step_of(a.ca), bid, lds, lean_pre<MB>(a.ca, bid)); chain_lean_tail<MB, 0>(a.ca, chain_step_of(a.ca), bid, lds); }
         else chain_body<MB, false>(a.ca, chain_step_of(a.ca), bid, lds);
     }
@@ -807,7 +813,10 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         }
         if (p->same_group) ngroups = 1;
         // the chain of one candidate over 4 CUs (chain.hip.h, chain_split): eight row blocks, one batch tile, <= 4 class blocks, no alphas
-        p->chain_split = (p->same_group && g.MB == 1 && g.nrb == 8 && g.ncb <= 4 && !g.alphas && tu.chain_split != 0 && tu.chain_split != 1) ? 4 : 0;
+        // — in the same-group launch, and in the two-group launches while the chain bounds them (< 28 candidates: sweep(8 candidates) = 36 us
+        // against a 47 us chain; beyond, the chain hides under the other group's sweep and 4 x 64 chain workgroups would only take CUs from it)
+        p->chain_split = ((p->same_group || (ngroups == 2 && K < 28)) && !p->lean_chain && !p->persist && g.MB == 1 && g.nrb == 8 && g.ncb <= 4 && !g.alphas &&
+                          tu.chain_split != 0 && tu.chain_split != 1) ? 4 : 0;
         p->lp_group = lp.group;
         int split = K;
         if (ngroups == 2) {
@@ -909,7 +918,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     // (not with chain_split: the reducing unit's drain + arrival + summing pass behind the LAST dy of the step ends the launch 3.5 us later,
     //  while the chain's four parts sum their own row blocks of the slabs at entry, every load in flight at once; measured, K = 1: 41.3 with
     //  the reduction in the sweep, 38.4 without, 43.0 with a hybrid — cells >= 1 in the sweep, cell 0 in the chain — profiles/r06_chain_split_r128.log)
-    p->red_in_sweep = K < 28 && !p->lean_chain && !p->persist && !tu.no_red_in_sweep && !p->chain_split;
+    p->red_in_sweep = K < 28 && !p->lean_chain && !p->persist && !tu.no_red_in_sweep && !(p->chain_split && p->same_group);
     for (const auto& gr : p->groups) if (gr.ntap != 0) p->red_in_sweep = false;     // (tap-major workgroups serve several candidates)
     if (p->red_in_sweep) {
         CREATE_CHK(hipMalloc(&p->d_red_cnt, sizeof(uint32_t) * K * MFAS_MAX_CELLS));
@@ -919,12 +928,13 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
         CREATE_CHK(hipMalloc(&p->d_cellflag, sizeof(uint32_t) * K * CELLFLAG_STRIDE));
         CREATE_CHK(set_lds((k_step_same<1, false>), p->lds_step)); CREATE_CHK(set_lds((k_step_same<1, true>), p->lds_step));
         CREATE_CHK(set_lds((k_step_same<2, false>), p->lds_step)); CREATE_CHK(set_lds((k_step_same<2, true>), p->lds_step));
-        if (p->chain_split) {
-            p->lds_split = std::max(p->lds_step, chain_split_lds_floats<4>(g.Rp, g.Cp) * 4);
-            CREATE_CHK(set_lds((k_step_same<1, false, 4>), p->lds_split)); CREATE_CHK(set_lds((k_step_same<1, true, 4>), p->lds_split));
-            CREATE_CHK(hipMalloc(&p->d_xch, sizeof(float) * (size_t)K * XCH_CAND_FLOATS));
-            if ((size_t)K * XCH_CAND_FLOATS >= (1ull << 30)) { mfas_population_destroy(p); return fail(MFAS_EINVAL, "internal: exchange area beyond the 32-bit buffer offsets"); }
-        }
+    }
+    if (p->chain_split) {
+        p->lds_split = std::max(p->lds_step, chain_split_lds_floats<4>(g.Rp, g.Cp) * 4);
+        CREATE_CHK(set_lds((k_step_same<1, false, 4>), p->lds_split)); CREATE_CHK(set_lds((k_step_same<1, true, 4>), p->lds_split));
+        CREATE_CHK(set_lds((k_step<1, false, 4, false, 4>), p->lds_split)); CREATE_CHK(set_lds((k_step<1, true, 4, false, 4>), p->lds_split));
+        CREATE_CHK(hipMalloc(&p->d_xch, sizeof(float) * (size_t)K * XCH_CAND_FLOATS));
+        if ((size_t)K * XCH_CAND_FLOATS >= (1ull << 30)) { mfas_population_destroy(p); return fail(MFAS_EINVAL, "internal: exchange area beyond the 32-bit buffer offsets"); }
     }
     CREATE_CHK(hipMemsetAsync(p->plane, 0, sizeof(float) * 3 * (size_t)p->plane_stride, p->stream));
     CREATE_CHK(hipMemsetAsync(p->wt, 0, sizeof(float) * (size_t)std::max<int64_t>(p->wt_size, 64), p->stream));
@@ -1398,7 +1408,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
 
     // Candidate groups A/B: every launch pairs the sweep of one group with the chain of the other (k_step).
     int NG = 0;
-    int64_t split_launches = 0;         // chain_split launches of this call (exchange parity)
+    int64_t split_launches[2] = {0, 0}; // chain_split launches of this call per candidate group (exchange parity)
     StepArgs st;
     auto init_args = [&]() -> hipError_t {     // (again after persist_fallback: the population's buffers and layout have changed)
         NG = (int)p->groups.size();
@@ -1418,7 +1428,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         // chain_split: every piece of both parities "not written" (all-ones words), parity counter back to 0
         if (e_ == hipSuccess && p->chain_split) e_ = hipMemsetAsync(p->d_xch, 0xFF, sizeof(float) * (size_t)K * XCH_CAND_FLOATS, p->stream);
         st.ca.xch = p->d_xch; st.ca.nsplit = p->chain_split; st.ca.xpar = 0;
-        split_launches = 0;
+        split_launches[0] = split_launches[1] = 0;
         return e_;
     };
     HIPCHK(init_args());
@@ -1532,7 +1542,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             if (p->chain_split) {      // NS parts per candidate: the per-cell flags count arrivals, chain blocks = NS * ceil8(candidates)
                 const int NS = p->chain_split, Kp = (int)((nch + 7) & ~7u);
                 st.sa.flag_target = st.ca.flag_target = (uint32_t)NS * ((uint32_t)st.ca.gstep + 1u);
-                st.ca.ncand = (int)nch; st.ca.xpar = (int)(split_launches++ & 1);
+                st.ca.ncand = (int)nch; st.ca.xpar = (int)(split_launches[0]++ & 1);
                 st.nchain = NS * Kp;
                 if (p->nontemporal) hipLaunchKernelGGL((k_step_same<1, true, 4>), dim3(st.nchain + nsw), dim3(STEP_THREADS), p->lds_split, p->stream, st);
                 else hipLaunchKernelGGL((k_step_same<1, false, 4>), dim3(st.nchain + nsw), dim3(STEP_THREADS), p->lds_split, p->stream, st);
@@ -1542,6 +1552,12 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             else { if (p->nontemporal) hipLaunchKernelGGL((k_step_same<2, true>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st);
                    else hipLaunchKernelGGL((k_step_same<2, false>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st); }
             st.sa.cellflag = nullptr; st.ca.cellflag = nullptr;
+        } else if (p->chain_split && nch > 0) {      // two-group launch whose chain blocks are chain_split parts (no flags: the kernel boundary)
+            const int NS = p->chain_split, Kp = (int)((nch + 7) & ~7u);
+            st.ca.ncand = (int)nch; st.ca.xpar = (int)(split_launches[gc & 1]++ & 1);
+            st.nchain = NS * Kp;
+            if (p->nontemporal) hipLaunchKernelGGL((k_step<1, true, 4, false, 4>), dim3(st.nchain + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_split, p->stream, st);
+            else hipLaunchKernelGGL((k_step<1, false, 4, false, 4>), dim3(st.nchain + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_split, p->stream, st);
         } else {
 #define STEP_LAUNCH(M, T, W, F) hipLaunchKernelGGL((k_step<M, T, W, F>), dim3(nch + st.ga.nblocks + nsw), dim3(STEP_THREADS), p->lds_step, p->stream, st)
 #define STEP_PICK(M, W) do { if (p->nontemporal) { if (p->lean_chain) STEP_LAUNCH(M, true, W, true); else STEP_LAUNCH(M, true, W, false); } \
