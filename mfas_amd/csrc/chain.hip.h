@@ -890,6 +890,7 @@ struct LeanRes {
     int bad;            // non-finite loss seen
 };
 #define LEAN_OWN_TILES 7   // slots 0..2: OUT_1..OUT_3, slots 3..6: head class blocks 0..3
+#define LEAN_BNF 384       // BatchNorm pair-exchange flags (uint32) inside the scratch: [forward sum | forward squares | backward][parity][tile wave]
 #define LEAN_SCR 1024      // floats: forward BN exchange [parity][sum | squares][tile][16] | +256: dgamma / dbeta [L][2][16] | +512: backward BN exchange | +768: [tile][cell][mean | rstd][16]
 
 #ifndef MFAS_RES_TRANSPOSED_SLABS
@@ -1216,6 +1217,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
         }
     }
     if constexpr (!RES) {
+        if (tid < 16) reinterpret_cast<uint32_t*>(ll.scr + LEAN_BNF)[tid] = 0u;   // (one step per launch: LDS starts undefined; resident: lean_res_load)
         if (tid < nvec) { vec_l[tid] = vw; vec_l[nvec + tid] = vm; vec_l[2 * nvec + tid] = vv; }
         *reinterpret_cast<f32x4*>(ll.own + (wave << 8) + lane * 4) = st0;
         if (wave + 1 < LEAN_OWN_TILES) *reinterpret_cast<f32x4*>(ll.own + ((LEAN_OWN_TILES + wave + 1) << 8) + lane * 4) = st1;
@@ -1245,6 +1247,22 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
 
     // ------------------------------------------------------------------ forward, in the tile waves' registers
     float* bnw = ll.scr;                                     // BN exchange: [parity][sum | sum of squares][tile][16]
+    // BatchNorm with TWO batch tiles (B = 17 .. 32): the column statistics need both tile waves' partial sums.  Round 6: the two waves
+    // exchange them PAIRWISE — data, then a sequence number behind it (LDS executes a wave's instructions in order; release / acquire at
+    // workgroup scope = a wait for the wave's own LDS operations), the partner polls the number — instead of through workgroup barriers
+    // that made the tile waves wait for the six waves summing slabs: 3 barriers per cell were 12 of the 22.6 us of a BatchNorm step.
+    // Parity double-buffering of the regions is enough: a wave cannot pass exchange k + 1 before its partner has finished reading k.
+    uint32_t* bnf = reinterpret_cast<uint32_t*>(ll.scr + LEAN_BNF);
+    const uint32_t bnseq = (uint32_t)cs.gstep * (uint32_t)MFAS_MAX_CELLS + 1u;
+    auto pair_post = [&](float* slot, const f32x4 val, const int kind, const int i) {
+        if (l15 == 0) *reinterpret_cast<f32x4*>(slot + r0) = val;
+        __hip_atomic_store(bnf + (kind * 2 + (i & 1)) * 2 + wave, bnseq + (uint32_t)i, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto pair_wait = [&](const int kind, const int i) {
+        const uint32_t* f = bnf + (kind * 2 + (i & 1)) * 2 + (wave ^ 1);
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != bnseq + (uint32_t)i) { }
+    };
+    static_assert(MB <= 2, "pairwise exchange: two tile waves");
     float* gv2 = ll.scr + 256;                               // [cell][dgamma | dbeta][16]
     float* bst = ll.scr + 768 + (is_tw ? wave : 0) * 128;     // this tile wave's copy of every cell's batch mean | rstd: [cell][2][16]
     f32x4 av[MFAS_MAX_CELLS];                                 // activations: all the backward needs again in registers (x-hat is recomputed
@@ -1311,9 +1329,11 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                 float* ex = bnw + (i & 1) * 128;
                 f32x4 tot = s1;
                 if constexpr (MB > 1) {
-                    if (is_tw && l15 == 0) *reinterpret_cast<f32x4*>(ex + wave * 16 + r0) = s1;
-                    lds_barrier();
-                    if (is_tw) tot = *reinterpret_cast<const f32x4*>(ex + r0) + *reinterpret_cast<const f32x4*>(ex + 16 + r0);
+                    if (is_tw) {
+                        pair_post(ex + wave * 16, s1, 0, i);
+                        pair_wait(0, i);
+                        tot = *reinterpret_cast<const f32x4*>(ex + r0) + *reinterpret_cast<const f32x4*>(ex + 16 + r0);
+                    }
                 }
                 // (divisions and square root through common.hip.h's correctly rounding packed sequences: the values of operator/ and
                 //  sqrtf() for a fraction of the instructions)
@@ -1326,9 +1346,11 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                 }
                 f32x4 tot2 = s2;
                 if constexpr (MB > 1) {
-                    if (is_tw && l15 == 0) *reinterpret_cast<f32x4*>(ex + 64 + wave * 16 + r0) = s2;
-                    lds_barrier();
-                    if (is_tw) tot2 = *reinterpret_cast<const f32x4*>(ex + 64 + r0) + *reinterpret_cast<const f32x4*>(ex + 64 + 16 + r0);
+                    if (is_tw) {
+                        pair_post(ex + 64 + wave * 16, s2, 1, i);
+                        pair_wait(1, i);
+                        tot2 = *reinterpret_cast<const f32x4*>(ex + 64 + r0) + *reinterpret_cast<const f32x4*>(ex + 64 + 16 + r0);
+                    }
                 }
                 if (is_tw) {
                     const f32x4 gam = *reinterpret_cast<const f32x4*>(vecW + vbl + VEC_G * Rp + r0);
@@ -1555,12 +1577,10 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                 float* ex = bnw + 512 + (i & 1) * 128;     // (not the forward's region: no barrier separates the last forward cell's reads from these writes)
                 f32x4 dbet = p0, dgam = p1;
                 if constexpr (MB > 1) {
-                    if (is_tw && l15 == 0) {
-                        *reinterpret_cast<f32x4*>(ex + wave * 16 + r0) = p0;
-                        *reinterpret_cast<f32x4*>(ex + 64 + wave * 16 + r0) = p1;
-                    }
-                    lds_barrier();
                     if (is_tw) {
+                        if (l15 == 0) *reinterpret_cast<f32x4*>(ex + 64 + wave * 16 + r0) = p1;
+                        pair_post(ex + wave * 16, p0, 2, i);
+                        pair_wait(2, i);
                         dbet = *reinterpret_cast<const f32x4*>(ex + r0) + *reinterpret_cast<const f32x4*>(ex + 16 + r0);
                         dgam = *reinterpret_cast<const f32x4*>(ex + 64 + r0) + *reinterpret_cast<const f32x4*>(ex + 64 + 16 + r0);
                     }
@@ -1740,6 +1760,7 @@ __device__ __forceinline__ void lean_res_load(const ChainArgs& a, const int bid,
         *reinterpret_cast<f32x4*>(ll.own + (3 * LEAN_OWN_TILES + s) * 256 + lane * 4) = t;
     }
     if (tid == CHAIN_THREADS - 64) { rs.loss = 0.0; rs.corr = 0; rs.bad = 0; }     // (rs may live in LDS: one writer, the lane that accumulates)
+    if (tid < 16) reinterpret_cast<uint32_t*>(ll.scr + LEAN_BNF)[tid] = 0u;       // BatchNorm pair-exchange flags (chain_lean): sequence numbers start at 1
     __syncthreads();
 }
 

@@ -127,6 +127,7 @@ struct Tuning {
     int no_tap_major = 0;           // MFAS_NO_TAP_MAJOR       per-segment sweep units also at R < 128
     int force_tap_major = 0;        // MFAS_FORCE_TAP_MAJOR    tap-major units even with < 192 workgroups
     int no_red_in_sweep = 0;        // MFAS_NO_RED_IN_SWEEP    the chain reduces the partial slabs itself
+    int force_red_in_sweep = 0;     // MFAS_FORCE_RED_IN_SWEEP reduce-in-sweep whatever the population size (A/B: measured negative at 128 candidates)
     double occ_bytes = -1.0;        // MFAS_OCC_BYTES          MB == 2: crossover between the 2- and 4-waves-per-SIMD sweep builds
     int no_xcd_placement = 0;       // MFAS_NO_XCD_PLACEMENT   resident launch: block b runs role b
     int n_xcd = 0;                  // MFAS_XCDS=n             XCDs the placement assumes (0: 8 — MI355X in SPX mode)
@@ -163,6 +164,7 @@ static Tuning tuning_from_env() {
     t.no_tap_major = flag("MFAS_NO_TAP_MAJOR");
     t.force_tap_major = flag("MFAS_FORCE_TAP_MAJOR");
     t.no_red_in_sweep = flag("MFAS_NO_RED_IN_SWEEP");
+    t.force_red_in_sweep = flag("MFAS_FORCE_RED_IN_SWEEP");
     if (const char* e = getenv("MFAS_OCC_BYTES")) t.occ_bytes = atof(e);
     t.no_xcd_placement = flag("MFAS_NO_XCD_PLACEMENT");
     t.n_xcd = num("MFAS_XCDS", 0);
@@ -192,11 +194,11 @@ extern "C" int mfas_tuning_describe(char* buf, int32_t cap) {
     char tmp[1024];
     snprintf(tmp, sizeof(tmp),
              "persist=%d no_lean_chain=%d persist_no_resident=%d persist_no_res_chain=%d subchunks=%d subchunk_skip=%d groups=%d same_group=%d "
-             "no_tap_major=%d force_tap_major=%d no_red_in_sweep=%d occ_bytes=%g no_xcd_placement=%d n_xcd=%d persist_trace=%d nt=%d eval_no_x16=%d "
+             "no_tap_major=%d force_tap_major=%d no_red_in_sweep=%d force_red_in_sweep=%d occ_bytes=%g no_xcd_placement=%d n_xcd=%d persist_trace=%d nt=%d eval_no_x16=%d "
              "eval_no_msplit=%d eval_no_b3=%d eval_no_wl=%d no_gather=%d gather_verbose=%d no_plain_chain=%d persist_verbose=%d prof_every=%d "
              "chain_split=%d test_not_resident=%d test_lose_step=%d hooks=%d",
              t.persist, t.no_lean_chain, t.persist_no_resident, t.persist_no_res_chain, t.subchunks, t.subchunk_skip, t.groups, t.same_group,
-             t.no_tap_major, t.force_tap_major, t.no_red_in_sweep, t.occ_bytes, t.no_xcd_placement, t.n_xcd, t.persist_trace, t.nt, t.eval_no_x16,
+             t.no_tap_major, t.force_tap_major, t.no_red_in_sweep, t.force_red_in_sweep, t.occ_bytes, t.no_xcd_placement, t.n_xcd, t.persist_trace, t.nt, t.eval_no_x16,
              t.eval_no_msplit, t.eval_no_b3, t.eval_no_wl, t.no_gather, t.gather_verbose, t.no_plain_chain, t.persist_verbose, t.prof_every,
              t.chain_split, t.test_not_resident, t.test_lose_step,
 #ifdef MFAS_TEST_HOOKS
@@ -918,7 +920,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
     // (not with chain_split: the reducing unit's drain + arrival + summing pass behind the LAST dy of the step ends the launch 3.5 us later,
     //  while the chain's four parts sum their own row blocks of the slabs at entry, every load in flight at once; measured, K = 1: 41.3 with
     //  the reduction in the sweep, 38.4 without, 43.0 with a hybrid — cells >= 1 in the sweep, cell 0 in the chain — profiles/r06_chain_split_r128.log)
-    p->red_in_sweep = K < 28 && !p->lean_chain && !p->persist && !tu.no_red_in_sweep && !(p->chain_split && p->same_group);
+    p->red_in_sweep = (K < 28 || tu.force_red_in_sweep) && !p->lean_chain && !p->persist && !tu.no_red_in_sweep && !(p->chain_split && p->same_group);
     for (const auto& gr : p->groups) if (gr.ntap != 0) p->red_in_sweep = false;     // (tap-major workgroups serve several candidates)
     if (p->red_in_sweep) {
         CREATE_CHK(hipMalloc(&p->d_red_cnt, sizeof(uint32_t) * K * MFAS_MAX_CELLS));

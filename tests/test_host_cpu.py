@@ -57,7 +57,7 @@ print(json.dumps(_lib.tuning()))
         return json.loads(out.stdout.strip().splitlines()[-1])
 
     defaults = {"persist": "-1", "no_lean_chain": "0", "persist_no_resident": "0", "persist_no_res_chain": "0", "subchunks": "0",
-                "subchunk_skip": "0", "groups": "0", "same_group": "-1", "no_tap_major": "0", "force_tap_major": "0", "no_red_in_sweep": "0",
+                "subchunk_skip": "0", "groups": "0", "same_group": "-1", "no_tap_major": "0", "force_tap_major": "0", "no_red_in_sweep": "0", "force_red_in_sweep": "0",
                 "occ_bytes": "-1", "no_xcd_placement": "0", "n_xcd": "0", "persist_trace": "0", "nt": "-1", "eval_no_x16": "0",
                 "eval_no_msplit": "0", "eval_no_b3": "0", "eval_no_wl": "0", "no_gather": "0", "gather_verbose": "0", "no_plain_chain": "0",
                 "persist_verbose": "0", "prof_every": "16", "chain_split": "-1", "test_not_resident": "-1", "test_lose_step": "-1", "hooks": "0"}
@@ -66,7 +66,7 @@ print(json.dumps(_lib.tuning()))
               "persist_no_resident": ("MFAS_PERSIST_NO_RESIDENT", "1", "1"), "persist_no_res_chain": ("MFAS_PERSIST_NO_RES_CHAIN", "1", "1"),
               "subchunks": ("MFAS_SUBCHUNKS", "4", "4"), "subchunk_skip": ("MFAS_SUBCHUNK_SKIP", "3", "3"), "groups": ("MFAS_GROUPS", "2", "2"),
               "same_group": ("MFAS_SAME_GROUP", "2", "2"), "no_tap_major": ("MFAS_NO_TAP_MAJOR", "1", "1"),
-              "force_tap_major": ("MFAS_FORCE_TAP_MAJOR", "1", "1"), "no_red_in_sweep": ("MFAS_NO_RED_IN_SWEEP", "1", "1"),
+              "force_tap_major": ("MFAS_FORCE_TAP_MAJOR", "1", "1"), "no_red_in_sweep": ("MFAS_NO_RED_IN_SWEEP", "1", "1"), "force_red_in_sweep": ("MFAS_FORCE_RED_IN_SWEEP", "1", "1"),
               "occ_bytes": ("MFAS_OCC_BYTES", "3e8", "3e+08"), "no_xcd_placement": ("MFAS_NO_XCD_PLACEMENT", "1", "1"), "n_xcd": ("MFAS_XCDS", "4", "4"),
               "persist_trace": ("MFAS_PERSIST_TRACE", "1", "1"), "nt": ("MFAS_NT", "1", "1"), "eval_no_x16": ("MFAS_EVAL_NO_X16", "1", "1"),
               "eval_no_msplit": ("MFAS_EVAL_NO_MSPLIT", "1", "1"), "eval_no_b3": ("MFAS_EVAL_NO_B3", "1", "1"), "eval_no_wl": ("MFAS_EVAL_NO_WL", "1", "1"),
