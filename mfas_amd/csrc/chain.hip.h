@@ -1052,7 +1052,7 @@ __device__ __forceinline__ bool lean_ce_in_regs(const ChainArgs& a) { return a.g
 // (MODE 1 — persistent, everything exchanged through memory — went with the streaming persistent form in round 3.)
 // PLAIN: the search default compiled on its own — no BatchNorm, no alphas, softmax CE, no external logits / gradients: the flags
 // are compile-time false, their uniform values need no scalar registers and their branches are gone.
-template <int MB, int MODE = 0, int PB = 16, bool PLAIN = false>
+template <int MB, int MODE = 0, int PB = 16, int PLAIN = 0>
 __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& cs, const int bid, float* lds, const LeanPre& lp,
                                            const uint32_t keep_pre = 0u, const int lab_pre = 0) {
     constexpr bool COH = MODE >= 1;
@@ -1070,7 +1070,9 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     constexpr int Rp = 16, SX = Rp + 4;
     const int Cp = g.Cp, ncb = g.ncb, R = g.R, C = g.C, L = lp.L, SC = Cp + 4;
     constexpr int sav_plane = MFAS_MAX_CELLS * MB * 256;
-    const bool f_bn = PLAIN ? false : (g.bn != 0);
+    // (PLAIN: 0 every flag at run time; 1 the search default — no BatchNorm; 2, round 6: `--batchnorm` and nothing else — the generic form
+    //  carried 10 spilled registers through the BatchNorm cells' serial path)
+    const bool f_bn = PLAIN == 1 ? false : (PLAIN == 2 ? true : (g.bn != 0));
     const bool f_alphas = PLAIN ? false : (g.alphas != 0);
     const LeanLds<MB> ll(lds, g);
     const int nvec = ll.nvec;
@@ -1292,7 +1294,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             if constexpr (TS) {
                 if (i == 1) lds_barrier();     // the other waves' sums of cells 1..L-1 are in LDS (they got there under cell 0)
             }
-            if constexpr (RES) {
+            if constexpr (RES && PLAIN != 2) {
                 if (i == (L > 1 ? 1 : 0) && is_tw) {      // the head's operands, a phase ahead
 #pragma unroll
                     for (int cb = 0; cb < 4; ++cb) {
@@ -1403,7 +1405,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
         for (int cb = 0; cb < 4; ++cb)
             if (cb < ncb) {
                 f32x4 w, hb;
-                if constexpr (RES) { w = phw[cb]; hb = phb[cb]; }
+                if constexpr (RES && PLAIN != 2) { w = phw[cb]; hb = phb[cb]; }
                 else { w = *reinterpret_cast<const f32x4*>(ll.template wtile<RES>(3 + cb) + lane * 4); hb = *reinterpret_cast<const f32x4*>(vecW + g.vec_head + cb * 16 + r0); }
                 f32x4 acc = z4;
 #pragma unroll
@@ -1419,7 +1421,7 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
             for (int i = 0; i < MFAS_MAX_CELLS; ++i)
                 pt4[i] = i < MFAS_MAX_CELLS - 1 ? *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(i) + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) pht[cb] = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(3 + cb) + lane * 4);
+            for (int cb = 0; cb < 4; ++cb) if constexpr (PLAIN != 2) pht[cb] = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(3 + cb) + lane * 4);
         }
     }
     if constexpr (MODE == 0 && !PLAIN) {
@@ -1551,7 +1553,8 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                         pt[cb] = z4;
                         if (cb < ncb) {
                             f32x4 wt4;
-                            if constexpr (RES) wt4 = pht[cb]; else wt4 = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(3 + cb) + lane * 4);
+                            // (the BatchNorm-only build reads the head's transposed tiles where they are used: 16 registers less, no spills)
+                            if constexpr (RES && PLAIN != 2) wt4 = pht[cb]; else wt4 = *reinterpret_cast<const f32x4*>(ll.template ttile<RES>(3 + cb) + lane * 4);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) pt[cb] = MFMA16(wt4[q], lgt[cb][q], pt[cb]);
                         }

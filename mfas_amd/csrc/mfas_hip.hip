@@ -1027,7 +1027,7 @@ static int create_impl(const mfas_hyper* hp, const int32_t* confs, const int32_t
 #define SET_RES(M, P) CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 1, P>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, false, 2, P>), p->lds_president)); \
                    CREATE_CHK(set_lds((k_president<M, PERSIST_NTR16, true, 1, P>), p->lds_president)); CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 1, P>), p->lds_president)); \
                    CREATE_CHK(set_lds((k_president<M, PERSIST_NTR, true, 2, P>), p->lds_president))
-        SET_RES(1, false); SET_RES(2, false); SET_RES(1, true); SET_RES(2, true);
+        SET_RES(1, 0); SET_RES(2, 0); SET_RES(1, 1); SET_RES(2, 1); SET_RES(1, 2); SET_RES(2, 2);
 #undef SET_RES
     }
     // W/m/v beyond what the 256 MiB Infinity Cache can keep between steps are streamed nontemporally
@@ -1626,9 +1626,12 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
         {      // one instantiation per unit form
             const int lw = (int)(p->lds_president / 4) - PERSIST_LDS_WORDS;
             // the search default — no BatchNorm, no alphas, single-task softmax CE — runs the chain compiled for exactly that (chain_lean PLAIN)
-            const bool plain = !g.bn && !g.alphas && !g.multitask && g.loss_mode == 0 && !p->tune.no_plain_chain;
-#define RES_LAUNCH(M, NTR, X, NU) do { if (plain) hipLaunchKernelGGL((k_president<M, NTR, X, NU, true>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); \
-                                       else hipLaunchKernelGGL((k_president<M, NTR, X, NU, false>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); } while (0)
+            // (round 6: and `--batchnorm` alone, /root/reference/main_searchable_ntu.py:48, the chain compiled for exactly THAT — PLAIN = 2)
+            const bool simple = !g.alphas && !g.multitask && g.loss_mode == 0 && !p->tune.no_plain_chain;
+            const int plain = simple ? (g.bn ? 2 : 1) : 0;
+#define RES_LAUNCH(M, NTR, X, NU) do { if (plain == 1) hipLaunchKernelGGL((k_president<M, NTR, X, NU, 1>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); \
+                                       else if (plain == 2) hipLaunchKernelGGL((k_president<M, NTR, X, NU, 2>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); \
+                                       else hipLaunchKernelGGL((k_president<M, NTR, X, NU, 0>), dim3(grid), dim3(STEP_THREADS), p->lds_president, p->stream, pa, lw); } while (0)
 #define RES_PICK(M) do { if (train->dtype == MFAS_DT_F32) { if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, false, 2); else RES_LAUNCH(M, PERSIST_NTR, false, 1); } \
                          else if (pa.res_wide) RES_LAUNCH(M, PERSIST_NTR16, true, 1); \
                          else if (pa.res_nu == 2) RES_LAUNCH(M, PERSIST_NTR, true, 2); else RES_LAUNCH(M, PERSIST_NTR, true, 1); } while (0)

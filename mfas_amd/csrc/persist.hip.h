@@ -528,7 +528,7 @@ __device__ __forceinline__ bool persist_roll_call(uint32_t* sync, const int K, c
 // hardware queues, which HIP does not promise: after a few hundred stream creations in one process the second launch queued
 // behind the first and every roll call failed.  One launch cannot be split by the runtime.)
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NTR, bool X16, int NU, bool PLAIN>
+template <int MB, int NTR, bool X16, int NU, int PLAIN>
 __global__ void __launch_bounds__(STEP_THREADS, 2) k_president(const PersistArgs a, const int lds_word) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* ldsw = reinterpret_cast<int*>(lds) + lds_word;
