@@ -891,6 +891,7 @@ struct LeanRes {
 };
 #define LEAN_OWN_TILES 7   // slots 0..2: OUT_1..OUT_3, slots 3..6: head class blocks 0..3
 #define LEAN_BNF 384       // BatchNorm pair-exchange flags (uint32) inside the scratch: [forward sum | forward squares | backward][parity][tile wave]
+#define LEAN_BNV 400       // the cells' batch variance [cell][16] for the running statistics (chain_lean_tail)
 #define LEAN_SCR 1024      // floats: forward BN exchange [parity][sum | squares][tile][16] | +256: dgamma / dbeta [L][2][16] | +512: backward BN exchange | +768: [tile][cell][mean | rstd][16]
 
 #ifndef MFAS_RES_TRANSPOSED_SLABS
@@ -1366,18 +1367,9 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
                         *reinterpret_cast<f32x4*>(bst + i * 32 + r0) = mu;
                         *reinterpret_cast<f32x4*>(bst + i * 32 + 16 + r0) = rstd;
                     }
-                    if (wave == 0 && l15 == 0) {   // running stats: momentum 0.1, unbiased variance
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (cm[q]) {
-                                float rm = vecW[vbl + VEC_RM * Rp + r0 + q], rv = vecW[vbl + VEC_RV * Rp + r0 + q];
-                                const float unb = var[q] * (nf / (nf - 1.0f));
-                                rm += g.bn_mom * (mu[q] - rm);
-                                rv += g.bn_mom * (unb - rv);
-                                if constexpr (RES) { vec_l[vbl + VEC_RM * Rp + r0 + q] = rm; vec_l[vbl + VEC_RV * Rp + r0 + q] = rv; }
-                                else { W[vb + VEC_RM * Rp + r0 + q] = rm; W[vb + VEC_RV * Rp + r0 + q] = rv; }
-                            }
-                    }
+                    // (running statistics: chain_lean_tail steps them from this variance and the mean above, after dy is out — as four
+                    //  serial element updates on tile wave 0 they delayed BOTH tile waves of every forward cell)
+                    if (wave == 0 && l15 == 0) *reinterpret_cast<f32x4*>(ll.scr + LEAN_BNV + i * 16 + r0) = var;
                 }
             }
             if (is_tw) {
@@ -1652,6 +1644,16 @@ __device__ __forceinline__ void chain_lean_tail(const ChainArgs& a, const ChainS
         if constexpr (RES) { const int e = (int)(o - cd.vec_off); vec_l[e] = w; vec_l[nvec + e] = m; vec_l[2 * nvec + e] = v; }
         else { a.plane[o] = w; a.plane[a.plane_stride + o] = m; a.plane[2 * a.plane_stride + o] = v; }
     };
+    if (g.bn && tid < L * 16 && (tid & 15) < R) {      // running statistics: momentum 0.1, unbiased variance (torch BatchNorm1d, train mode)
+        const int i = tid >> 4, c = tid & 15, vbl = i * g.vec_cell_stride;
+        const float mu = ll.scr[768 + i * 32 + c], var = ll.scr[LEAN_BNV + i * 16 + c], nf = (float)cs.nvalid;
+        float rm = vecW[vbl + VEC_RM * Rp + c], rv = vecW[vbl + VEC_RV * Rp + c];
+        const float unb = var * (nf / (nf - 1.0f));
+        rm += g.bn_mom * (mu - rm);
+        rv += g.bn_mom * (unb - rv);
+        if constexpr (RES) { vec_l[vbl + VEC_RM * Rp + c] = rm; vec_l[vbl + VEC_RV * Rp + c] = rv; }
+        else { a.plane[cvec_off + vbl + VEC_RM * Rp + c] = rm; a.plane[cvec_off + vbl + VEC_RV * Rp + c] = rv; }
+    }
     if (a.logits_out) return;       // train-mode forward only: no statistics, no update
     if (lean_ce_in_regs(a)) {
         // the register softmax left (m, sum e) per row in red_l and the raw logits in LDS: row loss = ln(sum_c e^x_c) - x_label and
