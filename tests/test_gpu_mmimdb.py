@@ -130,3 +130,48 @@ def test_searchers_for_the_other_datasets(dev):
     data = AVMNISTSearcher(args, dev, tabs).search()
     confs, accs, _ = data.get_k_best(2)
     assert len(confs) == 2 and all(0.0 <= a <= 1.0 for a in accs)
+
+
+def test_full_size_c5_properties(dev, monkeypatch):
+    """BASELINE configs[4] at FULL size through the boundary the search calls (round 6): 512 sampled L = 4 MM-IMDB-shaped
+    configurations (bench.py's `--workload c5` population: np.random.seed(0) over get_possible_layer_configurations(0)), R = 16, B = 20,
+    fp16 taps, N = 15,552 / 2,608, the reference's per-candidate shuffles, ONE epoch.  No reference network exists for this searchable
+    (SURVEY D7), so the properties are the engine's own: (1) the share trains as resident rounds and every candidate ends with a finite F1
+    in [0, 1] (> 90 % above 0 after one epoch); (2) the call is deterministic — the same torch seed gives the same 512 numbers; (3) a candidate's result does not depend
+    on the round it trains in beyond the column-chunk summation order: the first 24 candidates trained as their OWN call (one resident
+    round, its own unit widths) agree with their values inside the 512-candidate call to 0.02 F1, mean to 0.005; (4) forcing the
+    launch-per-phase schedule for the whole share (MFAS_NO_ROUNDS=1) moves the population mean by < 0.005."""
+    import bench
+    import mfas_amd as M
+    from mfas_amd import mmimdb_searchable as MM
+    from mfas_amd import ntu_searchable as NS
+    train, devt = bench.synth_mm_tables(15552, 2608, dev)
+    np.random.seed(0)
+    layer = MM.get_possible_layer_configurations(0)
+    confs = [np.array([layer[i] for i in np.random.choice(len(layer), 4)]) for _ in range(512)]
+    args = SimpleNamespace(vid_len=(8, 32), num_outputs=MM.MM_NUM_OUTPUTS, drpt=0.5, inner_representation_size=16, batchnorm=False, alphas=False,
+                           multitask=False, weightsharing=False, batchsize=20, eta_max=1e-3, eta_min=1e-6, Ti=1, Tm=2, use_dataparallel=False,
+                           verbose=False, epochs=1, engine_init="torch", engine_order="per_candidate", engine_profile=True)
+    loaders = {"train": M.FeatureLoader(train, 20, shuffle=True), "dev": M.FeatureLoader(devt, 20, shuffle=False)}
+
+    def call(cs):
+        torch.manual_seed(5)
+        NS.PROFILE.clear()
+        out = np.array([float(x) for x in MM.train_sampled_models(cs, MM.Searchable_Text_Image_Net, loaders, args, dev)])
+        return out, [p[3] for p in NS.PROFILE]
+
+    f1, scheds = call(confs)
+    assert len(scheds) >= 8 and all(s["persistent"] for s in scheds), scheds            # resident rounds
+    assert sum(s["candidates"] for s in scheds) == 512
+    assert np.isfinite(f1).all() and (f1 >= 0.0).all() and (f1 <= 1.0).all()
+    print("c5 full size, one epoch: mean best F1 %.4f, %d of 512 at 0" % (f1.mean(), int((f1 == 0).sum())))
+    assert (f1 > 0.0).mean() > 0.9 and f1.mean() > 0.05, (f1.mean(), (f1 > 0).mean())       # (one epoch: a few sigmoid-heavy configurations have not left F1 = 0 yet)
+    again, _ = call(confs)
+    assert np.array_equal(f1, again)
+    sub, ss = call(confs[:24])
+    assert len(ss) == 1 and ss[0]["persistent"]
+    assert np.abs(sub - f1[:24]).max() < 0.02 and abs(sub.mean() - f1[:24].mean()) < 0.005, (sub, f1[:24])
+    monkeypatch.setenv("MFAS_NO_ROUNDS", "1")
+    lpp, sl = call(confs)
+    assert len(sl) == 1 and not sl[0]["persistent"]
+    assert abs(lpp.mean() - f1.mean()) < 0.005 and np.abs(lpp - f1).max() < 0.05, (lpp.mean(), f1.mean())
