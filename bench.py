@@ -556,7 +556,7 @@ def main():
         traffic = mfma = traffic_src = mfma_src = None
         headline = plain and a.pop == 128 and a.R == 128 and not a.no_bn and world == 1
         prof_avg_us = prof_src = None
-        for tag in ("r05", "r04", "r03", "r02", "r01"):      # the committed rocprofv3 --kernel-trace --stats average of the headline kernel (builder's box)
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):      # the committed rocprofv3 --kernel-trace --stats average of the headline kernel (builder's box)
             cp = os.path.join(ROOT, "profiles", f"{tag}_bench_pop128_kernel_stats.csv")
             if headline and prof_avg_us is None and os.path.exists(cp):
                 try:
@@ -567,7 +567,7 @@ def main():
                     prof_src = f"profiles/{tag}_bench_pop128_kernel_stats.csv ({top['Name'][:48]}, {top['Calls']} calls; rocprofv3 --kernel-trace --stats of this command on the builder's box)"
                 except Exception:
                     prof_avg_us = None
-        for tag in ("r05", "r04", "r03", "r02", "r01"):
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
             tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
             if headline and traffic is None and os.path.exists(tp):
                 try:

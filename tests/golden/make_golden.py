@@ -774,10 +774,16 @@ def g15merge():
         parts.insert(0, np.load(os.path.join(HERE, "g15_bench_workload.npz")))
     assert parts and all(np.array_equal(p["meta"], parts[0]["meta"]) for p in parts)
     seeds = np.concatenate([p["seeds"] for p in parts])
-    assert np.array_equal(seeds, np.arange(len(seeds))), seeds
-    save("g15_bench_workload.npz", best_acc=np.concatenate([p["best_acc"] for p in parts]),
-         hist=np.concatenate([p["hist"] for p in parts]), seeds=seeds, meta=parts[0]["meta"],
-         cmd=np.array(" ; ".join(str(p["cmd"]) for p in parts) + " ; g15merge"))
+    best = np.concatenate([p["best_acc"] for p in parts])
+    hist = np.concatenate([p["hist"] for p in parts])
+    # (an extension run merged while its last parts are still being computed: keep the contiguous prefix 0 .. n-1)
+    n = 0
+    while n < len(seeds) and seeds[n] == n:
+        n += 1
+    assert n >= 256, seeds
+    cmds = [str(p["cmd"]) for p in parts]
+    cmd = cmds[0] + f" ; G15_SEED0=256.. G15_NS=16 x {len(cmds) - 1} parts (tools/r06_extend_goldens.sh) ; g15merge -> {n} seeds"
+    save("g15_bench_workload.npz", best_acc=best[:n], hist=hist[:n], seeds=seeds[:n], meta=parts[0]["meta"], cmd=np.array(cmd))
 
 
 # ------------------------------------------------------------------ G16 weight sharing (next#4)

@@ -15,7 +15,7 @@ starts, gate 3 s.e. + 0.1 % <= 0.2 %; and G15 is the bench workload itself with 
 (E=10, snr 0.12) gated on the mean best dev accuracy over 1,024 engine seeds vs 256 reference seeds: the reference's own seed
 sigma there is 0.90 %, so that gate is 3 s.e. + 0.1 % = +-0.29 % (asserted <= 0.3 % in the test; G18c, masks injected, is the
 +-0.2 % one).  G19a / G19b are the same two experiments in the SEARCH-DEFAULT regime (R=16, no batchnorm, B=20: BASELINE
-configs[2] at full size) — pointwise +-0.1 % and +-0.24 % on the population mean."""
+configs[2] at full size) — pointwise +-0.1 % and, round 6, +-0.2 % on the population mean (128 reference calls)."""
 import numpy as np
 import pytest
 
@@ -204,15 +204,15 @@ def test_engine_bench_workload_vs_reference():
     g = golden("g15_bench_workload.npz")
     N, Nd, snr, R, B, E, bn, drpt = g["meta"]
     N, Nd, R, B, E = int(N), int(Nd), int(R), int(B), int(E)
-    assert float(snr) == 0.12 and len(g["best_acc"]) >= 256 and E == 10     # the bench workload, not a neighbour of it
+    assert float(snr) == 0.12 and len(g["best_acc"]) >= 560 and E == 10     # the bench workload, not a neighbour of it
     hp = O.Hyper(R=R, B=B, bn=bool(bn), drpt=float(drpt), epochs=E)
     ttr, tdv = O.synth_table(N, 1, snr=float(snr), quant="bf16"), O.synth_table(Nd, 2, snr=float(snr), quant="bf16")
     dev = torch.device("cuda:0")
     ta, tb = M.FeatureTable.from_numpy(ttr, dev, torch.bfloat16), M.FeatureTable.from_numpy(tdv, dev, torch.bfloat16)
     best, per_epoch = [], []
-    for grp in range(64):
-        seeds = list(range(16 * grp, 16 * grp + 16))
-        pop = M.Population(engine_hyper(hp), [CONF] * 16, dev, drop_seeds=[7000 + s for s in seeds])
+    for grp in range(64):          # round 6: 4,096 engine seeds (64 populations of 64; 1,024 before) against the extended reference fixture
+        seeds = list(range(64 * grp, 64 * grp + 64))
+        pop = M.Population(engine_hyper(hp), [CONF] * 64, dev, drop_seeds=[7000 + s for s in seeds])
         pop.init([3000 + 10 * s for s in seeds])          # == O.init_params(conf, hp, 3000 + 10 * seed): the reference's starts
         order = M.ntu_searchable.make_order(N, E, True, 900 + grp, dev)
         stats, status = pop.train(ta, tb, E, etas_for(hp, N), order=order)
@@ -244,7 +244,8 @@ def test_engine_bench_workload_vs_reference():
     gate(best, ref_best, "best dev acc")
     se_best = np.sqrt(ref_best.std(ddof=1) ** 2 / len(ref_best) + best.std(ddof=1) ** 2 / len(best))
     print(f"G15: engine {best.mean():.5f} ({len(best)} seeds) reference {ref_best.mean():.5f} ({len(ref_best)} seeds) gate {3.0 * se_best + TOL:.5f}")
-    assert 3.0 * se_best + TOL <= 0.003             # the gate that is claimed (reference sigma 0.90 %)
+    # the gate that is claimed (reference sigma 0.90 %): round 6 bought reference seeds with CPU time — >= 1,000 of them make it 0.2 %
+    assert 3.0 * se_best + TOL <= (0.00205 if len(ref_best) >= 1000 else 0.0023), (3.0 * se_best + TOL, len(ref_best))
     for e in range(E):
         gate(per_epoch[:, e], ref_epoch[:, e], f"dev acc epoch {e}")
     assert outliers[0][1] == 0                      # the returned quantity itself has no stragglers
@@ -254,12 +255,12 @@ def test_engine_bench_workload_vs_reference():
 # ------------------------------------------------------------------ G19: the SEARCH-DEFAULT regime at full size (BASELINE configs[2])
 # What _epnas actually issues (main_searchable_ntu.py:26-47,56; models/searchable.py:90,120): R=16, no batchnorm, drpt 0.5, B=20.
 # G19b = ONE train_sampled_models call on bench.py's configs[2] population (the 16 np.random.seed(0) L=4 confs, E=10,
-# N=10,000/5,600, bf16-rounded taps at snr 0.12) through the unchanged reference with its OWN dropout / shuffle streams, 64 seeds.
+# N=10,000/5,600, bf16-rounded taps at snr 0.12) through the unchanged reference with its OWN dropout / shuffle streams, 128 seeds (64 in round 5).
 # The reference's seed-to-seed spread of one candidate's best dev accuracy is 0.4 ... 3.3 % here (chance is 1.7 %, the best conf
 # reaches 24 %), so a per-conf gate of 3 s.e. + 0.1 % is +-0.3 ... 1.6 % with 64 reference seeds and would need > 1,500 reference
 # seeds (11 CPU-hours each conf) to reach 0.3 % everywhere; the quantity the driver's line carries, `small_pop.c2.mean_best_dev_acc`
-# (the population mean of ONE call), has a spread of 0.29 % and IS gated at <= 0.3 % (asserted below).
-G19_ENGINE_CALLS = 128
+# (the population mean of ONE call), has a spread of 0.29 % and IS gated at <= 0.2 % (round 6; asserted below).
+G19_ENGINE_CALLS = 256
 
 
 def g19b():
@@ -281,23 +282,23 @@ def bench_c2_confs():
 def test_search_default_reference_fixture():
     """G19b is the workload bench.py calls configs[2] (same 16 confs, same sizes, same snr), holds >= 64 reference seeds, is in
     the regime the metric is sensitive in, and makes the gate on the population mean (what `small_pop.c2.mean_best_dev_acc`
-    reports) at most 0.3 % top-1 with G19_ENGINE_CALLS engine calls."""
+    reports) at most 0.2 % top-1 with G19_ENGINE_CALLS engine calls."""
     best, dev_acc, confs = g19b()
-    assert best.shape[0] >= 64 and best.shape[1] == 16 and dev_acc.shape == best.shape + (10,)
+    assert best.shape[0] >= 128 and best.shape[1] == 16 and dev_acc.shape == best.shape + (10,)
     assert np.array_equal(confs, np.array(bench_c2_confs()))
     np.testing.assert_allclose(dev_acc.max(axis=2), best, atol=6e-5)          # best = max over epochs (printed to 4 decimals)
     pm = best.mean(axis=1)                                                    # one call's population mean
     assert 0.08 < pm.mean() < 0.14 and best.mean(axis=0).max() > 0.2 and best.mean(axis=0).min() > 1.5 / 60
     s = pm.std(ddof=1)
-    assert 3.0 * s * np.sqrt(1.0 / len(pm) + 1.0 / G19_ENGINE_CALLS) + TOL <= 0.003, (s, len(pm))
+    assert 3.0 * s * np.sqrt(1.0 / len(pm) + 1.0 / G19_ENGINE_CALLS) + TOL <= 0.002, (s, len(pm))       # round 6: 128 reference calls (64 before: 0.0024)
 
 
 @pytest.mark.gpu
 def test_engine_search_default_population_vs_reference():
     """BASELINE configs[2] at FULL size through the boundary the search calls — train_sampled_models with the engine's defaults
     (torch-stream initialisation, per-candidate shuffles, its own dropout stream), G19_ENGINE_CALLS calls of the 16-conf
-    population under different torch seeds — against 64 calls of the unchanged reference (G19b).  Gates: the population mean of
-    the best dev accuracy (the number bench.py reports for configs[2]) within 3 s.e. + 0.1 %, that gate <= 0.3 %; every single
+    population under different torch seeds — against 128 calls of the unchanged reference (G19b).  Gates: the population mean of
+    the best dev accuracy (the number bench.py reports for configs[2]) within 3 s.e. + 0.1 %, that gate <= 0.2 %; every single
     conf within 3 s.e. + 0.1 % of its own reference mean (0.3 ... 1.6 % by the reference's own spread) and spread within x2.5."""
     torch = pytest.importorskip("torch")
     from types import SimpleNamespace
@@ -321,7 +322,7 @@ def test_engine_search_default_population_vs_reference():
     gate = 3.0 * se + TOL
     print(f"G19b population mean: engine {pm.mean():.5f} (sd {pm.std(ddof=1):.5f}, {len(pm)} calls) reference {pr.mean():.5f} "
           f"(sd {pr.std(ddof=1):.5f}, {len(pr)} calls) gate {gate:.5f}")
-    assert gate <= 0.003
+    assert gate <= 0.00205            # round 6: 3 s.e. + 0.1 % <= 0.2 % top-1 (128 reference calls x 256 engine calls; 0.24 % in round 5)
     assert abs(pm.mean() - pr.mean()) <= gate, (pm.mean(), pr.mean(), se)
     assert pm.std(ddof=1) <= 2.5 * pr.std(ddof=1) + 1e-4
     for j in range(16):
