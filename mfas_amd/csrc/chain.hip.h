@@ -1257,13 +1257,18 @@ __device__ __forceinline__ void chain_lean(const ChainArgs& a, const ChainStep& 
     // Parity double-buffering of the regions is enough: a wave cannot pass exchange k + 1 before its partner has finished reading k.
     uint32_t* bnf = reinterpret_cast<uint32_t*>(ll.scr + LEAN_BNF);
     const uint32_t bnseq = (uint32_t)cs.gstep * (uint32_t)MFAS_MAX_CELLS + 1u;
+    // (the LDS unit executes ONE wave's instructions in issue order — data store, then number store: no wait between them; and a wave's
+    //  data read is issued only after its poll has returned the number: compiler barriers keep that order, no s_waitcnt is added)
     auto pair_post = [&](float* slot, const f32x4 val, const int kind, const int i) {
-        if (l15 == 0) *reinterpret_cast<f32x4*>(slot + r0) = val;
-        __hip_atomic_store(bnf + (kind * 2 + (i & 1)) * 2 + wave, bnseq + (uint32_t)i, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (l15 == 0) *as_lds(reinterpret_cast<f32x4*>(slot + r0)) = val;
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(as_lds(bnf + (kind * 2 + (i & 1)) * 2 + wave), bnseq + (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
     };
     auto pair_wait = [&](const int kind, const int i) {
         const uint32_t* f = bnf + (kind * 2 + (i & 1)) * 2 + (wave ^ 1);
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != bnseq + (uint32_t)i) { }
+        while (__hip_atomic_load(as_lds(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != bnseq + (uint32_t)i) { asm volatile("" ::: "memory"); }
+        asm volatile("" ::: "memory");
     };
     static_assert(MB <= 2, "pairwise exchange: two tile waves");
     float* gv2 = ll.scr + 256;                               // [cell][dgamma | dbeta][16]
