@@ -438,14 +438,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     const uint32_t h0 = lowbias32(cd.drop_seed + 0x9E3779B9U * (uint32_t)(cs.gstep + 1));
     const int64_t sbo = cd.step_off;   // this candidate's step buffers inside a.stepbuf (COH accesses index from the base)
 
-    if (tid < Bp) {
-        int lab = 0;
-        if (tid < nvalid) {
-            const int32_t* ord = cand_order(a.order, g, cd.gidx);
-            const int64_t row = ord ? (int64_t)ord[cs.pos_t + tid] : (int64_t)(cs.base_t + tid);
-            lab = g.loss_mode == 0 ? a.tab.label[row] : (int)row;   // mode 1 keeps the table row for the multi-hot targets
-        }
-        lab_l[tid] = lab;
+    // labels: order entry -> label are two DEPENDENT loads; consumed at once (round 1-5 form: `lab_l[tid] = label[ord[..]]` right here) they
+    // held wave 0 — and with it the phase-0 barrier — through two memory round trips before it had requested anything else.  Now the
+    // order entry is requested here, the label under the last forward cell, and the LDS store sits in front of the head's barrier.
+    int64_t lab_row = 0;
+    int lab_r = 0;
+    if (tid < Bp && tid < nvalid) {
+        const int32_t* ord = cand_order(a.order, g, cd.gidx);
+        lab_row = ord ? (int64_t)ord[cs.pos_t + tid] : (int64_t)(cs.base_t + tid);
     }
 
     // ------------------------------------------------------------------ phase 0: all 512 threads reduce the
@@ -519,6 +519,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
     // ------------------------------------------------------------------ forward chain
     for (int i = 0; i < L; ++i) {
         CT_STAMP(1 + i);
+        if (i == L - 1 && tid < Bp && tid < nvalid) lab_r = g.loss_mode == 0 ? a.tab.label[lab_row] : (int)lab_row;   // (mode 1 keeps the table row for the multi-hot targets)
         if (pf && i >= 1) {   // wa holds P_i; request the NEXT product's tiles now: P_{i+1}, or the head after the last cell
             if (i + 1 < L) { if (wave < nrb) issue_tiles<COH>(wb, W, cd.seg_off[i + 1][2] + (int64_t)wave * nrb * 256, nrb, lane); }
             else if (wave < ncb) issue_tiles<COH>(wb, W, cd.head_off + (int64_t)wave * nrb * 256, nrb, lane);
@@ -662,6 +663,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const ChainStep& 
                 for (int q = 0; q < 4; ++q) lg_l[(mb * 16 + 4 * lg + q) * SC + c] = acc[mb][q] + bias;
         }
     }
+    if (tid < Bp) lab_l[tid] = lab_r;
     lds_barrier();
     CT_STAMP(6);
     if (a.logits_out) {   // train-mode forward only
@@ -1930,6 +1932,8 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
 #pragma unroll
     for (int i = 0; i < MFAS_MAX_CELLS; ++i) nlbits |= (cd.conf[i][2] & 3) << (2 * i);
     const int cgidx = cd.gidx;
+    asm volatile("" :: "s"(nlbits), "s"(cgidx));
+    CS_STAMP(34);
     // the candidate record's offsets the cell loops need, read ONCE (behind a barrier a field of `cd` is a fresh scalar load: a few hundred
     // cycles in front of every product's tile requests)
     const int64_t oP1 = cd.seg_off[1][2], oP2 = cd.seg_off[2][2], oP3 = cd.seg_off[3][2];
@@ -1950,14 +1954,6 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
     const int64_t xoth_par = xq + (int64_t)(a.xpar ^ 1) * (XCH_SLOTS * 8 * 256);
 
     // ---- entry: everything that does not depend on the step's data is requested first
-    // (the labels — order entry -> label: two dependent loads behind the candidate record — are requested here and only dropped into LDS
-    //  in front of the head's barrier: nothing at entry waits for them)
-    int lab_r = 0;
-    if (tid < Bp && tid < nvalid) {
-        const int32_t* ord = cand_order(a.order, g, cd.gidx);
-        const int64_t row = ord ? (int64_t)ord[cs.pos_t + tid] : (int64_t)(cs.base_t + tid);
-        lab_r = g.loss_mode == 0 ? a.tab.label[row] : (int)row;
-    }
     // the head's tiles: class block (wave - 4) of every part, in registers until the head product
     // (wave w: class block w & 3, the even (w < 4) or odd (w >= 4) k-blocks — chain_body's two MFMA chains on two waves; four tiles =
     //  16 registers per wave: eight cost the 128-register build spills)
@@ -1989,11 +1985,6 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
         }
     };
     if (L > 1) stage_issue(W, oP1, nrb);        // P_1
-    // this part's pieces of the OTHER parity back to "not written" (read by nobody in this launch)
-    for (int e = tid; e < XCH_SLOTS * NRO * 64; e += CHAIN_THREADS) {
-        const int s = e / (NRO * 64), r = e - s * (NRO * 64);
-        stc4<true>(a.xch, xoth_par + ((int64_t)s * 8 + rb0) * 256 + r * 4, __builtin_bit_cast(f32x4, (u32x4){XCH_SENT, XCH_SENT, XCH_SENT, XCH_SENT}));
-    }
     // vector block (W plane): own columns of every cell, head bias — REQUESTED here (two elements per thread cover 4 x 5 x NCOL <= 1024),
     // dropped into LDS behind the slab sums below: every load of the entry is in flight at once (one round trip, not one per loop)
     static_assert(MFAS_MAX_CELLS * 5 * (8 / NS) * 16 <= 2 * CHAIN_THREADS, "two vector elements per thread");
@@ -2036,6 +2027,7 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             }
         }
     }
+    CS_STAMP(35);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int e = tid + u * CHAIN_THREADS;
@@ -2053,11 +2045,27 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
                 keepm |= (drop_keep(h0, i, (uint32_t)((4 * lg + q) * R + r), g.drop_thr) ? 1u : 0u) << (4 * i + q);
         }
     };
+    CS_STAMP(36);
+    // this part's pieces of the OTHER parity back to "not written" (read by nobody in this launch)
+    for (int e = tid; e < XCH_SLOTS * NRO * 64; e += CHAIN_THREADS) {
+        const int s = e / (NRO * 64), r = e - s * (NRO * 64);
+        stc4<true>(a.xch, xoth_par + ((int64_t)s * 8 + rb0) * 256 + r * 4, __builtin_bit_cast(f32x4, (u32x4){XCH_SENT, XCH_SENT, XCH_SENT, XCH_SENT}));
+    }
+    // the labels — order entry -> label: two DEPENDENT loads behind the candidate record — belong to the idle wave 7 and to the end of the
+    // entry: in front of the slab requests (round 6, first form) the wait for the order entry held every later request of wave 0 back by a
+    // memory round trip, and the write-through sentinel stores above sat in front of the slab loads' in-order return (entry 17 k -> 9 k cycles)
+    const int lab_b = tid - (CHAIN_THREADS - 64);
+    int64_t lab_row = 0;
+    if (lab_b >= 0 && lab_b < Bp && lab_b < nvalid) {
+        const int32_t* ord = cand_order(a.order, g, cd.gidx);
+        lab_row = ord ? (int64_t)ord[cs.pos_t + lab_b] : (int64_t)(cs.base_t + lab_b);
+    }
     keep_bits(0);
     if (L > 1) stage_store(tb, nrb);
     CS_STAMP(22);
     __syncthreads();
     CS_STAMP(0);
+    int lab_r = 0;
 
     // piece of another part -> the LDS operand buffer (row-major [b][SX]); one 16-byte piece per thread: wave w takes row block
     // (rb0 + NRO + w) mod 8 — the foreign row blocks come first, so the MAIN waves poll too (their poll's returned load is also
@@ -2093,6 +2101,7 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
     for (int i = 0; i < L; ++i) {
         CS_STAMP(1 + i);
         // next product's tiles: P_{i+1} -> tb[(i+1) & 1]; after the last cell the first backward product (head^T, ncb k-blocks) -> tb[L & 1]
+        if (i == L - 1 && lab_b >= 0 && lab_b < Bp && lab_b < nvalid) lab_r = g.loss_mode == 0 ? a.tab.label[lab_row] : (int)lab_row;
         const bool st_fw = i + 1 < L && i >= 1;          // (P_1 was staged at entry)
         const bool st_hd = i + 1 == L;
         if (st_fw) stage_issue(W, offP(i + 1), nrb);
@@ -2222,7 +2231,7 @@ __device__ __forceinline__ void chain_split(const ChainArgs& a, const ChainStep&
             for (int q = 0; q < 4; ++q) lg_l[(4 * lg + q) * SC + c] = acc[q] + bias;
         }
     }
-    if (tid < Bp) lab_l[tid] = lab_r;
+    if (lab_b >= 0 && lab_b < Bp) lab_l[lab_b] = lab_r;
     lds_barrier();
     CS_STAMP(6);
     if (g.loss_mode == 1) {

@@ -1784,6 +1784,7 @@ extern "C" int mfas_population_train(mfas_population* p, const mfas_table* train
             if (p->chain_split) {      // chain_split's extra stamps: forward cell 1 product done | out sent | tail done | fetched;  backward cell 2 the same;  softmax done;  entry staged
                 fprintf(stderr, "  | split:");
                 for (int i = 13; i < 23; ++i) fprintf(stderr, " %d", ts[i]);
+                fprintf(stderr, "  | entry: record here %d, slabs summed %d, vector block in LDS %d", ts[34], ts[35], ts[36]);
                 fprintf(stderr, "  | 10 ns ticks: chain of step 3 %d, end of chain 3 -> entry of chain 4 %d, chain of step 4 %d", ts[24] - ts[23], ts[25] - ts[24], ts[26] - ts[25]);
                 fprintf(stderr, "; end of chain 3 -> first cell-0 unit sees its flag %d -> last sweep unit of the launch ends %d -> entry of chain 4 %d", (int32_t)((uint32_t)ts[28] - (uint32_t)ts[24]), (int32_t)((uint32_t)ts[27] - (uint32_t)ts[28]), (int32_t)((uint32_t)ts[25] - (uint32_t)ts[27]));
                 fprintf(stderr, "; unit (cell 0, S, chunk 0) after the end of chain 3: flag seen %d, dy staged %d, tiles done %d, slab drained %d, arrival counted %d",
