@@ -1007,6 +1007,52 @@ def test_chain_split_bit_identical(dev, seed):
             assert np.array_equal(out[ref][4][k], out["split"][4][k]), (ref, k, "second call")
 
 
+@pytest.mark.parametrize("mode", ["multitask", "multilabel"])
+def test_chain_split_other_heads_bit_identical(dev, mode):
+    """chain_split replicates the head and the loss on every part: the multitask head (summed-logit argmax, three-term loss: the
+    16-lanes-per-row softmax, not the lean one) and the multi-label head (weighted BCE rows, F1-samples dev metric, loss_mode 1) at
+    R = 128 must equal the one-CU chain bit for bit too — statistics incl. train loss sums, W, m, v."""
+    import os
+    from mfas_amd import FeatureTable, Hyper, Population
+    rng = np.random.default_rng(77)
+    K, B, N, C = 3, 16, 16 * 5 + 7, (60 if mode == "multitask" else 23)
+    hp = Hyper(R=128, C=C, B=B, bn=True, drpt=0.5, multitask=(mode == "multitask"))
+    if mode == "multilabel":
+        hp.loss_mode, hp.f1_threshold = 1, 0.3
+    confs = [np.stack([rng.integers(0, 4, L), rng.integers(0, 4, L), rng.integers(0, 3, L)], 1) for L in (4, 2, 3)]
+
+    def table(n, seed):
+        t = FeatureTable.synthetic(n, seed, dev, torch.bfloat16, snr=0.5, C=C, with_logits=(mode == "multitask"))
+        if mode == "multilabel":
+            g = torch.Generator(device=dev)
+            g.manual_seed(seed)
+            t = FeatureTable(t.taps, torch.zeros(n, dtype=torch.int32, device=dev), multilabel=(torch.rand(n, C, generator=g, device=dev) < 0.2).float())
+        return t
+    tr, dv = table(N, 3), table(40, 4)
+    etas = O.eta_sequence(1e-3, 1e-6, 1, 2, N / B, 2 * 6)
+    out = {}
+    for split in ("0", None):
+        if split is not None:
+            os.environ["MFAS_CHAIN_SPLIT"] = split
+        try:
+            pop = Population(hp, confs, dev, drop_seeds=[5, 6, 7], chunk_cols=128)
+        finally:
+            os.environ.pop("MFAS_CHAIN_SPLIT", None)
+        assert pop.schedule()["chain_cus"] == (1 if split == "0" else 4) and pop.schedule()["groups"] == -1
+        if mode == "multilabel":
+            pop.set_pos_weight(O.mm_pos_weight(C))
+        pop.init([1, 2, 3])
+        stats, status = pop.train(tr, dv, 2, etas)
+        assert not status.any()
+        out[split] = (stats.tobytes(), [[pop.get_params(k, pl).cpu().numpy() for pl in range(3)] for k in range(K)])
+        assert (stats["train_loss_sum"] != 0).all()
+        pop.close()
+    assert out["0"][0] == out[None][0]
+    for k in range(K):
+        for pl in range(3):
+            assert np.array_equal(out["0"][1][k][pl], out[None][1][k][pl]), (k, pl)
+
+
 def _hooks_variant_loaded():
     from mfas_amd import _lib
     return _lib.tuning()["hooks"] == "1"
