@@ -769,7 +769,7 @@ def g15():
 
 def g15merge():
     import glob
-    parts = [np.load(f) for f in sorted(glob.glob(os.path.join(HERE, "g15_part_*.npz")))]
+    parts = sorted((np.load(f) for f in glob.glob(os.path.join(HERE, "g15_part_*.npz"))), key=lambda p: int(p["seeds"][0]))
     if parts and int(parts[0]["seeds"][0]) != 0:      # extension run (round 6): the committed fixture holds seeds 0 … n-1, the parts go on from n
         parts.insert(0, np.load(os.path.join(HERE, "g15_bench_workload.npz")))
     assert parts and all(np.array_equal(p["meta"], parts[0]["meta"]) for p in parts)

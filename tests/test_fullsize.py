@@ -12,9 +12,8 @@ The remedy for chaos is samples, not a wider gate: G14 holds 64 starts of the re
 (snr 0.10: dev accuracy 0.69 instead of a saturated 0.98); G18c is the same experiment WITH dropout 0.5 (the reference's dropout
 modules swapped for the engine's masks, shuffled fixed order, bench.py's snr 0.12): 512 reference starts against 2,048 engine
 starts, gate 3 s.e. + 0.1 % <= 0.2 %; and G15 is the bench workload itself with the reference's OWN dropout / shuffle streams
-(E=10, snr 0.12) gated on the mean best dev accuracy over 1,024 engine seeds vs 256 reference seeds: the reference's own seed
-sigma there is 0.90 %, so that gate is 3 s.e. + 0.1 % = +-0.29 % (asserted <= 0.3 % in the test; G18c, masks injected, is the
-+-0.2 % one).  G19a / G19b are the same two experiments in the SEARCH-DEFAULT regime (R=16, no batchnorm, B=20: BASELINE
+(E=10, snr 0.12) gated on the mean best dev accuracy over 4,096 engine seeds vs 1,024 reference seeds (round 6; 1,024 vs 256 in
+round 5): the reference's own seed sigma there is 0.87 %, so that gate is 3 s.e. + 0.1 % = +-0.19 % (asserted <= 0.205 % in the test).  G19a / G19b are the same two experiments in the SEARCH-DEFAULT regime (R=16, no batchnorm, B=20: BASELINE
 configs[2] at full size) — pointwise +-0.1 % and, round 6, +-0.2 % on the population mean (128 reference calls)."""
 import numpy as np
 import pytest
@@ -197,14 +196,14 @@ def test_engine_bench_workload_vs_reference():
     N=10,000/5,600, bf16-rounded taps at snr 0.12 — bench.py's tables) through the unchanged reference with its OWN dropout
     (Philox) and shuffle streams for 256 seeds (train_searchable/ntu.py:14-89).  The engine's streams are its own, so the gate
     is statistical: mean best dev accuracy over 1,024 engine seeds (64 populations of 16, each with its own epoch orders; the
-    first 256 initial states are the reference's own) within 3 s.e. + 0.1 % = +-0.29 % (asserted <= 0.3 %); the per-epoch dev accuracies likewise.  (The
+    first 1,024 initial states are the reference's own) within 3 s.e. + 0.1 % = +-0.19 % (asserted <= 0.205 %; round 6: 1,024 reference seeds, 4,096 engine seeds); the per-epoch dev accuracies likewise.  (The
     pointwise pin of the dropout path is G18a/b/c, where the reference runs with the engine's masks.)"""
     torch = pytest.importorskip("torch")
     import mfas_amd as M
     g = golden("g15_bench_workload.npz")
     N, Nd, snr, R, B, E, bn, drpt = g["meta"]
     N, Nd, R, B, E = int(N), int(Nd), int(R), int(B), int(E)
-    assert float(snr) == 0.12 and len(g["best_acc"]) >= 560 and E == 10     # the bench workload, not a neighbour of it
+    assert float(snr) == 0.12 and len(g["best_acc"]) >= 1000 and E == 10     # the bench workload, not a neighbour of it
     hp = O.Hyper(R=R, B=B, bn=bool(bn), drpt=float(drpt), epochs=E)
     ttr, tdv = O.synth_table(N, 1, snr=float(snr), quant="bf16"), O.synth_table(Nd, 2, snr=float(snr), quant="bf16")
     dev = torch.device("cuda:0")
