@@ -194,8 +194,8 @@ def test_engine_fullsize_dropout_vs_reference():
 def test_engine_bench_workload_vs_reference():
     """G15: BASELINE configs[1] exactly as bench.py runs it (conf 4, R=128, BN, drpt 0.5, shuffled, B=16, E=10,
     N=10,000/5,600, bf16-rounded taps at snr 0.12 — bench.py's tables) through the unchanged reference with its OWN dropout
-    (Philox) and shuffle streams for 256 seeds (train_searchable/ntu.py:14-89).  The engine's streams are its own, so the gate
-    is statistical: mean best dev accuracy over 1,024 engine seeds (64 populations of 16, each with its own epoch orders; the
+    (Philox) and shuffle streams for 1,024 seeds (train_searchable/ntu.py:14-89).  The engine's streams are its own, so the gate
+    is statistical: mean best dev accuracy over 4,096 engine seeds (64 populations of 64, each with its own epoch orders; the
     first 1,024 initial states are the reference's own) within 3 s.e. + 0.1 % = +-0.19 % (asserted <= 0.205 %; round 6: 1,024 reference seeds, 4,096 engine seeds); the per-epoch dev accuracies likewise.  (The
     pointwise pin of the dropout path is G18a/b/c, where the reference runs with the engine's masks.)"""
     torch = pytest.importorskip("torch")
