@@ -1852,10 +1852,15 @@ __device__ __forceinline__ void lean_res_store(const ChainArgs& a, const int bid
 //     the sentinel (all-ones words: not a value the arithmetic produces), then drops it into the LDS operand buffer.  No flags, no
 //     store drains: a hand-off is one store -> load round trip.  Parities alternate per chain launch; a launch resets the pieces it
 //     owns in the OTHER parity (the kernel boundary orders the reset before the next launch's data);
-//   * the head (16 x 128 x 64) and the softmax are REPLICATED on every part (waves 4 .. 4 + ncb - 1, tiles held in registers since
-//     entry): no exchange for logits / dlogits; statistics, dlogits, the head bias belong to part 0;
-//   * the weight tiles of the next product are staged global -> registers -> LDS by all eight waves while the main waves compute
-//     (the 128-register build of the same-group launch has no room for chain_body's register prefetch);
+//   * the head (16 x 128 x 64) and the softmax are REPLICATED on every part (class block c on the wave pair (c, c + 4): even / odd
+//     k-blocks — chain_body's two MFMA chains — four tiles per wave held in registers since entry, the odd sums cross through LDS): no
+//     exchange for logits / dlogits; statistics, dlogits, the head bias belong to part 0;
+//   * a product's odd-k MFMA chain runs on a HELPER wave (main wave w: even k-blocks on top of the feature sums; wave w + NRO: odd
+//     k-blocks from zero; handed over through LDS at a barrier every wave of the part passes: the same two sums chain_body adds);
+//   * the weight tiles of the next product are staged global -> registers -> LDS (ONE buffer: read before a product's barrier, written
+//     behind it) by all eight waves while the main waves compute; saved activations / x-hat of the own row blocks stay in LDS; labels
+//     and the sentinel reset sit at the END of the entry, the slab sums' loads all in flight at once; 66 KB of LDS and 128 registers,
+//     so two workgroups of the launch (its dynamic LDS size is also the sweep units') still share a CU;
 //   * per-cell "dy is out" flags become arrival COUNTERS (every part adds 1 behind its exchange poll — whose returned load implies
 //     the wave's earlier stores were acknowledged — so no extra drain; target = NS * (step + 1)).
 // The arithmetic per row block is chain_body's (same products in the same even / odd MFMA chains, same reductions): every schedule
