@@ -19,7 +19,7 @@ Strong scaling of a SMALL population — what the search actually issues (models
                   L=4 confs per GPU (weak scaling; default 512: the "memory-bound cell-kernel stress")
 
 The default line (workload c1, no workload flags) ALSO carries the search-sized workloads, measured after the timed region:
-  N = 1: ``config.small_pop = {"c2": {...}, "c3": {...}, "c1_single": {...}}`` — one call of 16 / 50 sampled L=4 confs at the search
+  N = 1: ``config.small_pop = {"c2": {...}, "c3": {...}, "c1_single": {...}, "c1_pop6": {...}, "c1_pop12": {...}}`` — one call of 16 / 50 sampled L=4 confs at the search
          script's defaults (candidates/s, us per train step, schedule, nominal fraction of the HBM bound) and ONE conf-4 R=128
          candidate (train steps/s: SURVEY.md 8d C2);
   N > 1: ``config.strong = {"c2": {...}, "c3": {...}}`` — the same two calls sharded over the ranks by the engine's own policy
@@ -468,7 +468,8 @@ def main():
         small = {"c2": search_sized("c2", 16), "c3": search_sized("c3", 50)}
         # steps/s of the single found architecture — ONE conf-4 candidate (R=128, batchnorm, B=16), and the
         # share an 8-GPU search call leaves a rank at this R (6 candidates)
-        for name, K in (("c1_single", 1), ("c1_pop6", 6)):
+        # (round 6: and 12 — the smallest population of the two-group launches, whose chain blocks are chain_split parts too)
+        for name, K in (("c1_single", 1), ("c1_pop6", 6), ("c1_pop12", 12)):
             kargs = SimpleNamespace(**vars(args))
             kargs.engine_profile = not a.no_profile
             kconfs = [np.array(CONF4)] * K

@@ -101,14 +101,14 @@ def test_bench_single_gpu_line_carries_the_search_sized_workloads(dev):
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-9
     sp = line["config"]["small_pop"]
-    assert set(sp) == {"c2", "c3", "c1_single", "c1_pop6"}
+    assert set(sp) == {"c2", "c3", "c1_single", "c1_pop6", "c1_pop12"}
     assert sp["c2"]["candidates"] == 16 and sp["c2"]["schedule"]["persistent"] == 1 and sp["c2"]["populations_per_call"] == 1
     assert sp["c3"]["candidates"] == 50 and sp["c3"]["populations_per_call"] == 2          # two resident rounds
     for k in ("c2", "c3"):
         assert sp[k]["cand_per_s"] > 0 and sp[k]["us_per_train_step_incl_dev_eval"] > 0 and 0 < sp[k]["frac_of_hbm_bound"] < 1.5
     one = sp["c1_single"]
     assert one["candidates"] == 1 and one["train_steps_per_s"] > 0 and one["kernel_us_per_train_step"] > 0 and one["schedule"]["groups"] == -1
-    assert sp["c1_pop6"]["candidates"] == 6
+    assert sp["c1_pop6"]["candidates"] == 6 and sp["c1_pop12"]["candidates"] == 12 and sp["c1_pop12"]["schedule"]["groups"] == 2
 
 
 def test_bench_mmimdb_shaped_workload(dev):
